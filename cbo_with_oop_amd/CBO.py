@@ -1,0 +1,70 @@
+"""The four methods of the reference's agent that drive the hot path, as a mixin/standalone class
+(/root/reference/src/CBO.py:209-277).  The experiment loop, monitor, do-calculus and graph classes stay
+the reference's own (out of scope); INTEGRATION.md shows the two-line change that makes
+``src/CBO.py`` use this module.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .GaussianProcessFactory import GaussianProcessFactory as GPFactory
+from .utils_functions.utils import find_current_global, find_next_y_point
+
+
+class CBOAcquisitionPath:
+    """Holds exactly the state those methods read on the reference's ``CBO`` object: ``gp_type``,
+    ``exploration_set``, ``costs``, ``task``, per-set data, spaces, prior closures and models."""
+
+    def __init__(self, gp_type, exploration_set, costs, task, data_x, data_y, space_list, mean_functions=None,
+                 var_functions=None, grid_shapes=None):
+        self.gp_type = gp_type
+        self.exploration_set = exploration_set
+        self.es_size = len(exploration_set)
+        self.costs = costs
+        self.task = task
+        self.data_x, self.data_y = data_x, data_y
+        self.space_list = space_list
+        self.mean_functions = mean_functions or [None] * self.es_size
+        self.var_functions = var_functions or [None] * self.es_size
+        self.grid_shapes = grid_shapes or [None] * self.es_size
+        self.intervention_names = ["".join(v) for v in exploration_set]
+        self.models = []
+        self.last_intervention = None
+
+    def update_all_gaussian_processes(self):
+        """CBO.py:209-222."""
+        self.models = [
+            GPFactory.create(self.gp_type, self.data_x[s], self.data_y[s],
+                             [self.mean_functions[s], self.var_functions[s]], emukit_wrapper=True)
+            for s in range(self.es_size)
+        ]
+
+    def update_gaussian_process_of_last_intervention(self):
+        """CBO.py:224-235."""
+        s = self.last_intervention
+        self.models[s] = GPFactory.create(self.gp_type, self.data_x[s], self.data_y[s],
+                                          [self.mean_functions[s], self.var_functions[s]], emukit_wrapper=True)
+
+    def compute_best_acquisition_values(self, current_best):
+        """CBO.py:237-260."""
+        xs, ys = [], []
+        for s in range(len(self.exploration_set)):
+            y, x = find_next_y_point(self.space_list[s], self.models[s], current_best, self.exploration_set[s],
+                                     self.costs, task=self.task, grid_shape=self.grid_shapes[s])
+            ys.append(y)
+            xs.append(x)
+        return xs, ys
+
+    def current_best_solution(self, current_best_y):
+        """CBO.py:262-267 (the monitor's ``current_best_y`` dict is passed in)."""
+        return find_current_global(current_best_y, self.intervention_names, self.task)
+
+    def select_next_intervention(self, acquisition_ys):
+        """CBO.py:269-277: first index of the maximum."""
+        ys = np.asarray([np.asarray(y, dtype=np.float64).reshape(-1)[0] for y in acquisition_ys])
+        indices = int(np.where(ys == np.max(ys))[0][0])
+        self.last_intervention = indices
+        return self.exploration_set[indices], self.last_intervention
+
+    # BASELINE.json's north_star calls it select_intervention
+    select_intervention = select_next_intervention

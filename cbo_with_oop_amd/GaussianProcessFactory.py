@@ -1,0 +1,208 @@
+"""Host-side mirror of the reference's GP factory for the MI355X path.
+
+Same names, argument meaning and error behaviour as /root/reference/src/GaussianProcessFactory.py:9-73;
+the object ``create`` returns answers the calls the reference makes on a GPy ``GPRegression`` and on
+emukit's ``GPyModelWrapper`` around it, but every number comes from the HIP kernels
+behind libcbo_hip.so (include/cbo_hip.h).  There is no CPU implementation in this package.
+"""
+from __future__ import annotations
+
+import ctypes
+import warnings
+from enum import IntEnum
+
+import numpy as np
+
+from . import _lib
+
+
+class GaussianProcessType(IntEnum):
+    """src/GaussianProcessFactory.py:9-15."""
+    GRAPH_GP = 0
+    CAUSAL_GP = 1
+    NON_CAUSAL_GP = 2
+
+
+def _column(values, n, what):
+    """A reference closure returns (k,1) (DoCalculus.py:66); accept (k,), (k,1) or a scalar."""
+    v = np.asarray(values, dtype=np.float64)
+    if v.ndim == 0:
+        v = np.full(n, float(v))
+    v = np.ascontiguousarray(v.reshape(-1))
+    if v.shape[0] != n:
+        raise ValueError(f"{what} returned {v.shape[0]} values for {n} points")
+    return v
+
+
+class HipGaussianProcess:
+    """GP posterior resident on one MI355X.  Duck-types the two objects the reference uses:
+
+    * GPy ``GPRegression``: ``predict(Xnew)`` -> (mean (M,1), var (M,1)) with the Gaussian likelihood
+      noise included (used by src/DoCalculus.py:77), ``X``, ``Y``, ``set_XY``, ``optimize``.
+    * emukit ``GPyModelWrapper``: ``predict``, ``set_data`` (src/Monitor.py:160), ``optimize``
+      (src/CBO.py:173), ``X``, ``Y``, ``model``.
+    """
+
+    def __init__(self, x, y, *, variance=1.0, lengthscale=1.0, ard=False, noise_var=1e-10, mean_function=None,
+                 variance_adjustment=None, zero_diag=None, context=None):
+        if (mean_function is None) != (variance_adjustment is None):
+            raise ValueError("mean_function and variance_adjustment must be given together")
+        self._lib = _lib.load()
+        self._ctx = context if context is not None else _lib.Context.get()
+        self.mean_function = mean_function
+        self.variance_adjustment = variance_adjustment
+        self.causal = mean_function is not None
+        self.variance = float(variance)
+        self.noise_var = float(noise_var)
+        self.ard = bool(ard)
+        x = _lib.as_f64(x)
+        if x.ndim != 2:
+            raise ValueError("x must be (N, d)")
+        self.input_dim = x.shape[1]
+        ls = np.atleast_1d(np.asarray(lengthscale, dtype=np.float64))
+        if self.ard and ls.size == 1:
+            ls = np.full(self.input_dim, ls[0])
+        self.lengthscale = np.ascontiguousarray(ls)
+        # GPy's plain RBF takes the X2=None shortcut (zero diagonal distance); CausalRBF passes X2
+        # explicitly (causal_kernels.py:53-55)
+        self.zero_diag = (not self.causal) if zero_diag is None else bool(zero_diag)
+        self._handle = ctypes.c_void_p()
+        self._set_arrays(x, y)
+        pm, pv = self._prior(self.X)
+        _lib.check(self._lib.cbo_gp_create(
+            self._ctx.handle, 0, self.X.shape[0], self.input_dim, _lib.dptr(self.X), _lib.dptr(self._y_flat),
+            _lib.dptr(pm), _lib.dptr(pv), self.variance, _lib.dptr(self.lengthscale), int(self.ard), self.noise_var,
+            int(self.zero_diag), ctypes.byref(self._handle)))
+        self._fit()
+
+    # -- construction helpers ------------------------------------------------------------------
+    def _set_arrays(self, x, y):
+        x = _lib.as_f64(x)
+        y = _lib.as_f64(y)
+        if y.ndim == 1:
+            y = y[:, None]
+        if x.ndim != 2 or y.shape != (x.shape[0], 1):
+            raise ValueError(f"expected x (N,d) and y (N,1), got {x.shape} and {y.shape}")
+        if x.shape[1] != self.input_dim:
+            raise ValueError("input dimension changed")
+        self.X, self.Y = x, y
+        self._y_flat = np.ascontiguousarray(y[:, 0])
+
+    def _prior(self, pts):
+        if not self.causal:
+            return None, None
+        n = pts.shape[0]
+        return (_column(self.mean_function(pts), n, "mean_function"),
+                _column(self.variance_adjustment(pts), n, "variance_adjustment"))
+
+    def _fit(self):
+        tries = ctypes.c_int(0)
+        jitter = ctypes.c_double(0.0)
+        _lib.check(self._lib.cbo_gp_fit(self._handle, ctypes.byref(tries), ctypes.byref(jitter)))
+        self.jitter_tries, self.jitter = tries.value, jitter.value
+        if tries.value:
+            # GPy logs a warning when jitchol needed jitter
+            warnings.warn(f"Added jitter of {jitter.value:.10e}", RuntimeWarning, stacklevel=3)
+
+    # -- reference-facing API -------------------------------------------------------------------
+    @property
+    def model(self):
+        """emukit's wrapper exposes the GPy model as ``.model``; here they are the same object."""
+        return self
+
+    def predict(self, x, include_likelihood=True):
+        """(mean (M,1), var (M,1)); GP.predict / GPyModelWrapper.predict."""
+        x = _lib.as_f64(x)
+        if x.ndim != 2 or x.shape[1] != self.input_dim:
+            raise ValueError(f"x must be (M, {self.input_dim})")
+        m = x.shape[0]
+        pm, pv = self._prior(x)
+        mean = np.empty(m)
+        var = np.empty(m)
+        _lib.check(self._lib.cbo_gp_predict(self._handle, m, _lib.dptr(x), _lib.dptr(pm), _lib.dptr(pv),
+                                            int(include_likelihood), _lib.dptr(mean), _lib.dptr(var)))
+        return mean[:, None], var[:, None]
+
+    def predict_noiseless(self, x):
+        return self.predict(x, include_likelihood=False)
+
+    def set_data(self, X, Y):
+        """GPyModelWrapper.set_data -> GP.set_XY: replace the data and refit (src/Monitor.py:160)."""
+        self._set_arrays(X, Y)
+        pm, pv = self._prior(self.X)
+        _lib.check(self._lib.cbo_gp_set_data(self._handle, self.X.shape[0], _lib.dptr(self.X),
+                                             _lib.dptr(self._y_flat), _lib.dptr(pm), _lib.dptr(pv)))
+        tries = ctypes.c_int(0)
+        jitter = ctypes.c_double(0.0)
+        _lib.check(self._lib.cbo_gp_jitter(self._handle, ctypes.byref(tries), ctypes.byref(jitter)))
+        self.jitter_tries, self.jitter = tries.value, jitter.value
+
+    set_XY = set_data
+
+    def optimize(self, *args, **kwargs):
+        """Hyper-parameter MLE (emukit -> GPy optimize_restarts, src/CBO.py:173) is outside this round's
+        hot-path scope: the kernel keeps the reference's initial values."""
+        warnings.warn("HipGaussianProcess.optimize: hyper-parameter MLE is not part of the MI355X hot path yet; "
+                      "hyper-parameters are left unchanged", RuntimeWarning, stacklevel=2)
+
+    def get_prediction_gradients(self, x):
+        raise NotImplementedError("prediction gradients (SURVEY.md §8 f3) are not part of the grid-sweep path")
+
+    # -- posterior state (GPy: model.posterior.woodbury_chol / woodbury_vector) -------------------
+    def posterior_state(self):
+        n = self.X.shape[0]
+        L = np.empty((n, n))
+        alpha = np.empty(n)
+        _lib.check(self._lib.cbo_gp_get_posterior(self._handle, _lib.dptr(L), _lib.dptr(alpha)))
+        return L, alpha[:, None]
+
+    def assembled_Ky(self):
+        n = self.X.shape[0]
+        K = np.empty((n, n))
+        _lib.check(self._lib.cbo_gp_assemble_kxx(self._handle, _lib.dptr(K)))
+        return K
+
+    # -- lifetime ------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.cbo_gp_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GaussianProcessFactory:
+    """src/GaussianProcessFactory.py:18-73, same static methods."""
+
+    @staticmethod
+    def create(gp_type, x, y, parameters=None, emukit_wrapper=False):
+        gp_functions = {
+            GaussianProcessType.GRAPH_GP: GaussianProcessFactory.create_graph_gp,
+            GaussianProcessType.CAUSAL_GP: GaussianProcessFactory.create_causal_gp,
+            GaussianProcessType.NON_CAUSAL_GP: GaussianProcessFactory.create_non_causal_gp,
+        }
+        # emukit_wrapper only selected the wrapper class in the reference; HipGaussianProcess answers
+        # both interfaces, so the flag changes nothing here.
+        return gp_functions[gp_type](x, y, parameters)
+
+    @staticmethod
+    def create_graph_gp(x, y, parameters):
+        """:49-54  RBF(lengthscale=p[0], variance=p[1], ARD=p[3]), noise fixed to 1e-2 after construction."""
+        return HipGaussianProcess(x, y, variance=parameters[1], lengthscale=parameters[0], ard=parameters[3],
+                                  noise_var=1e-2)
+
+    @staticmethod
+    def create_non_causal_gp(x, y, _):
+        """:57-60  RBF(lengthscale=1, variance=1), noise 1e-10."""
+        return HipGaussianProcess(x, y, variance=1.0, lengthscale=1.0, noise_var=1e-10)
+
+    @staticmethod
+    def create_causal_gp(x, y, parameters):
+        """:63-73  CausalRBF(variance_adjustment=var_function) + mean function, noise 1e-10."""
+        mean_function, var_function = parameters
+        return HipGaussianProcess(x, y, variance=1.0, lengthscale=1.0, noise_var=1e-10,
+                                  mean_function=mean_function, variance_adjustment=var_function)

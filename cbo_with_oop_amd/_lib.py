@@ -1,0 +1,191 @@
+"""ctypes binding of libcbo_hip.so (include/cbo_hip.h).  No PyTorch, no fallback: if the shared
+library is missing, or no gfx950 GPU is visible when a context is requested, this raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("CBO_HIP_LIB", os.path.join(_HERE, "libcbo_hip.so"))
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int64_p = ctypes.POINTER(ctypes.c_int64)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+
+CBO_OK = 0
+CBO_ERR_INVALID = -1
+CBO_ERR_HIP = -2
+CBO_ERR_NOT_PD = -3
+CBO_ERR_NONPOS_DIAG = -4
+CBO_ERR_NOT_FITTED = -5
+CBO_ERR_UNSUPPORTED = -6
+CBO_ERR_NO_DEVICE = -7
+CBO_ERR_COMM = -8
+
+TASK_CODE = {"min": 0, "max": 1}
+
+
+class CboTimers(ctypes.Structure):
+    _fields_ = [("ms_kxx", ctypes.c_double), ("ms_chol", ctypes.c_double), ("ms_alpha", ctypes.c_double),
+                ("ms_kstar", ctypes.c_double), ("ms_trsm", ctypes.c_double), ("ms_acq", ctypes.c_double),
+                ("n_fit", ctypes.c_int64), ("n_sweep", ctypes.c_int64), ("n_trsm_launches", ctypes.c_int64),
+                ("trsm_flops", ctypes.c_double)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class CboHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libcbo_hip error {code}: {message}")
+        self.code = code
+
+
+# every exported symbol of include/cbo_hip.h: name -> (restype, argtypes)
+SIGNATURES = {
+    "cbo_abi_version": (ctypes.c_int, []),
+    "cbo_last_error": (ctypes.c_char_p, []),
+    "cbo_device_count": (ctypes.c_int, [c_int_p]),
+    "cbo_init": (ctypes.c_int, [ctypes.c_int, c_void_pp]),
+    "cbo_shutdown": (None, [ctypes.c_void_p]),
+    "cbo_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
+    "cbo_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "cbo_reset_timers": (ctypes.c_int, [ctypes.c_void_p]),
+    "cbo_get_timers": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(CboTimers)]),
+    "cbo_device_name": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]),
+    "cbo_gp_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_double_p,
+                                     c_double_p, c_double_p, c_double_p, ctypes.c_double, c_double_p, ctypes.c_int,
+                                     ctypes.c_double, ctypes.c_int, c_void_pp]),
+    "cbo_gp_destroy": (None, [ctypes.c_void_p]),
+    "cbo_gp_fit": (ctypes.c_int, [ctypes.c_void_p, c_int_p, c_double_p]),
+    "cbo_gp_set_data": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_double_p, c_double_p, c_double_p,
+                                       c_double_p]),
+    "cbo_gp_predict": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_double_p, c_double_p, c_double_p,
+                                      ctypes.c_int, c_double_p, c_double_p]),
+    "cbo_gp_get_posterior": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p]),
+    "cbo_gp_assemble_kxx": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
+    "cbo_gp_n": (ctypes.c_int64, [ctypes.c_void_p]),
+    "cbo_gp_jitter": (ctypes.c_int, [ctypes.c_void_p, c_int_p, c_double_p]),
+    "cbo_cands_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, c_double_p, c_double_p,
+                                        c_double_p, ctypes.c_int64, c_void_pp]),
+    "cbo_cands_destroy": (None, [ctypes.c_void_p]),
+    "cbo_acq_sweep": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_int,
+                                     ctypes.c_double, ctypes.c_double, c_double_p, c_double_p, c_double_p,
+                                     c_double_p, c_int64_p]),
+    "cbo_acq_sweep_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_double_p, c_double_p, c_double_p,
+                                          ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                          c_double_p, c_double_p, c_int64_p]),
+    "cbo_argmax_sets": (ctypes.c_int, [c_double_p, ctypes.c_int, c_int_p]),
+    "cbo_argmax_pairs": (ctypes.c_int, [c_double_p, c_int64_p, ctypes.c_int, c_double_p, c_int64_p]),
+    "cbo_selftest_mfma": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load libcbo_hip.so (once) and declare every prototype.  Raises if the library is missing."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    f"{LIB_PATH} not found: build it with `make -C cbo_with_oop_amd/csrc` (or "
+                    f"`python -c 'import __graft_entry__ as g; g.build()'`).  There is no CPU fallback.")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (restype, argtypes) in SIGNATURES.items():
+                fn = getattr(lib, name)       # AttributeError if the .so lacks a declared symbol
+                fn.restype = restype
+                fn.argtypes = argtypes
+            _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != CBO_OK:
+        msg = load().cbo_last_error()
+        raise_for(rc, msg.decode() if msg else "")
+
+
+def raise_for(rc, msg):
+    if rc in (CBO_ERR_NOT_PD, CBO_ERR_NONPOS_DIAG):
+        # GPy's jitchol raises numpy.linalg.LinAlgError (SURVEY.md §8b conventions)
+        raise np.linalg.LinAlgError(msg)
+    raise CboHipError(rc, msg)
+
+
+def dptr(a):
+    """float64 C-contiguous ndarray (or None) -> double*; the array must be kept alive by the caller."""
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_double_p)
+
+
+def as_f64(a, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class Context:
+    """One HIP device + stream (cbo_ctx).  Contexts are cached per device id."""
+    _cache = {}
+
+    def __init__(self, device_id=0):
+        lib = load()
+        h = ctypes.c_void_p()
+        check(lib.cbo_init(int(device_id), ctypes.byref(h)))
+        self.handle = h
+        self.device_id = int(device_id)
+
+    @classmethod
+    def get(cls, device_id=None):
+        if device_id is None:
+            device_id = int(os.environ.get("CBO_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            n = device_count()
+            if n > 0:
+                device_id %= n
+        ctx = cls._cache.get(device_id)
+        if ctx is None:
+            ctx = cls(device_id)
+            cls._cache[device_id] = ctx
+        return ctx
+
+    def synchronize(self):
+        check(load().cbo_synchronize(self.handle))
+
+    def set_profiling(self, enabled):
+        check(load().cbo_set_profiling(self.handle, int(bool(enabled))))
+
+    def reset_timers(self):
+        check(load().cbo_reset_timers(self.handle))
+
+    def timers(self):
+        t = CboTimers()
+        check(load().cbo_get_timers(self.handle, ctypes.byref(t)))
+        return t.as_dict()
+
+    def name(self):
+        buf = ctypes.create_string_buffer(256)
+        check(load().cbo_device_name(self.handle, buf, 256))
+        return buf.value.decode()
+
+    def selftest_mfma(self):
+        err = ctypes.c_double(-1.0)
+        check(load().cbo_selftest_mfma(self.handle, ctypes.byref(err)))
+        return err.value
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    check(load().cbo_device_count(ctypes.byref(n)))
+    return n.value

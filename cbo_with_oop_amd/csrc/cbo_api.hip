@@ -1,0 +1,706 @@
+// C-ABI host side of libcbo_hip.so (declared in include/cbo_hip.h): handle management, the jitchol
+// retry ladder, candidate chunking, profiling events.  All arithmetic of the path runs in the HIP
+// kernels of kernels_*.hip; there is no CPU fallback here.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cbo_internal.h"
+
+using namespace cbo;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(CBO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+enum Phase { PH_KXX = 0, PH_CHOL, PH_ALPHA, PH_KSTAR, PH_TRSM, PH_ACQ, PH_COUNT };
+
+struct EventPair {
+    hipEvent_t a, b;
+    int phase;
+};
+
+struct cbo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool profiling = false;
+    std::vector<EventPair> pending;
+    std::vector<hipEvent_t> pool;
+    cbo_timers timers{};
+    // sweep workspaces (grown on demand)
+    double *V = nullptr; size_t V_bytes = 0;
+    double *q = nullptr, *mu = nullptr, *mean = nullptr, *var = nullptr, *acq = nullptr; size_t vec_elems = 0;
+    double *part_val = nullptr; int64_t *part_idx = nullptr;
+    double *best_val = nullptr; int64_t *best_idx = nullptr;   // device
+    double *h_best_val = nullptr; int64_t *h_best_idx = nullptr; // pinned host
+    int *h_info = nullptr;
+    size_t max_ws_bytes = (size_t)4 << 30;
+    char name[128] = {0};
+};
+
+struct cbo_gp {
+    cbo_ctx *ctx = nullptr;
+    int64_t n = 0, n_pad = 0, lda = 0;
+    int d = 0;
+    PointSet X;                      // scaled SoA coordinates
+    double *raw = nullptr;           // staging for AoS upload (n*d)
+    double *y = nullptr, *ls_dev = nullptr;
+    std::vector<double> ls;          // per-dim lengthscales (ard) or single value
+    std::vector<double> h_pv;        // host copy of prior variance (diag check of jitchol)
+    KernelHyper h{};
+    double noise_var = 0.0;
+    double *A = nullptr;             // [n_pad][lda] Ky -> U, rhs strip at column n_pad
+    double *invDt = nullptr;         // [n_pad/16][16][16]
+    double *alpha = nullptr;         // [2*n_pad]
+    double *z = nullptr;             // [n_pad] contiguous copy of L^-1 r
+    int *info = nullptr;
+    bool fitted = false;
+    int tries = 0;
+    double jitter = 0.0;
+};
+
+struct cbo_cands {
+    cbo_ctx *ctx = nullptr;
+    int64_t m = 0, m_pad = 0;
+    int d = 0;
+    double *raw = nullptr;           // AoS (m,d) as uploaded
+    double *pm = nullptr, *pv = nullptr;
+    int64_t index_offset = 0;
+    // scaled view for the GP it was last prepared for
+    PointSet P;
+    const cbo_gp *prepared_for = nullptr;
+    std::vector<double> prepared_ls;
+};
+
+// ---- profiling helpers ---------------------------------------------------------------------------
+static hipEvent_t get_event(cbo_ctx *c)
+{
+    if (!c->pool.empty()) {
+        hipEvent_t e = c->pool.back();
+        c->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+struct PhaseScope {
+    cbo_ctx *c;
+    EventPair p{};
+    bool on;
+    PhaseScope(cbo_ctx *ctx, int phase) : c(ctx), on(ctx->profiling)
+    {
+        if (on) {
+            p.a = get_event(c);
+            p.b = get_event(c);
+            p.phase = phase;
+            hipEventRecord(p.a, c->stream);
+        }
+    }
+    ~PhaseScope()
+    {
+        if (on) {
+            hipEventRecord(p.b, c->stream);
+            c->pending.push_back(p);
+        }
+    }
+};
+
+static void resolve_events(cbo_ctx *c)
+{
+    if (c->pending.empty()) return;
+    hipStreamSynchronize(c->stream);
+    for (auto &p : c->pending) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, p.a, p.b);
+        switch (p.phase) {
+            case PH_KXX: c->timers.ms_kxx += ms; break;
+            case PH_CHOL: c->timers.ms_chol += ms; break;
+            case PH_ALPHA: c->timers.ms_alpha += ms; break;
+            case PH_KSTAR: c->timers.ms_kstar += ms; break;
+            case PH_TRSM: c->timers.ms_trsm += ms; break;
+            case PH_ACQ: c->timers.ms_acq += ms; break;
+        }
+        c->pool.push_back(p.a);
+        c->pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+
+// ---- context -------------------------------------------------------------------------------------
+extern "C" int cbo_abi_version(void) { return CBO_HIP_ABI_VERSION; }
+extern "C" const char *cbo_last_error(void) { return g_err.c_str(); }
+
+extern "C" int cbo_device_count(int *count_out)
+{
+    if (!count_out) return fail(CBO_ERR_INVALID, "count_out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count_out = n;
+    return CBO_OK;
+}
+
+extern "C" int cbo_init(int device_id, cbo_ctx **out)
+{
+    if (!out) return fail(CBO_ERR_INVALID, "out is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(CBO_ERR_NO_DEVICE, "no HIP device visible: libcbo_hip has no CPU fallback");
+    }
+    if (device_id < 0 || device_id >= n) return fail(CBO_ERR_INVALID, "device_id out of range");
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(CBO_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName +
+                                           ", this library carries gfx950 code objects only");
+    cbo_ctx *c = new cbo_ctx();
+    c->device = device_id;
+    std::snprintf(c->name, sizeof(c->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&c->part_val, 2048 * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->part_idx, 2048 * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(&c->best_val, sizeof(double)));
+    HIP_TRY(hipMalloc(&c->best_idx, sizeof(int64_t)));
+    HIP_TRY(hipHostMalloc(&c->h_best_val, sizeof(double)));
+    HIP_TRY(hipHostMalloc(&c->h_best_idx, sizeof(int64_t)));
+    HIP_TRY(hipHostMalloc(&c->h_info, sizeof(int)));
+    const char *ws = std::getenv("CBO_HIP_WORKSPACE_MB");
+    if (ws) c->max_ws_bytes = (size_t)std::atoll(ws) << 20;
+    *out = c;
+    return CBO_OK;
+}
+
+extern "C" void cbo_shutdown(cbo_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto e : c->pool) hipEventDestroy(e);
+    hipFree(c->V); hipFree(c->q); hipFree(c->mu); hipFree(c->mean); hipFree(c->var); hipFree(c->acq);
+    hipFree(c->part_val); hipFree(c->part_idx); hipFree(c->best_val); hipFree(c->best_idx);
+    hipHostFree(c->h_best_val); hipHostFree(c->h_best_idx); hipHostFree(c->h_info);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int cbo_synchronize(cbo_ctx *c)
+{
+    if (!c) return fail(CBO_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CBO_OK;
+}
+
+extern "C" int cbo_set_profiling(cbo_ctx *c, int enabled)
+{
+    if (!c) return fail(CBO_ERR_INVALID, "ctx is NULL");
+    c->profiling = enabled != 0;
+    return CBO_OK;
+}
+
+extern "C" int cbo_reset_timers(cbo_ctx *c)
+{
+    if (!c) return fail(CBO_ERR_INVALID, "ctx is NULL");
+    resolve_events(c);
+    c->timers = cbo_timers{};
+    return CBO_OK;
+}
+
+extern "C" int cbo_get_timers(cbo_ctx *c, cbo_timers *out)
+{
+    if (!c || !out) return fail(CBO_ERR_INVALID, "NULL argument");
+    resolve_events(c);
+    *out = c->timers;
+    return CBO_OK;
+}
+
+extern "C" int cbo_device_name(cbo_ctx *c, char *buf, int buflen)
+{
+    if (!c || !buf || buflen <= 0) return fail(CBO_ERR_INVALID, "NULL argument");
+    std::snprintf(buf, (size_t)buflen, "%s", c->name);
+    return CBO_OK;
+}
+
+// ---- GP ------------------------------------------------------------------------------------------
+static void free_gp_data(cbo_gp *g)
+{
+    hipFree(g->X.xs); hipFree(g->X.sq); hipFree(g->X.sv); hipFree(g->X.pm); hipFree(g->X.pv);
+    hipFree(g->raw); hipFree(g->y); hipFree(g->A); hipFree(g->invDt); hipFree(g->alpha); hipFree(g->z);
+    g->X = PointSet{};
+    g->raw = g->y = g->A = g->invDt = g->alpha = g->z = nullptr;
+}
+
+static int upload_gp_data(cbo_gp *g, int64_t n, const double *X, const double *y, const double *pm, const double *pv)
+{
+    cbo_ctx *c = g->ctx;
+    if (n <= 0 || !X || !y) return fail(CBO_ERR_INVALID, "n must be positive and X, y non-NULL");
+    if ((pm == nullptr) != (pv == nullptr))
+        return fail(CBO_ERR_INVALID, "prior mean and prior variance must be given together");
+    if (n > ((int64_t)1 << 30)) return fail(CBO_ERR_INVALID, "n too large");
+    const int64_t n_pad = round_up(n, kPadN);
+    if (n_pad != g->n_pad || (pv != nullptr) != (g->X.sv != nullptr)) {
+        free_gp_data(g);
+        g->n_pad = n_pad;
+        g->lda = n_pad + kRhsCols + kLdExtra;
+        HIP_TRY(hipMalloc(&g->X.xs, sizeof(double) * g->d * n_pad));
+        HIP_TRY(hipMalloc(&g->X.sq, sizeof(double) * n_pad));
+        if (pv) {
+            HIP_TRY(hipMalloc(&g->X.sv, sizeof(double) * n_pad));
+            HIP_TRY(hipMalloc(&g->X.pm, sizeof(double) * n_pad));
+            HIP_TRY(hipMalloc(&g->X.pv, sizeof(double) * n_pad));
+        }
+        HIP_TRY(hipMalloc(&g->raw, sizeof(double) * n_pad * g->d));
+        HIP_TRY(hipMalloc(&g->y, sizeof(double) * n_pad));
+        HIP_TRY(hipMalloc(&g->A, sizeof(double) * n_pad * g->lda));
+        HIP_TRY(hipMalloc(&g->invDt, sizeof(double) * (n_pad / 16) * 256));
+        HIP_TRY(hipMalloc(&g->alpha, sizeof(double) * 2 * n_pad));
+        HIP_TRY(hipMalloc(&g->z, sizeof(double) * n_pad));
+    }
+    g->n = n;
+    g->X.n = n; g->X.ld = n_pad; g->X.d = g->d;
+    g->fitted = false;
+    HIP_TRY(hipMemcpyAsync(g->raw, X, sizeof(double) * n * g->d, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(g->y, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    g->h_pv.clear();
+    if (pv) {
+        HIP_TRY(hipMemcpyAsync(g->X.pm, pm, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(g->X.pv, pv, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        g->h_pv.assign(pv, pv + n);
+    }
+    launch_prep_points(c->stream, g->raw, n, g->d, g->h.ard ? g->ls_dev : nullptr, pv ? g->X.pv : nullptr, g->X.xs,
+                       n_pad, g->X.sq, g->X.sv);
+    HIP_TRY(hipGetLastError());
+    // host buffers are the caller's: make sure the copies are done before returning
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CBO_OK;
+}
+
+extern "C" int cbo_gp_create(cbo_ctx *c, int dtype, int64_t n, int d, const double *X, const double *y,
+                             const double *pm, const double *pv, double variance, const double *lengthscale,
+                             int ard, double noise_var, int zero_diag, cbo_gp **out)
+{
+    if (!c || !out || !lengthscale) return fail(CBO_ERR_INVALID, "NULL argument");
+    if (dtype != CBO_DTYPE_F64) return fail(CBO_ERR_UNSUPPORTED, "only CBO_DTYPE_F64 is implemented");
+    if (d < 1 || d > CBO_MAX_DIM) return fail(CBO_ERR_INVALID, "d must be in [1, CBO_MAX_DIM]");
+    HIP_TRY(hipSetDevice(c->device));
+    cbo_gp *g = new cbo_gp();
+    g->ctx = c;
+    g->d = d;
+    g->noise_var = noise_var;
+    g->h.variance = variance;
+    g->h.ard = ard ? 1 : 0;
+    g->h.zero_diag = zero_diag ? 1 : 0;
+    g->h.lengthscale = ard ? 1.0 : lengthscale[0];
+    g->ls.assign(lengthscale, lengthscale + (ard ? d : 1));
+    if (hipMalloc(&g->info, sizeof(int)) != hipSuccess) { delete g; return fail(CBO_ERR_HIP, "hipMalloc info"); }
+    if (ard) {
+        if (hipMalloc(&g->ls_dev, sizeof(double) * d) != hipSuccess ||
+            hipMemcpy(g->ls_dev, lengthscale, sizeof(double) * d, hipMemcpyHostToDevice) != hipSuccess) {
+            cbo_gp_destroy(g);
+            return fail(CBO_ERR_HIP, "hipMalloc/hipMemcpy lengthscales");
+        }
+    }
+    const int rc = upload_gp_data(g, n, X, y, pm, pv);
+    if (rc != CBO_OK) { cbo_gp_destroy(g); return rc; }
+    *out = g;
+    return CBO_OK;
+}
+
+extern "C" void cbo_gp_destroy(cbo_gp *g)
+{
+    if (!g) return;
+    hipSetDevice(g->ctx->device);
+    hipStreamSynchronize(g->ctx->stream);
+    free_gp_data(g);
+    hipFree(g->info);
+    hipFree(g->ls_dev);
+    delete g;
+}
+
+extern "C" int64_t cbo_gp_n(const cbo_gp *g) { return g ? g->n : -1; }
+
+extern "C" int cbo_gp_jitter(const cbo_gp *g, int *tries_out, double *jitter_out)
+{
+    if (!g) return fail(CBO_ERR_INVALID, "gp is NULL");
+    if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
+    if (tries_out) *tries_out = g->tries;
+    if (jitter_out) *jitter_out = g->jitter;
+    return CBO_OK;
+}
+
+static void enqueue_factor(cbo_gp *g, double jitter)
+{
+    cbo_ctx *c = g->ctx;
+    {
+        PhaseScope ps(c, PH_KXX);
+        launch_kxx(c->stream, g->X, g->h, g->noise_var + kGpyDiagJitter, jitter, g->A, g->lda, g->n_pad);
+        launch_rhs(c->stream, g->y, g->X.pm, g->n, g->A, g->lda, g->n_pad);
+    }
+    {
+        PhaseScope ps(c, PH_CHOL);
+        launch_cholesky(c->stream, g->A, g->lda, g->n_pad, g->invDt, g->info);
+    }
+}
+
+extern "C" int cbo_gp_fit(cbo_gp *g, int *tries_out, double *jitter_out)
+{
+    if (!g) return fail(CBO_ERR_INVALID, "gp is NULL");
+    cbo_ctx *c = g->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    g->fitted = false;
+    // GPy util.linalg.jitchol: plain attempt, then mean(diag)*1e-6 jitter, x10 per retry, <= 5 retries.
+    double jitter = 0.0;
+    int tries = 0;
+    for (;;) {
+        enqueue_factor(g, jitter);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(c->h_info, g->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (*c->h_info == 0) break;
+        if (tries == 0) {
+            // diag of Ky as assembled (jitter-free): variance + v_i + (noise + 1e-8); the kernel's own
+            // diagonal differs from this only when zero_diag is off and |x|^2 rounds differently from
+            // x.x, i.e. by O(1e-16) relative -- irrelevant for a 1e-6 * mean(diag) jitter.
+            double sum = 0.0;
+            bool nonpos = false;
+            for (int64_t i = 0; i < g->n; ++i) {
+                const double dv = g->h.variance + (g->h_pv.empty() ? 0.0 : g->h_pv[i]) + (g->noise_var + kGpyDiagJitter);
+                if (!(dv > 0.0)) nonpos = true;
+                sum += dv;
+            }
+            if (nonpos) return fail(CBO_ERR_NONPOS_DIAG, "not pd: non-positive diagonal elements");
+            jitter = sum / (double)g->n * 1e-6;
+        } else {
+            jitter *= 10.0;
+        }
+        ++tries;
+        if (tries > 5 || !std::isfinite(jitter))
+            return fail(CBO_ERR_NOT_PD, "not positive definite, even with jitter.");
+    }
+    {
+        PhaseScope ps(c, PH_ALPHA);
+        launch_backsolve(c->stream, g->A, g->lda, g->n_pad, g->alpha);
+        // contiguous z for the sweep (alpha[n_pad..] held the working copy and is consumed by the solve)
+        HIP_TRY(hipMemcpy2DAsync(g->z, sizeof(double), g->A + g->n_pad, sizeof(double) * g->lda, sizeof(double),
+                                 (size_t)g->n_pad, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIP_TRY(hipGetLastError());
+    g->fitted = true;
+    g->tries = tries;
+    g->jitter = jitter;
+    if (c->profiling) c->timers.n_fit += 1;
+    if (tries_out) *tries_out = tries;
+    if (jitter_out) *jitter_out = jitter;
+    return CBO_OK;
+}
+
+extern "C" int cbo_gp_set_data(cbo_gp *g, int64_t n, const double *X, const double *y, const double *pm,
+                               const double *pv)
+{
+    if (!g) return fail(CBO_ERR_INVALID, "gp is NULL");
+    HIP_TRY(hipSetDevice(g->ctx->device));
+    HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    const int rc = upload_gp_data(g, n, X, y, pm, pv);
+    if (rc != CBO_OK) return rc;
+    return cbo_gp_fit(g, nullptr, nullptr);
+}
+
+extern "C" int cbo_gp_get_posterior(cbo_gp *g, double *L_out, double *alpha_out)
+{
+    if (!g) return fail(CBO_ERR_INVALID, "gp is NULL");
+    if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
+    cbo_ctx *c = g->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    if (L_out) {
+        double *tmp = nullptr;
+        HIP_TRY(hipMalloc(&tmp, sizeof(double) * g->n * g->n));
+        launch_export_lower(c->stream, g->A, g->lda, g->n, tmp);
+        hipError_t e = hipMemcpyAsync(L_out, tmp, sizeof(double) * g->n * g->n, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipFree(tmp);
+        HIP_TRY(e);
+    }
+    if (alpha_out) {
+        HIP_TRY(hipMemcpyAsync(alpha_out, g->alpha, sizeof(double) * g->n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return CBO_OK;
+}
+
+extern "C" int cbo_gp_assemble_kxx(cbo_gp *g, double *K_out)
+{
+    if (!g || !K_out) return fail(CBO_ERR_INVALID, "NULL argument");
+    cbo_ctx *c = g->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    double *Atmp = nullptr, *tmp = nullptr;
+    HIP_TRY(hipMalloc(&Atmp, sizeof(double) * g->n_pad * g->lda));
+    if (hipMalloc(&tmp, sizeof(double) * g->n * g->n) != hipSuccess) { hipFree(Atmp); return fail(CBO_ERR_HIP, "hipMalloc"); }
+    launch_kxx(c->stream, g->X, g->h, g->noise_var + kGpyDiagJitter, 0.0, Atmp, g->lda, g->n_pad);
+    launch_export_sym(c->stream, Atmp, g->lda, g->n, tmp);
+    hipError_t e = hipMemcpyAsync(K_out, tmp, sizeof(double) * g->n * g->n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(Atmp);
+    hipFree(tmp);
+    HIP_TRY(e);
+    return CBO_OK;
+}
+
+// ---- candidates ----------------------------------------------------------------------------------
+extern "C" int cbo_cands_create(cbo_ctx *c, int64_t m, int d, const double *Xs, const double *pm, const double *pv,
+                                int64_t index_offset, cbo_cands **out)
+{
+    if (!c || !out || !Xs) return fail(CBO_ERR_INVALID, "NULL argument");
+    if (m <= 0) return fail(CBO_ERR_INVALID, "m must be positive");
+    if (d < 1 || d > CBO_MAX_DIM) return fail(CBO_ERR_INVALID, "d must be in [1, CBO_MAX_DIM]");
+    if ((pm == nullptr) != (pv == nullptr))
+        return fail(CBO_ERR_INVALID, "prior mean and prior variance must be given together");
+    HIP_TRY(hipSetDevice(c->device));
+    cbo_cands *k = new cbo_cands();
+    k->ctx = c; k->m = m; k->d = d; k->index_offset = index_offset;
+    k->m_pad = round_up(m, kStrip);
+    hipError_t e = hipMalloc(&k->raw, sizeof(double) * m * d);
+    if (e == hipSuccess) e = hipMalloc(&k->P.xs, sizeof(double) * d * k->m_pad);
+    if (e == hipSuccess) e = hipMalloc(&k->P.sq, sizeof(double) * k->m_pad);
+    if (e == hipSuccess && pv) e = hipMalloc(&k->P.sv, sizeof(double) * k->m_pad);
+    if (e == hipSuccess && pv) e = hipMalloc(&k->pm, sizeof(double) * k->m_pad);
+    if (e == hipSuccess && pv) e = hipMalloc(&k->pv, sizeof(double) * k->m_pad);
+    if (e == hipSuccess) e = hipMemcpyAsync(k->raw, Xs, sizeof(double) * m * d, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && pv) e = hipMemcpyAsync(k->pm, pm, sizeof(double) * m, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && pv) e = hipMemcpyAsync(k->pv, pv, sizeof(double) * m, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        cbo_cands_destroy(k);
+        return fail(CBO_ERR_HIP, std::string("cbo_cands_create: ") + hipGetErrorString(e));
+    }
+    k->P.n = m; k->P.ld = k->m_pad; k->P.d = d;
+    *out = k;
+    return CBO_OK;
+}
+
+extern "C" void cbo_cands_destroy(cbo_cands *k)
+{
+    if (!k) return;
+    hipSetDevice(k->ctx->device);
+    hipStreamSynchronize(k->ctx->stream);
+    hipFree(k->raw); hipFree(k->pm); hipFree(k->pv);
+    hipFree(k->P.xs); hipFree(k->P.sq); hipFree(k->P.sv);
+    delete k;
+}
+
+static int ensure_workspaces(cbo_ctx *c, int64_t n_pad, int64_t m_pad, int64_t *chunk_cols, int64_t *ldv)
+{
+    // V chunk: as many 64-column strips as fit the workspace budget (at least one strip).
+    int64_t cols = m_pad;
+    const int64_t max_cols = (int64_t)(c->max_ws_bytes / (sizeof(double) * (size_t)n_pad)) / kStrip * kStrip;
+    if (cols > max_cols) cols = max_cols < kStrip ? kStrip : max_cols;
+    const int64_t ld = cols + kLdExtra;
+    const size_t need = sizeof(double) * (size_t)n_pad * (size_t)ld;
+    if (need > c->V_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->V);
+        c->V = nullptr; c->V_bytes = 0;
+        HIP_TRY(hipMalloc(&c->V, need));
+        c->V_bytes = need;
+    }
+    if ((size_t)m_pad > c->vec_elems) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->q); hipFree(c->mu); hipFree(c->mean); hipFree(c->var); hipFree(c->acq);
+        c->q = c->mu = c->mean = c->var = c->acq = nullptr; c->vec_elems = 0;
+        HIP_TRY(hipMalloc(&c->q, sizeof(double) * m_pad));
+        HIP_TRY(hipMalloc(&c->mu, sizeof(double) * m_pad));
+        HIP_TRY(hipMalloc(&c->mean, sizeof(double) * m_pad));
+        HIP_TRY(hipMalloc(&c->var, sizeof(double) * m_pad));
+        HIP_TRY(hipMalloc(&c->acq, sizeof(double) * m_pad));
+        c->vec_elems = (size_t)m_pad;
+    }
+    *chunk_cols = cols;
+    *ldv = ld;
+    return CBO_OK;
+}
+
+// Scale / transpose the candidate coordinates for this GP's lengthscales (GPy ARD divides the inputs).
+static int prepare_cands(cbo_gp *g, cbo_cands *k)
+{
+    cbo_ctx *c = g->ctx;
+    if (k->prepared_for == g && k->prepared_ls == g->ls) return CBO_OK;
+    launch_prep_points(c->stream, k->raw, k->m, k->d, g->h.ard ? g->ls_dev : nullptr, k->pv, k->P.xs, k->m_pad,
+                       k->P.sq, k->P.sv);
+    HIP_TRY(hipGetLastError());
+    k->prepared_for = g;
+    k->prepared_ls = g->ls;
+    return CBO_OK;
+}
+
+// q = colsum((L^-1 K*)^2), mu = (L^-1 K*)^T z for all candidates, chunk by chunk.
+static int enqueue_posterior(cbo_gp *g, cbo_cands *k)
+{
+    cbo_ctx *c = g->ctx;
+    int rc = prepare_cands(g, k);
+    if (rc != CBO_OK) return rc;
+    int64_t chunk = 0, ldv = 0;
+    rc = ensure_workspaces(c, g->n_pad, k->m_pad, &chunk, &ldv);
+    if (rc != CBO_OK) return rc;
+    for (int64_t c0 = 0; c0 < k->m_pad; c0 += chunk) {
+        const int64_t cols = (k->m_pad - c0 < chunk) ? (k->m_pad - c0) : chunk;
+        {
+            PhaseScope ps(c, PH_KSTAR);
+            launch_kstar(c->stream, g->X, k->P, c0, cols, g->h, c->V, ldv, g->n_pad);
+        }
+        {
+            PhaseScope ps(c, PH_TRSM);
+            launch_trsm_strips(c->stream, g->A, g->lda, g->invDt, c->V, ldv, g->n_pad, cols, g->z, 1, c->q + c0,
+                               c->mu + c0);
+        }
+        if (c->profiling) {
+            c->timers.n_trsm_launches += 1;
+            c->timers.trsm_flops += (double)g->n_pad * (double)g->n_pad * (double)cols;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return CBO_OK;
+}
+
+extern "C" int cbo_acq_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task, double ei_jitter, double cost,
+                             double *acq_out, double *mean_out, double *var_out, double *best_val, int64_t *best_idx)
+{
+    if (!g || !k) return fail(CBO_ERR_INVALID, "NULL argument");
+    if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
+    if (g->ctx != k->ctx) return fail(CBO_ERR_INVALID, "gp and candidates live on different contexts");
+    if (g->d != k->d) return fail(CBO_ERR_INVALID, "gp and candidates have different dimensions");
+    if ((g->X.sv != nullptr) && (k->pv == nullptr))
+        return fail(CBO_ERR_INVALID, "causal gp needs candidate prior mean/variance");
+    if (task != CBO_TASK_MIN && task != CBO_TASK_MAX) return fail(CBO_ERR_INVALID, "task must be 0 (min) or 1 (max)");
+    cbo_ctx *c = g->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = enqueue_posterior(g, k);
+    if (rc != CBO_OK) return rc;
+    const bool causal = g->X.sv != nullptr;
+    AcqParams p;
+    p.variance = g->h.variance; p.noise_var = g->noise_var; p.y_best = y_best; p.ei_jitter = ei_jitter; p.cost = cost;
+    p.task = task; p.include_noise = 1; p.want_ei = 1;
+    const int nb = acq_blocks_for(k->m);
+    {
+        PhaseScope ps(c, PH_ACQ);
+        launch_acq(c->stream, c->q, c->mu, causal ? k->pm : nullptr, causal ? k->pv : nullptr, k->m, p,
+                   mean_out ? c->mean : nullptr, var_out ? c->var : nullptr, acq_out ? c->acq : nullptr, c->part_val,
+                   c->part_idx, k->index_offset, nb);
+        launch_argmax_final(c->stream, c->part_val, c->part_idx, nb, c->best_val, c->best_idx);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->h_best_val, c->best_val, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_best_idx, c->best_idx, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    if (acq_out) HIP_TRY(hipMemcpyAsync(acq_out, c->acq, sizeof(double) * k->m, hipMemcpyDeviceToHost, c->stream));
+    if (mean_out) HIP_TRY(hipMemcpyAsync(mean_out, c->mean, sizeof(double) * k->m, hipMemcpyDeviceToHost, c->stream));
+    if (var_out) HIP_TRY(hipMemcpyAsync(var_out, c->var, sizeof(double) * k->m, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (best_val) *best_val = *c->h_best_val;
+    if (best_idx) *best_idx = *c->h_best_idx;
+    if (c->profiling) c->timers.n_sweep += 1;
+    return CBO_OK;
+}
+
+extern "C" int cbo_acq_sweep_host(cbo_gp *g, int64_t m, const double *Xs, const double *pm, const double *pv,
+                                  double y_best, int task, double ei_jitter, double cost, double *acq_out,
+                                  double *best_val, int64_t *best_idx)
+{
+    if (!g) return fail(CBO_ERR_INVALID, "gp is NULL");
+    cbo_cands *k = nullptr;
+    int rc = cbo_cands_create(g->ctx, m, g->d, Xs, pm, pv, 0, &k);
+    if (rc != CBO_OK) return rc;
+    rc = cbo_acq_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, nullptr, nullptr, best_val, best_idx);
+    cbo_cands_destroy(k);
+    return rc;
+}
+
+extern "C" int cbo_gp_predict(cbo_gp *g, int64_t m, const double *Xs, const double *pm, const double *pv,
+                              int include_noise, double *mean_out, double *var_out)
+{
+    if (!g || !mean_out || !var_out) return fail(CBO_ERR_INVALID, "NULL argument");
+    if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
+    const bool causal = g->X.sv != nullptr;
+    if (causal && (!pm || !pv)) return fail(CBO_ERR_INVALID, "causal gp needs candidate prior mean/variance");
+    cbo_ctx *c = g->ctx;
+    cbo_cands *k = nullptr;
+    int rc = cbo_cands_create(c, m, g->d, Xs, causal ? pm : nullptr, causal ? pv : nullptr, 0, &k);
+    if (rc != CBO_OK) return rc;
+    rc = enqueue_posterior(g, k);
+    if (rc == CBO_OK) {
+        AcqParams p;
+        p.variance = g->h.variance; p.noise_var = g->noise_var; p.y_best = 0.0; p.ei_jitter = 0.0; p.cost = 1.0;
+        p.task = CBO_TASK_MIN; p.include_noise = include_noise ? 1 : 0; p.want_ei = 0;
+        {
+            PhaseScope ps(c, PH_ACQ);
+            launch_acq(c->stream, c->q, c->mu, k->pm, k->pv, m, p, c->mean, c->var, nullptr, c->part_val, c->part_idx,
+                       0, acq_blocks_for(m));
+        }
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(mean_out, c->mean, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(var_out, c->var, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(CBO_ERR_HIP, std::string("cbo_gp_predict: ") + hipGetErrorString(e));
+        if (c->profiling) c->timers.n_sweep += 1;
+    }
+    cbo_cands_destroy(k);
+    return rc;
+}
+
+// ---- tiny host-side reductions -------------------------------------------------------------------
+static bool host_better(double va, int64_t ia, double vb, int64_t ib)
+{
+    const bool na = std::isnan(va), nb = std::isnan(vb);
+    if (na != nb) return na;
+    if (na || va == vb) return ia < ib;
+    return va > vb;
+}
+
+extern "C" int cbo_argmax_sets(const double *ys, int s, int *idx_out)
+{
+    if (!ys || !idx_out || s <= 0) return fail(CBO_ERR_INVALID, "bad argument");
+    // np.where(ys == np.max(ys))[0][0]  (src/CBO.py:275): np.max propagates NaN, and NaN == NaN is
+    // false, so the reference raises IndexError there; we report the first NaN instead.
+    int best = 0;
+    for (int i = 1; i < s; ++i)
+        if (host_better(ys[i], i, ys[best], best)) best = i;
+    *idx_out = best;
+    return CBO_OK;
+}
+
+extern "C" int cbo_argmax_pairs(const double *vals, const int64_t *idxs, int n, double *best_val, int64_t *best_idx)
+{
+    if (!vals || !idxs || n <= 0 || !best_val || !best_idx) return fail(CBO_ERR_INVALID, "bad argument");
+    int b = 0;
+    for (int i = 1; i < n; ++i)
+        if (host_better(vals[i], idxs[i], vals[b], idxs[b])) b = i;
+    *best_val = vals[b];
+    *best_idx = idxs[b];
+    return CBO_OK;
+}
+
+extern "C" int cbo_selftest_mfma(cbo_ctx *c, double *max_abs_err_out)
+{
+    if (!c) return fail(CBO_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    double err = -1.0;
+    if (run_mfma_selftest(c->stream, &err) != 0) return fail(CBO_ERR_HIP, "mfma selftest launch failed");
+    if (max_abs_err_out) *max_abs_err_out = err;
+    if (err != 0.0) return fail(CBO_ERR_HIP, "fp64 MFMA lane map differs from what the kernels assume");
+    return CBO_OK;
+}

@@ -1,0 +1,92 @@
+// Internal declarations shared by the kernel translation units and the C-ABI host code.
+// gfx950 (MI355X / CDNA4) only: 64-lane wavefronts, v_mfma_f64_16x16x4_f64, 160 KiB LDS per CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+#include "cbo_hip.h"
+
+namespace cbo {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// ---- data layout in HBM ------------------------------------------------------
+// * Points: SoA, coordinate k of point i at xs[k * ld + i]; squared norms sq[i]; sqrt(v(x_i)) sv[i].
+// * Ky and its Cholesky factor share one row-major buffer A[n_pad][lda].  Only the UPPER triangle is
+//   meaningful: Ky = U^T U, U[k][i] = L[i][k].  A right-hand-side strip of 64 columns sits at column
+//   n_pad; its first column carries r = y - m(X) and is overwritten by z = L^-1 r during the
+//   factorisation.  n_pad = round_up(n, 128); padded rows/cols form an identity block.
+// * invDt[b] (b = 16-row block index) holds inv(U_bb) row-major, i.e. invDt[b][k][i] = inv(L_bb)[i][k].
+// * V workspace [n_pad][ldv]: K(X, X*) for a chunk of candidates, overwritten by L^-1 K*.
+constexpr int kPadN = 128;       // n_pad granularity
+constexpr int kStrip = 64;       // candidate columns per workgroup strip
+constexpr int kRhsCols = 64;     // width of the right-hand-side strip appended to A
+constexpr int kLdExtra = 16;     // extra doubles per row so consecutive rows fall in different channels
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// GPy constants (GPy 1.10.0 exact_gaussian_inference.py / posterior.py); see oracle/gp_oracle.py.
+constexpr double kGpyDiagJitter = 1e-8;
+constexpr double kGpyVarClip = 1e-15;
+
+struct PointSet {            // device-resident SoA point set
+    double *xs = nullptr;    // [d][ld]
+    double *sq = nullptr;    // [ld]
+    double *sv = nullptr;    // [ld] sqrt(prior variance) or nullptr
+    double *pm = nullptr;    // [ld] prior mean or nullptr
+    double *pv = nullptr;    // [ld] prior variance (raw) or nullptr
+    int64_t n = 0, ld = 0;
+    int d = 0;
+};
+
+struct KernelHyper {
+    double variance;
+    double lengthscale;      // isotropic lengthscale (distance divided after sqrt); 1.0 when ard
+    int ard;                 // inputs were pre-scaled per dimension
+    int zero_diag;           // GPy X2=None shortcut: r2[i][i] = 0
+};
+
+// ---- kernel launchers (kernels_*.hip) -----------------------------------------------------------
+// AoS (n,d) raw -> SoA (optionally divided by per-dim lengthscale), squared norms, sqrt(v).
+void launch_prep_points(hipStream_t s, const double *raw_aos, int64_t n, int d, const double *ls_dev /*d or null*/,
+                        const double *pv_raw /*n or null*/, double *xs, int64_t ld, double *sq, double *sv);
+
+// K(X,X) + diag into the upper 64x64 tiles of A (identity on the padding), and the rhs strip.
+void launch_kxx(hipStream_t s, const PointSet &X, const KernelHyper &h, double diag_add, double jitter,
+                double *A, int64_t lda, int64_t n_pad);
+void launch_rhs(hipStream_t s, const double *y, const double *pm, int64_t n, double *A, int64_t lda, int64_t n_pad);
+// K(X, X*) for candidate columns [c_begin, c_begin + m_pad) into V (rows >= n are zero).
+void launch_kstar(hipStream_t s, const PointSet &X, const PointSet &C, int64_t c_begin, int64_t m_pad,
+                  const KernelHyper &h, double *V, int64_t ldv, int64_t n_pad);
+
+// Recursive blocked Cholesky (upper) of A[0:n_pad, 0:n_pad] incl. forward solve of the rhs strip.
+void launch_cholesky(hipStream_t s, double *A, int64_t lda, int64_t n_pad, double *invDt, int *info_dev);
+// alpha = U^-1 z  (z = first rhs column of A).
+void launch_backsolve(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, double *alpha);
+
+// V <- L^-1 V on m_pad columns (64-column strips); optional q[c] = sum_i V[i][c]^2, mu[c] = sum_i V[i][c] z[i].
+void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const double *invDt, double *V, int64_t ldv,
+                        int64_t n, int64_t m_pad, const double *z, int64_t z_stride, double *q, double *mu);
+
+struct AcqParams {
+    double variance, noise_var, y_best, ei_jitter, cost;
+    int task, include_noise, want_ei;
+};
+// var = clip(kss - q) (+ noise), mean = mu + m(X*), acq = +-EI / cost; per-block arg-max partials.
+void launch_acq(hipStream_t s, const double *q, const double *mu, const double *pm, const double *pv, int64_t m,
+                const AcqParams &p, double *mean_out, double *var_out, double *acq_out, double *part_val,
+                int64_t *part_idx, int64_t index_offset, int n_blocks);
+void launch_argmax_final(hipStream_t s, const double *part_val, const int64_t *part_idx, int n, double *best_val,
+                         int64_t *best_idx);
+int acq_blocks_for(int64_t m);
+
+void launch_gather_diag(hipStream_t s, const double *A, int64_t lda, int64_t n, double *diag);
+void launch_export_lower(hipStream_t s, const double *A, int64_t lda, int64_t n, double *L_rowmajor);
+void launch_export_sym(hipStream_t s, const double *A, int64_t lda, int64_t n, double *K_rowmajor);
+
+int run_mfma_selftest(hipStream_t s, double *max_err);
+
+}  // namespace cbo

@@ -1,0 +1,143 @@
+// Posterior epilogue + causal Expected Improvement / cost + arg-max for gfx950.
+//
+// Restates, element by element:
+//   GPy Posterior._raw_predict / GP.predict:  var = clip(Kdiag - q, 1e-15, inf) (+ noise), mean = mu + m(X*)
+//   CausalRBF.Kdiag                           /root/reference/src/utils_functions/causal_kernels.py:64-79
+//   CausalExpectedImprovement.evaluate        /root/reference/src/utils_functions/causal_acquisition_functions.py:27-43
+//   get_standard_normal_pdf_cdf               ... :77-88   (scipy.stats.norm.pdf / .cdf = cephes ndtr)
+//   emukit Quotient with Cost.evaluate        /root/reference/src/utils_functions/cost_functions.py:11-17
+//   top-1 selection (argsort()[::-1][:1] generalised; lowest index wins ties, NaN is maximal as in
+//   numpy.argmax)                             /root/reference/src/utils_functions/causal_optimizer.py:52-55
+// HBM-bound and tiny next to the TRSM: 2-4 doubles in, up to 3 out per candidate.  The arg-max is a
+// wavefront shuffle reduction, one partial per workgroup, then one 256-thread finishing block.
+#include "cbo_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace cbo {
+
+// scipy.special.ndtr (cephes ndtr.c): 0.5 erfc(-x/sqrt2) split at |x/sqrt2| < sqrt(1/2).
+__device__ __forceinline__ double ndtr(double a)
+{
+    const double SQRTH = 7.07106781186547524401E-1;
+    if (isnan(a)) return a;
+    const double x = a * SQRTH;
+    const double zabs = fabs(x);
+    double y;
+    if (zabs < SQRTH) {
+        y = 0.5 + 0.5 * erf(x);
+    } else {
+        y = 0.5 * erfc(zabs);
+        if (x > 0) y = 1.0 - y;
+    }
+    return y;
+}
+
+__device__ __forceinline__ bool better(double va, int64_t ia, double vb, int64_t ib)
+{
+    // true when (va, ia) beats (vb, ib): larger value, NaN maximal, lowest index on ties
+    const bool na = isnan(va), nb = isnan(vb);
+    if (na != nb) return na;
+    if (na || va == vb) return ia < ib;
+    return va > vb;
+}
+
+__device__ __forceinline__ void wave_argmax(double &v, int64_t &i)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_down(v, off);
+        const int64_t oi = __shfl_down(i, off);
+        if (better(ov, oi, v, i)) { v = ov; i = oi; }
+    }
+}
+
+__device__ __forceinline__ void block_argmax(double v, int64_t i, double *out_v, int64_t *out_i)
+{
+    __shared__ double sv[4];
+    __shared__ int64_t si[4];
+    wave_argmax(v, i);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sv[wave] = v; si[wave] = i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double bv = sv[0];
+        int64_t bi = si[0];
+        for (int w = 1; w < 4; ++w)
+            if (better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; }
+        *out_v = bv;
+        *out_i = bi;
+    }
+}
+
+constexpr int64_t kNoIndex = INT64_MAX;
+
+__global__ __launch_bounds__(256) void acq_kernel(const double *__restrict__ q, const double *__restrict__ mu,
+                                                  const double *__restrict__ pm, const double *__restrict__ pv,
+                                                  int64_t m, AcqParams p, double *__restrict__ mean_out,
+                                                  double *__restrict__ var_out, double *__restrict__ acq_out,
+                                                  double *__restrict__ part_val, int64_t *__restrict__ part_idx,
+                                                  int64_t index_offset)
+{
+    double bv = -INFINITY;
+    int64_t bi = kNoIndex;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < m; c += (int64_t)gridDim.x * blockDim.x) {
+        const double kss = pv ? (p.variance + pv[c]) : p.variance;     // Kdiag
+        double var = kss - q[c];
+        var = (var < kGpyVarClip) ? kGpyVarClip : var;                  // np.clip(var, 1e-15, inf); NaN stays NaN
+        if (p.include_noise) var = var + p.noise_var;                   // Gaussian likelihood predictive_values
+        double mean = mu[c];
+        if (pm) mean = mean + pm[c];                                    // GP._raw_predict: mu += mean_function.f(Xnew)
+        if (mean_out) mean_out[c] = mean;
+        if (var_out) var_out[c] = var;
+        if (p.want_ei) {
+            const double s = sqrt(var);
+            const double mj = mean + p.ei_jitter;
+            const double u = (p.y_best - mj) / s;
+            const double pdf = exp(-(u * u) / 2.0) / 2.5066282746310002;   // scipy _norm_pdf: exp(-x**2/2)/sqrt(2 pi)
+            const double cdf = ndtr(u);
+            double imp = s * (u * cdf + pdf);
+            if (p.task != CBO_TASK_MIN) imp = -imp;
+            const double acq = imp / p.cost;
+            if (acq_out) acq_out[c] = acq;
+            const int64_t gi = c + index_offset;
+            if (better(acq, gi, bv, bi)) { bv = acq; bi = gi; }
+        }
+    }
+    if (p.want_ei) block_argmax(bv, bi, &part_val[blockIdx.x], &part_idx[blockIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restrict__ part_val,
+                                                           const int64_t *__restrict__ part_idx, int n,
+                                                           double *__restrict__ best_val, int64_t *__restrict__ best_idx)
+{
+    double bv = -INFINITY;
+    int64_t bi = kNoIndex;
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        if (better(part_val[i], part_idx[i], bv, bi)) { bv = part_val[i]; bi = part_idx[i]; }
+    block_argmax(bv, bi, best_val, best_idx);
+}
+
+int acq_blocks_for(int64_t m)
+{
+    int64_t b = (m + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+void launch_acq(hipStream_t s, const double *q, const double *mu, const double *pm, const double *pv, int64_t m,
+                const AcqParams &p, double *mean_out, double *var_out, double *acq_out, double *part_val,
+                int64_t *part_idx, int64_t index_offset, int n_blocks)
+{
+    hipLaunchKernelGGL(acq_kernel, dim3(n_blocks), dim3(256), 0, s, q, mu, pm, pv, m, p, mean_out, var_out, acq_out,
+                       part_val, part_idx, index_offset);
+}
+
+void launch_argmax_final(hipStream_t s, const double *part_val, const int64_t *part_idx, int n, double *best_val,
+                         int64_t *best_idx)
+{
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, s, part_val, part_idx, n, best_val, best_idx);
+}
+
+}  // namespace cbo

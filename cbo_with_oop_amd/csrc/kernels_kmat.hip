@@ -1,0 +1,277 @@
+// Kernel-matrix assembly for gfx950: K(X,X) (+ diagonal, identity padding) and K(X,X*).
+//
+// Arithmetic restates GPy's Stationary._unscaled_dist / _scaled_dist and the reference's
+// CausalRBF.K (/root/reference/src/utils_functions/causal_kernels.py:45-62) operation by operation
+// (GEMM-trick distance, clip at 0, sqrt, divide by the lengthscale, square again, exp, rank-1 term)
+// so that the only differences from the numpy path are the exp() implementation and the dot-product
+// association inside BLAS.  Contraction into FMAs is therefore switched off in this file except
+// where the reference itself goes through BLAS (the dot product).
+//
+// Roofline: HBM-write bound.  One 64x64 output tile per 256-thread workgroup, tile coordinates
+// staged in LDS, 16-byte coalesced stores (each wave writes 2 rows x 512 B per instruction).
+#include "cbo_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace cbo {
+
+// ------------------------------------------------------------------------------------------------
+// AoS -> SoA, optional per-dimension scaling (GPy ARD: X / lengthscale), squared norms exactly as
+// numpy's np.sum(np.square(X), 1) forms them (sequential for d < 8, the 8-way pairwise tree at d = 8).
+__global__ __launch_bounds__(256) void prep_points_kernel(const double *__restrict__ raw, int64_t n, int d,
+                                                          const double *__restrict__ ls,
+                                                          const double *__restrict__ pv,
+                                                          double *__restrict__ xs, int64_t ld,
+                                                          double *__restrict__ sq, double *__restrict__ sv)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ld) return;
+    double x[CBO_MAX_DIM];
+#pragma unroll
+    for (int k = 0; k < CBO_MAX_DIM; ++k) x[k] = 0.0;
+    if (i < n) {
+#pragma unroll
+        for (int k = 0; k < CBO_MAX_DIM; ++k)
+            if (k < d) {
+                double v = raw[i * d + k];
+                if (ls) v = v / ls[k];
+                x[k] = v;
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < CBO_MAX_DIM; ++k)
+        if (k < d) xs[(int64_t)k * ld + i] = x[k];
+    double s;
+    if (d == 8) {
+        double r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = __dmul_rn(x[k], x[k]);
+        s = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])),
+                      __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
+    } else {
+        s = 0.0;
+#pragma unroll
+        for (int k = 0; k < CBO_MAX_DIM; ++k)
+            if (k < d) s = __dadd_rn(s, __dmul_rn(x[k], x[k]));
+    }
+    sq[i] = s;
+    if (sv) sv[i] = (i < n && pv) ? sqrt(pv[i]) : 0.0;
+}
+
+void launch_prep_points(hipStream_t s, const double *raw_aos, int64_t n, int d, const double *ls_dev,
+                        const double *pv_raw, double *xs, int64_t ld, double *sq, double *sv)
+{
+    const int threads = 256;
+    const int blocks = (int)((ld + threads - 1) / threads);
+    hipLaunchKernelGGL(prep_points_kernel, dim3(blocks), dim3(threads), 0, s, raw_aos, n, d, ls_dev, pv_raw, xs, ld,
+                       sq, sv);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One kernel-matrix element, GPy operation order.
+template <int D>
+__device__ __forceinline__ double kernel_value(const double *xi, const double *xj, double sqi, double sqj,
+                                               double variance, double lengthscale, bool force_zero)
+{
+    // np.dot(X, X2.T): BLAS accumulates a_k*b_k with FMAs from a zero accumulator.
+    double dot = __dmul_rn(xi[0], xj[0]);
+#pragma unroll
+    for (int k = 1; k < D; ++k) dot = __fma_rn(xi[k], xj[k], dot);
+    double r2 = __dadd_rn(__dmul_rn(-2.0, dot), __dadd_rn(sqi, sqj));
+    if (force_zero) r2 = 0.0;
+    r2 = (r2 < 0.0) ? 0.0 : r2;                       // np.clip(r2, 0, inf) (NaN stays NaN)
+    const double r = sqrt(r2) / lengthscale;          // _scaled_dist: unscaled distance / lengthscale
+    return __dmul_rn(variance, exp(__dmul_rn(-0.5, __dmul_rn(r, r))));
+}
+
+struct KmatArgs {
+    const double *rx; int64_t ldr; const double *rsq; const double *rsv;   // row points (observations)
+    const double *cx; int64_t ldc; const double *csq; const double *csv;   // column points
+    int64_t n_rows, n_cols;        // valid rows / cols (beyond: padding)
+    int64_t col_begin;             // first column point index of this launch (K* chunks)
+    double *out; int64_t ldo;
+    double variance, lengthscale, diag_add, jitter;
+    int symmetric, zero_diag;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a)
+{
+    const int tj = blockIdx.x, ti = blockIdx.y;
+    if (a.symmetric && tj < ti) return;               // only upper tiles of Ky are ever read
+    __shared__ double sx[D][64], sy[D][64];
+    __shared__ double sxq[64], syq[64], sxv[64], syv[64];
+    const int tid = threadIdx.x;
+    const int64_t i0 = (int64_t)ti * 64, j0 = (int64_t)tj * 64;
+    if (tid < 64) {
+        const int64_t gi = i0 + tid;
+#pragma unroll
+        for (int k = 0; k < D; ++k) sx[k][tid] = a.rx[(int64_t)k * a.ldr + gi];
+        sxq[tid] = a.rsq[gi];
+        sxv[tid] = a.rsv ? a.rsv[gi] : 0.0;
+    } else if (tid < 128) {
+        const int t = tid - 64;
+        const int64_t gj = a.col_begin + j0 + t;
+#pragma unroll
+        for (int k = 0; k < D; ++k) sy[k][t] = a.cx[(int64_t)k * a.ldc + gj];
+        syq[t] = a.csq[gj];
+        syv[t] = a.csv ? a.csv[gj] : 0.0;
+    }
+    __syncthreads();
+    const int tx = tid & 31, ty = tid >> 5;
+    const bool causal = (a.rsv != nullptr) && (a.csv != nullptr);
+    double yj[2][D];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int k = 0; k < D; ++k) yj[c][k] = sy[k][2 * tx + c];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int ii = ty + 8 * rr;
+        const int64_t gi = i0 + ii;
+        double xi[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) xi[k] = sx[k][ii];
+        d2 o;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int jj = 2 * tx + c;
+            const int64_t gj = j0 + jj;                  // column within this launch's output
+            const bool row_ok = gi < a.n_rows;
+            const bool col_ok = (a.col_begin + gj) < a.n_cols;
+            double v;
+            if (a.symmetric) {
+                if (row_ok && col_ok) {
+                    v = kernel_value<D>(xi, yj[c], sxq[ii], syq[jj], a.variance, a.lengthscale,
+                                        a.zero_diag && gi == gj);
+                    if (causal) v = __dadd_rn(v, __dmul_rn(sxv[ii], syv[jj]));
+                    if (gi == gj) {
+                        v = __dadd_rn(v, a.diag_add);                 // Ky = K + (noise + 1e-8) I
+                        if (a.jitter != 0.0) v = __dadd_rn(v, a.jitter);   // jitchol: A + jitter I
+                    }
+                } else {
+                    v = (gi == gj) ? 1.0 : 0.0;                       // identity padding
+                }
+            } else {
+                if (row_ok) {
+                    v = kernel_value<D>(xi, yj[c], sxq[ii], syq[jj], a.variance, a.lengthscale, false);
+                    if (causal) v = __dadd_rn(v, __dmul_rn(sxv[ii], syv[jj]));
+                } else {
+                    v = 0.0;                                          // padded observation rows
+                }
+            }
+            o[c] = v;
+        }
+        *reinterpret_cast<d2 *>(&a.out[gi * a.ldo + j0 + 2 * tx]) = o;
+    }
+}
+
+template <int D>
+static void launch_kmat_d(hipStream_t s, const KmatArgs &a, dim3 grid)
+{
+    hipLaunchKernelGGL(kmat_tile_kernel<D>, grid, dim3(256), 0, s, a);
+}
+
+static void launch_kmat(hipStream_t s, int d, const KmatArgs &a, dim3 grid)
+{
+    switch (d) {
+        case 1: launch_kmat_d<1>(s, a, grid); break;
+        case 2: launch_kmat_d<2>(s, a, grid); break;
+        case 3: launch_kmat_d<3>(s, a, grid); break;
+        case 4: launch_kmat_d<4>(s, a, grid); break;
+        case 5: launch_kmat_d<5>(s, a, grid); break;
+        case 6: launch_kmat_d<6>(s, a, grid); break;
+        case 7: launch_kmat_d<7>(s, a, grid); break;
+        default: launch_kmat_d<8>(s, a, grid); break;
+    }
+}
+
+void launch_kxx(hipStream_t s, const PointSet &X, const KernelHyper &h, double diag_add, double jitter, double *A,
+                int64_t lda, int64_t n_pad)
+{
+    KmatArgs a;
+    a.rx = X.xs; a.ldr = X.ld; a.rsq = X.sq; a.rsv = X.sv;
+    a.cx = X.xs; a.ldc = X.ld; a.csq = X.sq; a.csv = X.sv;
+    a.n_rows = X.n; a.n_cols = X.n; a.col_begin = 0;
+    a.out = A; a.ldo = lda;
+    a.variance = h.variance; a.lengthscale = h.lengthscale; a.diag_add = diag_add; a.jitter = jitter;
+    a.symmetric = 1; a.zero_diag = h.zero_diag;
+    const int nt = (int)(n_pad / 64);
+    launch_kmat(s, X.d, a, dim3(nt, nt));
+}
+
+void launch_kstar(hipStream_t s, const PointSet &X, const PointSet &C, int64_t c_begin, int64_t m_pad,
+                  const KernelHyper &h, double *V, int64_t ldv, int64_t n_pad)
+{
+    KmatArgs a;
+    a.rx = X.xs; a.ldr = X.ld; a.rsq = X.sq; a.rsv = X.sv;
+    a.cx = C.xs; a.ldc = C.ld; a.csq = C.sq; a.csv = (X.sv != nullptr) ? C.sv : nullptr;
+    a.n_rows = X.n; a.n_cols = C.ld; a.col_begin = c_begin;   // all padded columns are computable
+    a.out = V; a.ldo = ldv;
+    a.variance = h.variance; a.lengthscale = h.lengthscale; a.diag_add = 0.0; a.jitter = 0.0;
+    a.symmetric = 0; a.zero_diag = 0;
+    launch_kmat(s, X.d, a, dim3((unsigned)(m_pad / 64), (unsigned)(n_pad / 64)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Right-hand-side strip: column n_pad of A carries r = y - m(X) (GPy: Y - mean_function.f(X)); the
+// other 63 columns of the strip and the padded rows are zero.
+__global__ __launch_bounds__(256) void rhs_kernel(const double *__restrict__ y, const double *__restrict__ pm,
+                                                  int64_t n, double *__restrict__ A, int64_t lda, int64_t n_pad)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pad * kRhsCols) return;
+    const int64_t i = idx / kRhsCols;
+    const int c = (int)(idx % kRhsCols);
+    double v = 0.0;
+    if (c == 0 && i < n) v = pm ? __dadd_rn(y[i], -pm[i]) : y[i];
+    A[i * lda + n_pad + c] = v;
+}
+
+void launch_rhs(hipStream_t s, const double *y, const double *pm, int64_t n, double *A, int64_t lda, int64_t n_pad)
+{
+    const int64_t total = n_pad * kRhsCols;
+    hipLaunchKernelGGL(rhs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, y, pm, n, A, lda, n_pad);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void gather_diag_kernel(const double *__restrict__ A, int64_t lda, int64_t n, double *__restrict__ diag)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) diag[i] = A[i * lda + i];
+}
+
+void launch_gather_diag(hipStream_t s, const double *A, int64_t lda, int64_t n, double *diag)
+{
+    hipLaunchKernelGGL(gather_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A, lda, n, diag);
+}
+
+// L (row-major lower, upper zero) from the upper factor U: L[i][k] = U[k][i].
+__global__ void export_lower_kernel(const double *__restrict__ A, int64_t lda, int64_t n, double *__restrict__ L)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    const int64_t i = idx / n, k = idx % n;
+    L[idx] = (k <= i) ? A[k * lda + i] : 0.0;
+}
+
+void launch_export_lower(hipStream_t s, const double *A, int64_t lda, int64_t n, double *L)
+{
+    hipLaunchKernelGGL(export_lower_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, s, A, lda, n, L);
+}
+
+// Symmetric matrix from its upper triangle.
+__global__ void export_sym_kernel(const double *__restrict__ A, int64_t lda, int64_t n, double *__restrict__ K)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    const int64_t i = idx / n, j = idx % n;
+    K[idx] = (j >= i) ? A[i * lda + j] : A[j * lda + i];
+}
+
+void launch_export_sym(hipStream_t s, const double *A, int64_t lda, int64_t n, double *K)
+{
+    hipLaunchKernelGGL(export_sym_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, s, A, lda, n, K);
+}
+
+}  // namespace cbo

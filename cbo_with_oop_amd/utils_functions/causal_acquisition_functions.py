@@ -1,0 +1,92 @@
+"""Causal Expected Improvement on the MI355X path.
+
+Mirrors /root/reference/src/utils_functions/causal_acquisition_functions.py:8-43 (constructor and
+``evaluate``); the arithmetic runs in kernels_acq.hip behind ``cbo_acq_sweep`` (include/cbo_hip.h).
+``CandidateGrid`` is the device-resident candidate set that replaces the 100 random anchors of
+causal_optimizer.py:52.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from .. import _lib
+from ..GaussianProcessFactory import _column
+
+
+class CandidateGrid:
+    """Candidate interventions (M,d) resident in HBM (cbo_cands).  ``index_offset`` makes reported
+    arg-max indices global when this is one shard of a larger grid (one shard per GPU)."""
+
+    def __init__(self, points, model=None, index_offset=0, context=None):
+        self.points = _lib.as_f64(points)
+        if self.points.ndim != 2:
+            raise ValueError("points must be (M, d)")
+        self._lib = _lib.load()
+        ctx = context if context is not None else (model._ctx if model is not None else _lib.Context.get())
+        self._ctx = ctx
+        pm = pv = None
+        if model is not None and model.causal:
+            m = self.points.shape[0]
+            pm = _column(model.mean_function(self.points), m, "mean_function")
+            pv = _column(model.variance_adjustment(self.points), m, "variance_adjustment")
+        self.index_offset = int(index_offset)
+        self._handle = ctypes.c_void_p()
+        _lib.check(self._lib.cbo_cands_create(ctx.handle, self.points.shape[0], self.points.shape[1],
+                                              _lib.dptr(self.points), _lib.dptr(pm), _lib.dptr(pv),
+                                              self.index_offset, ctypes.byref(self._handle)))
+
+    def __len__(self):
+        return self.points.shape[0]
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.cbo_cands_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CausalExpectedImprovement:
+    def __init__(self, current_global_min, task, model, jitter=0.0):
+        """Same signature as the reference (:10-25)."""
+        self.model = model
+        self.jitter = jitter
+        self.current_global_min = current_global_min
+        self.task = task
+
+    def sweep(self, candidates, cost=1.0, want_acq=False, want_posterior=False):
+        """Score every candidate and pick the best: returns dict(best_val, best_idx, acq, mean, var).
+        ``candidates`` is a CandidateGrid (device resident) or an (M,d) array."""
+        own = not isinstance(candidates, CandidateGrid)
+        grid = CandidateGrid(candidates, self.model) if own else candidates
+        m = len(grid)
+        acq = np.empty(m) if want_acq else None
+        mean = np.empty(m) if want_posterior else None
+        var = np.empty(m) if want_posterior else None
+        best_val = ctypes.c_double(0.0)
+        best_idx = ctypes.c_int64(-1)
+        try:
+            _lib.check(_lib.load().cbo_acq_sweep(
+                self.model._handle, grid._handle, float(np.asarray(self.current_global_min).reshape(-1)[0]),
+                _lib.TASK_CODE[self.task], float(self.jitter), float(cost), _lib.dptr(acq), _lib.dptr(mean),
+                _lib.dptr(var), ctypes.byref(best_val), ctypes.byref(best_idx)))
+        finally:
+            if own:
+                grid.close()
+        col = lambda a: None if a is None else a[:, None]
+        return {"best_val": best_val.value, "best_idx": best_idx.value, "acq": col(acq), "mean": col(mean),
+                "var": col(var)}
+
+    def evaluate(self, x):
+        """(M,1) improvement, as the reference's ``evaluate`` (:27-43)."""
+        return self.sweep(x, cost=1.0, want_acq=True)["acq"]
+
+    @property
+    def has_gradients(self):
+        return False

@@ -1,0 +1,89 @@
+"""``find_current_global`` and ``find_next_y_point`` of /root/reference/src/utils_functions/utils.py:8-37
+for the MI355X path.  ``find_next_y_point`` keeps the reference signature; the acquisition optimiser
+behind it is a dense candidate-grid sweep on the GPU instead of 100 random anchors + L-BFGS
+(BASELINE.json configs).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from ..graphs import meshgrid_candidates
+from .causal_acquisition_functions import CandidateGrid, CausalExpectedImprovement
+from .cost_functions import Cost
+
+
+def find_current_global(current_y, dict_interventions, task):
+    """utils.py:8-26: best value observed so far over all exploration sets."""
+    dict_values = {}
+    for j in range(len(dict_interventions)):
+        dict_values[dict_interventions[j]] = []
+    for variable, value in current_y.items():
+        if len(value) > 0:
+            if task == 'min':
+                dict_values[variable] = np.min(current_y[variable])
+            else:
+                dict_values[variable] = np.max(current_y[variable])
+    if task == 'min':
+        opt_variable = min(dict_values, key=dict_values.get)
+    else:
+        opt_variable = max(dict_values, key=dict_values.get)
+    return dict_values[opt_variable]
+
+
+def space_bounds(space):
+    """[(lo, hi)] from an emukit ParameterSpace (``get_bounds()``), from objects with ``.parameters``
+    carrying ``.min/.max`` (graph_functions.py:80-93 builds ContinuousParameter(name, min, max)), or
+    from a plain list of pairs."""
+    if hasattr(space, "get_bounds"):
+        return [tuple(b) for b in space.get_bounds()]
+    if hasattr(space, "parameters"):
+        return [(p.min, p.max) for p in space.parameters]
+    return [tuple(b) for b in space]
+
+
+def default_grid_shape(d, budget=None):
+    """Points per dimension for a d-dimensional sweep.  BASELINE.json: 200 per 1-D toy set, and the
+    16k grid 32x32x16 for d=3; other d get the largest equal split within the same 16k budget."""
+    if budget is None:
+        budget = int(os.environ.get("CBO_HIP_GRID_BUDGET", "16384"))
+    if d == 1:
+        return [min(budget, 200)]
+    if d == 3 and budget == 16384:
+        return [32, 32, 16]
+    n = max(2, int(np.floor(budget ** (1.0 / d))))
+    return [n] * d
+
+
+def find_next_y_point(space, model, current_global_best, evaluated_set, costs_functions, task='min',
+                      grid_shape=None, candidates=None):
+    """utils.py:29-37.  Returns (y_acquisition (1,1), x_new (1,d)).
+
+    ``candidates`` (optional (M,d) array or CandidateGrid) overrides the regular grid over ``space``.
+    """
+    cost_acquisition = Cost(costs_functions, evaluated_set)
+    ei = CausalExpectedImprovement(current_global_best, task, model)
+    own = False
+    if candidates is None:
+        bounds = space_bounds(space)
+        pts = meshgrid_candidates(bounds, grid_shape or default_grid_shape(len(bounds)))
+        grid, own = CandidateGrid(pts, model), True
+    elif isinstance(candidates, CandidateGrid):
+        grid = candidates
+    else:
+        grid, own = CandidateGrid(candidates, model), True
+    try:
+        batch_cost = float(cost_acquisition.evaluate(grid.points))      # ONE scalar for the batch (Quotient)
+        res = ei.sweep(grid, cost=batch_cost)
+        x_new = grid.points[res["best_idx"] - grid.index_offset][None, :].copy()
+        # utils.py:36 re-evaluates the acquisition at x_new alone; only variable costs change the value
+        point_cost = float(cost_acquisition.evaluate(x_new))
+        if point_cost == batch_cost:
+            y = np.array([[res["best_val"]]])
+        else:
+            y = ei.sweep(x_new, cost=point_cost, want_acq=True)["acq"]
+    finally:
+        if own:
+            grid.close()
+    return y, x_new

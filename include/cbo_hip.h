@@ -1,0 +1,157 @@
+/* cbo_hip.h -- C-ABI of libcbo_hip.so: MI355X (gfx950) GP posterior update + causal acquisition sweep.
+ *
+ * The reference (ChampiB/CBO_with_OOP, pure Python) has no FFI layer; its operator API for this path
+ * is a Python duck type.  Each entry point below names the reference interface it
+ * replaces (paths relative to /root/reference/).  The Python host side in cbo_with_oop_amd/ binds
+ * exactly these symbols with ctypes (cbo_with_oop_amd/_lib.py); INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions: plain pointers and sizes only; all host arrays are C-contiguous float64 (row-major
+ * (n,d) for points); the caller owns every host buffer and it is only touched during the call; every
+ * function returns 0 (CBO_OK) or a negative cbo_status and records a message for cbo_last_error();
+ * a handle is bound to one HIP device + one stream and is not thread-safe (distinct handles are).
+ * There is no CPU fallback anywhere behind this interface.
+ */
+#ifndef CBO_HIP_H
+#define CBO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CBO_HIP_ABI_VERSION 1
+#define CBO_MAX_DIM 8
+
+typedef enum cbo_status {
+    CBO_OK = 0,
+    CBO_ERR_INVALID = -1,     /* bad argument (shape, NULL, dtype) */
+    CBO_ERR_HIP = -2,         /* a HIP runtime call failed; see cbo_last_error() */
+    CBO_ERR_NOT_PD = -3,      /* jitchol exhausted its 5 retries (numpy.linalg.LinAlgError in GPy) */
+    CBO_ERR_NONPOS_DIAG = -4, /* jitchol: "not pd: non-positive diagonal elements" */
+    CBO_ERR_NOT_FITTED = -5,
+    CBO_ERR_UNSUPPORTED = -6, /* e.g. dtype f32 (planned) */
+    CBO_ERR_NO_DEVICE = -7,
+    CBO_ERR_COMM = -8
+} cbo_status;
+
+enum { CBO_DTYPE_F64 = 0, CBO_DTYPE_F32 = 1 };
+enum { CBO_TASK_MIN = 0, CBO_TASK_MAX = 1 };
+
+typedef struct cbo_ctx cbo_ctx;     /* one HIP device + stream + workspaces */
+typedef struct cbo_gp cbo_gp;       /* one GP posterior resident on a ctx */
+typedef struct cbo_cands cbo_cands; /* one candidate-intervention set resident on a ctx */
+
+/* Per-phase device time of the calls made since cbo_reset_timers(), from hipEvents recorded on the
+ * ctx stream (only while profiling is enabled with cbo_set_profiling).  ms_* are sums, n_* counts. */
+typedef struct cbo_timers {
+    double ms_kxx;     /* K(X,X) assembly (+ diagonal)                       */
+    double ms_chol;    /* jittered Cholesky incl. forward solve z = L^-1 r   */
+    double ms_alpha;   /* backward solve alpha = L^-T z                      */
+    double ms_kstar;   /* K(X,X*) assembly                                   */
+    double ms_trsm;    /* V = L^-1 K*, fused sum(V^2) and V^T z  (dominant)  */
+    double ms_acq;     /* variance/EI/cost/argmax epilogue                   */
+    int64_t n_fit;     /* number of fits timed                               */
+    int64_t n_sweep;   /* number of sweeps / predicts timed                  */
+    int64_t n_trsm_launches;
+    double trsm_flops; /* algorithmic flops of the timed trsm launches: sum n_pad^2 * m_pad */
+} cbo_timers;
+
+/* ---- context ---------------------------------------------------------------------------------- */
+int cbo_abi_version(void);
+const char *cbo_last_error(void);
+int cbo_device_count(int *count_out);
+/* Bind device `device_id`; fails with CBO_ERR_NO_DEVICE when no gfx950-class GPU is visible. */
+int cbo_init(int device_id, cbo_ctx **out);
+void cbo_shutdown(cbo_ctx *ctx);
+int cbo_synchronize(cbo_ctx *ctx);
+int cbo_set_profiling(cbo_ctx *ctx, int enabled);
+int cbo_reset_timers(cbo_ctx *ctx);
+int cbo_get_timers(cbo_ctx *ctx, cbo_timers *out);
+int cbo_device_name(cbo_ctx *ctx, char *buf, int buflen);
+
+/* ---- GP model ----------------------------------------------------------------------------------
+ * Replaces GaussianProcessFactory.create / create_non_causal_gp / create_causal_gp / create_graph_gp
+ * (src/GaussianProcessFactory.py:24-73) + GPy GPRegression construction.  prior_mean_X / prior_var_X
+ * are the reference's mean_function(X) / variance_adjustment(X) closures (DoCalculus.py:34-66)
+ * already evaluated on X (NULL, NULL = non-causal kernel, zero mean).  zero_diag selects GPy's
+ * X2=None distance shortcut (plain RBF) vs CausalRBF's explicit-X2 path (causal_kernels.py:53-55).
+ * Uploads X, y, priors; does not fit. */
+int cbo_gp_create(cbo_ctx *ctx, int dtype, int64_t n, int d, const double *X, const double *y,
+                  const double *prior_mean_X, const double *prior_var_X, double variance,
+                  const double *lengthscale /* 1 value, or d values if ard */, int ard,
+                  double noise_var, int zero_diag, cbo_gp **out);
+void cbo_gp_destroy(cbo_gp *gp);
+
+/* GPy ExactGaussianInference.inference + util.linalg.jitchol: K(X,X) assembly, Ky = K+(noise+1e-8)I,
+ * jittered Cholesky (retry ladder mean(diag)*1e-6 x10, <= 5 retries), alpha.  Everything runs on the
+ * device from the resident X, y.  jitter_tries_out / jitter_out may be NULL. */
+int cbo_gp_fit(cbo_gp *gp, int *jitter_tries_out, double *jitter_out);
+
+/* emukit GPyModelWrapper.set_data -> GPy set_XY (called from src/Monitor.py:160): replace the data
+ * and refit. */
+int cbo_gp_set_data(cbo_gp *gp, int64_t n, const double *X, const double *y,
+                    const double *prior_mean_X, const double *prior_var_X);
+
+/* GPyModelWrapper.predict -> GP.predict -> Posterior._raw_predict (called from
+ * src/utils_functions/causal_acquisition_functions.py:33 and src/DoCalculus.py:77):
+ * mean = K*^T Ky^-1 (y-m) + m(X*), var = clip(Kdiag - |L^-1 K*|^2, 1e-15) (+ noise). */
+int cbo_gp_predict(cbo_gp *gp, int64_t m, const double *Xs, const double *prior_mean_s,
+                   const double *prior_var_s, int include_noise, double *mean_out, double *var_out);
+
+/* Posterior state for inspection / tests (GPy posterior.woodbury_chol, .woodbury_vector).
+ * L_out: n*n row-major lower triangle (upper part zero); alpha_out: n. Either may be NULL. */
+int cbo_gp_get_posterior(cbo_gp *gp, double *L_out, double *alpha_out);
+/* Assembled Ky (before factorisation) of the last fit attempt is not kept; this re-assembles
+ * K(X,X) + diag into K_out (n*n row-major, symmetric) for tests of the assembly kernel. */
+int cbo_gp_assemble_kxx(cbo_gp *gp, double *K_out);
+int64_t cbo_gp_n(const cbo_gp *gp);
+/* Outcome of the jitchol ladder of the last fit: retries used (0 = none) and jitter added. */
+int cbo_gp_jitter(const cbo_gp *gp, int *jitter_tries_out, double *jitter_out);
+
+/* ---- candidate sets ---------------------------------------------------------------------------
+ * A candidate-intervention grid resident in HBM (the generalisation of the 100 random anchors of
+ * src/utils_functions/causal_optimizer.py:52-55).  index_offset is added to local
+ * row numbers when reporting the arg-max (candidate shards of a global grid). */
+int cbo_cands_create(cbo_ctx *ctx, int64_t m, int d, const double *Xs, const double *prior_mean_s,
+                     const double *prior_var_s, int64_t index_offset, cbo_cands **out);
+void cbo_cands_destroy(cbo_cands *c);
+
+/* ---- acquisition sweep -------------------------------------------------------------------------
+ * Replaces the batched `acquisition.evaluate(X)` of the anchor scoring step
+ * (causal_optimizer.py:52-55) = CausalExpectedImprovement.evaluate
+ * (causal_acquisition_functions.py:27-43) / Cost.evaluate (cost_functions.py:11-17), followed by the
+ * top-1 selection.  acq = sign * s (u Phi(u) + phi(u)) / cost, u = (y_best - (mean + ei_jitter))/s;
+ * task max returns -EI with the same u (reference quirk).  best_idx is the lowest index attaining
+ * the maximum (NaN counts as maximal, like numpy.argmax), offset by the set's index_offset.
+ * Outputs stay on the device unless asked for: acq_out / mean_out / var_out (m doubles each) may be
+ * NULL. */
+int cbo_acq_sweep(cbo_gp *gp, cbo_cands *cands, double y_best, int task, double ei_jitter,
+                  double cost, double *acq_out, double *mean_out, double *var_out, double *best_val,
+                  int64_t *best_idx);
+
+/* Host-buffer convenience form of the same call (uploads Xs first). */
+int cbo_acq_sweep_host(cbo_gp *gp, int64_t m, const double *Xs, const double *prior_mean_s,
+                       const double *prior_var_s, double y_best, int task, double ei_jitter,
+                       double cost, double *acq_out, double *best_val, int64_t *best_idx);
+
+/* src/CBO.py:269-277 select_next_intervention: first index of the maximum over exploration sets.
+ * Host-side (S <= 25). */
+int cbo_argmax_sets(const double *ys, int s, int *idx_out);
+
+/* Reduce (best_val, best_idx) pairs gathered from all candidate shards (one per GPU) to the global
+ * winner with the same tie rule; pure host arithmetic on 16 B per rank.  The gather itself is done by
+ * the launcher's communicator (RCCL all-gather via torch.distributed). */
+int cbo_argmax_pairs(const double *vals, const int64_t *idxs, int n, double *best_val,
+                     int64_t *best_idx);
+
+/* ---- hardware self-test ------------------------------------------------------------------------
+ * Runs the fp64 MFMA lane-layout check (asymmetric operands) used by tests; returns CBO_OK when the
+ * v_mfma_f64_16x16x4_f64 A/B/C maps this library assumes hold on the device. */
+int cbo_selftest_mfma(cbo_ctx *ctx, double *max_abs_err_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CBO_HIP_H */

@@ -1,0 +1,75 @@
+"""CPU tests of the host-side mirror of the reference interface (no device calls)."""
+import numpy as np
+import pytest
+
+from cbo_with_oop_amd.CBO import CBOAcquisitionPath
+from cbo_with_oop_amd.GaussianProcessFactory import GaussianProcessType
+from cbo_with_oop_amd.graphs import GRAPHS, CompleteGraph, CoralGraph, ToyGraph, meshgrid_candidates
+from cbo_with_oop_amd.sharding import reduce_pairs, shard_bounds
+from cbo_with_oop_amd.utils_functions.cost_functions import Cost, total_cost
+from cbo_with_oop_amd.utils_functions.utils import default_grid_shape, find_current_global, space_bounds
+from oracle import gp_oracle as O
+
+
+def test_enum_values_match_reference():
+    assert (GaussianProcessType.GRAPH_GP, GaussianProcessType.CAUSAL_GP, GaussianProcessType.NON_CAUSAL_GP) == (0, 1, 2)
+
+
+def test_graph_tables():
+    assert CompleteGraph.get_exploration_set("MIS") == [['B'], ['D'], ['E'], ['B', 'D'], ['B', 'E'], ['D', 'E']]
+    assert len(CompleteGraph.get_exploration_set("POMIS")) == 5
+    assert len(CoralGraph.get_exploration_set("MIS")) == 25
+    assert CoralGraph.get_interventional_ranges()["T"] == [2450, 2500]
+    assert ToyGraph.bounds(["X", "Z"]) == [(-5, 5), (-5, 20)]
+    assert set(GRAPHS) == {"complete_graph", "coral_graph", "simplified_coral_graph", "toy_graph"}
+    with pytest.raises(RuntimeError):
+        CompleteGraph.get_cost_structure(5)
+
+
+@pytest.mark.parametrize("type_cost", [1, 2, 3, 4])
+def test_cost_matches_oracle(type_cost):
+    costs = CompleteGraph.get_cost_structure(type_cost)
+    x = np.array([[1.0, -2.0], [3.0, 4.0], [-0.5, 0.25]])
+    es = ["B", "E"]
+    fixed = {1: [1, 1], 2: [10, 20], 3: [10, 20], 4: [1, 1]}[type_cost]
+    variable = type_cost in (3, 4)
+    assert Cost(costs, es).evaluate(x) == O.cost_of_batch(x, fixed, [variable] * 2)
+    assert total_cost(es, costs, {"B": 2.0, "E": -3.0}) == sum(fixed) + (5.0 if variable else 0.0)
+
+
+def test_meshgrid_order_and_grid_shapes():
+    g = meshgrid_candidates([(0, 1), (10, 12)], [2, 3])
+    assert np.array_equal(g, [[0, 10], [0, 11], [0, 12], [1, 10], [1, 11], [1, 12]])     # first dim slowest
+    assert default_grid_shape(1) == [200] and default_grid_shape(3) == [32, 32, 16]
+    assert np.prod(default_grid_shape(2)) <= 16384
+
+    class P:
+        def __init__(self, lo, hi): self.min, self.max = lo, hi
+
+    class S:
+        parameters = [P(-1, 2), P(0, 3)]
+    assert space_bounds(S()) == [(-1, 2), (0, 3)]
+    assert space_bounds([(0, 1)]) == [(0, 1)]
+
+
+def test_find_current_global_and_selection():
+    cur = {"X": [np.inf, -1.0, -2.5], "Z": [np.inf]}
+    assert find_current_global(cur, ["X", "Z"], "min") == O.find_current_global(cur, ["X", "Z"], "min") == -2.5
+    cur = {"X": [-np.inf, 3.0], "Z": [-np.inf, 4.0]}
+    assert find_current_global(cur, ["X", "Z"], "max") == 4.0
+    path = CBOAcquisitionPath(GaussianProcessType.NON_CAUSAL_GP, [["X"], ["Z"], ["X", "Z"]], {}, "min",
+                              [None] * 3, [None] * 3, [None] * 3)
+    ys = [np.array([[0.2]]), np.array([[0.9]]), np.array([[0.9]])]
+    assert path.select_next_intervention(ys) == (["Z"], 1)
+    assert path.select_intervention(ys) == (["Z"], 1) and path.last_intervention == 1
+    assert O.select_next_intervention(ys) == 1
+
+
+def test_shard_bounds_cover_the_grid():
+    for m in (1, 7, 64, 16384, 100003):
+        for w in (1, 2, 3, 4, 8):
+            blocks = [shard_bounds(m, w, r) for r in range(w)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == m
+            assert all(b[1] == nb[0] for b, nb in zip(blocks, blocks[1:]))
+    assert reduce_pairs([0.5, 0.9, 0.9], [5, 900, 300]) == (0.9, 300)
+    assert reduce_pairs([np.nan, 0.9], [7, 3]) [1] == 7          # NaN is maximal, like numpy.argmax

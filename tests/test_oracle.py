@@ -1,0 +1,142 @@
+"""CPU tests of the oracle itself: closed-form known answers, the committed golden fixtures, the
+80-bit arbiter.  (The reference holds no vectors for this path -- SURVEY.md §4 -- so these pin the
+oracle to mathematics and to the reference's data-level facts.)"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.stats
+
+from conftest import GOLDEN, ROOT, load_fixture
+from oracle import gp_oracle as O
+from oracle.truth import truth_predict
+
+D = 1e-10 + 1e-8      # noise + GPy diagonal jitter
+
+
+def test_one_point_gp_closed_form():
+    X, y = np.array([[0.3]]), np.array([[1.7]])
+    post = O.fit(X, y)
+    xs = np.array([[0.3], [1.3], [-2.0]])
+    mu, var = O.predict(post, xs)
+    k = np.exp(-0.5 * (xs[:, 0] - 0.3) ** 2)
+    assert np.allclose(mu[:, 0], k * 1.7 / (1 + D), rtol=1e-14)
+    assert np.allclose(var[:, 0], np.clip(1 - k ** 2 / (1 + D), 1e-15, None) + 1e-10, rtol=1e-9, atol=1e-15)
+    assert post.tries == 0 and post.L.shape == (1, 1)
+    assert np.isclose(post.alpha[0, 0], 1.7 / (1 + D), rtol=1e-15)
+
+
+def test_two_point_gp_closed_form():
+    X, y = np.array([[0.0], [1.0]]), np.array([[1.0], [-0.5]])
+    post = O.fit(X, y)
+    k01 = np.exp(-0.5)
+    Ky = np.array([[1 + D, k01], [k01, 1 + D]])
+    xs = np.array([[0.5], [2.0]])
+    Kx = np.exp(-0.5 * (X - xs.T) ** 2)
+    mu_ref = Kx.T @ np.linalg.solve(Ky, y)
+    var_ref = 1 - np.sum(Kx * np.linalg.solve(Ky, Kx), 0) + 1e-10
+    mu, var = O.predict(post, xs)
+    assert np.allclose(mu, mu_ref, rtol=1e-13)
+    assert np.allclose(var[:, 0], var_ref, rtol=1e-12)
+    mu_w, var_w = O.predict(post, xs, var_form="woodbury")
+    assert np.allclose(var_w, var, rtol=1e-12)
+
+
+def test_kernel_matches_direct_formula_and_kdiag():
+    rng = np.random.default_rng(1)
+    X, X2 = rng.uniform(-5, 5, (7, 3)), rng.uniform(-5, 5, (5, 3))
+    direct = np.exp(-0.5 * ((X[:, None, :] - X2[None, :, :]) ** 2).sum(-1))
+    assert np.allclose(O.rbf_K(X, X2), direct, rtol=1e-12)
+    v, v2 = rng.uniform(0.1, 1, (7, 1)), rng.uniform(0.1, 1, (5, 1))
+    assert np.allclose(O.causal_K(X, X2, v, v2), direct + np.sqrt(v) @ np.sqrt(v2).T, rtol=1e-12)
+    # Kdiag is the diagonal of K (causal_kernels.py:64-79 vs :45-62)
+    assert np.allclose(np.diag(O.causal_K(X, X, v, v, zero_diag=True)), O.causal_Kdiag(7, v), rtol=1e-15)
+    ard = O.rbf_K(X, X2, 2.0, np.array([0.5, 1.0, 2.0]))
+    assert np.allclose(ard, 2.0 * np.exp(-0.5 * (((X[:, None] - X2[None]) / [0.5, 1.0, 2.0]) ** 2).sum(-1)), rtol=1e-12)
+
+
+def test_expected_improvement_limits():
+    # u = 0: EI = s * phi(0)
+    s = 0.37
+    ei = O.expected_improvement(np.array([[1.2]]), np.array([[s * s]]), 1.2)
+    assert np.isclose(ei[0, 0], s / np.sqrt(2 * np.pi), rtol=1e-15)
+    # u -> -inf: EI -> 0 ; u large: EI -> y* - mu
+    assert O.expected_improvement(np.array([[50.0]]), np.array([[1.0]]), 0.0)[0, 0] == 0.0
+    assert np.isclose(O.expected_improvement(np.array([[-50.0]]), np.array([[1.0]]), 0.0)[0, 0], 50.0, rtol=1e-12)
+    # task max: the reference returns -EI with the same u (causal_acquisition_functions.py:38-41)
+    mu, var = np.array([[0.3], [-0.2]]), np.array([[0.5], [0.1]])
+    assert np.array_equal(O.expected_improvement(mu, var, 0.1, "max"), -O.expected_improvement(mu, var, 0.1, "min"))
+    # scipy identity used by the HIP kernel: ndtr(u) == norm.cdf(u)
+    u = np.linspace(-10, 10, 101)
+    assert np.array_equal(scipy.stats.norm.cdf(u), __import__("scipy.special").special.ndtr(u))
+
+
+def test_jitchol_ladder_on_singular_matrix():
+    X = np.array([[0.0], [0.0], [1.0]])          # duplicate rows -> exactly singular K
+    K = O.rbf_K(X, X)
+    with pytest.raises(np.linalg.LinAlgError):
+        np.linalg.cholesky(K - 1e-9 * np.eye(3))
+    L, jitter, tries = O.jitchol(K - 1e-9 * np.eye(3))
+    assert tries == 1 and np.isclose(jitter, np.mean(np.diag(K) - 1e-9) * 1e-6)
+    assert np.allclose(L @ L.T, K - 1e-9 * np.eye(3) + jitter * np.eye(3), atol=1e-15)
+    with pytest.raises(np.linalg.LinAlgError):
+        O.jitchol(-np.eye(3))                    # non-positive diagonal
+    with pytest.raises(np.linalg.LinAlgError):
+        O.jitchol(np.array([[1.0, 10.0], [10.0, 1.0]]))   # indefinite beyond 5 retries
+
+
+def test_cost_and_selection_quirks():
+    x = np.array([[1.0, -2.0], [3.0, 4.0]])
+    assert O.cost_of_batch(x, [1, 10], [False, False]) == 11
+    assert O.cost_of_batch(x, [1, 10], [True, True]) == 1 + 4 + 10 + 6      # |x| summed over the batch
+    assert O.select_next_intervention([np.array([[0.1]]), np.array([[0.7]]), np.array([[0.7]])]) == 1
+    cur = {"X": [np.inf, -1.0], "Z": [np.inf]}
+    assert O.find_current_global(cur, ["X", "Z"], "min") == -1.0
+
+
+def test_toy_sem_identity_from_fixture():
+    """data/toy_graph/interventional_data_{x,y}_BO.npy: Y = cos Z - exp(-Z/20)."""
+    from cbo_with_oop_amd.graphs import ToyGraph
+    f = load_fixture("toy_bo_d2")
+    assert f["X"].shape == (20, 2) and f["y"].shape == (20, 1)
+    assert np.max(np.abs(f["y"][:, 0] - ToyGraph.target_do_z(f["X"][:, 1]))) < 1e-12
+    g = load_fixture("toy_init_Z")
+    assert np.isclose(g["y"].min(), -2.1081858288678093, atol=1e-9)          # value captured from the reference
+
+
+def test_oracle_reproduces_golden(golden):
+    """The committed fixtures are what the oracle computes today (guards against silent drift)."""
+    f = golden
+    post = O.fit(f["X"], f["y"], f["mX"], f["vX"], float(f["variance"]), f["lengthscale_arg"], float(f["noise_var"]))
+    assert post.tries == int(f["tries"])
+    assert np.allclose(post.L, f["L"], rtol=1e-9, atol=1e-12)
+    acq, best_val, best_idx, mu, var = O.acquisition_sweep(post, f["Xs"], float(f["y_best"]), f["mXs"], f["vXs"],
+                                                           f["task"], float(f["cost"]))
+    assert best_idx == int(f["best_idx"])
+    assert np.allclose(var, f["var"], rtol=1e-6)
+    assert np.allclose(mu, f["mean"], rtol=1e-6, atol=1e-9)
+
+
+def test_oracle_against_extended_precision(golden):
+    f = golden
+    mt, vt, at = truth_predict(f["X"], f["y"], f["Xs"], f["mX"], f["vX"], f["mXs"], f["vXs"], float(f["variance"]),
+                               f["lengthscale_arg"], diag_add=float(f["noise_var"]) + 1e-8 + float(f["jitter"]),
+                               noise_var=float(f["noise_var"]))
+    assert np.allclose(vt, f["var_truth"], rtol=1e-12)
+    rel = np.max(np.abs(f["var"] - vt) / vt)
+    # the triangular form is accurate to eps*sqrt(cond): well under 1e-4 on every fixture
+    assert rel < 1e-4, rel
+
+
+def test_fixture_generator_is_committed_and_reference_free_at_runtime():
+    src = open(os.path.join(GOLDEN, "make_fixtures.py")).read()
+    assert "allow_pickle=False" in src and "allow_pickle=True" not in src
+    # nothing under tests/ (other than the generator) or in the product reads /root/reference
+    for base in ("cbo_with_oop_amd", "oracle"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for fn in files:
+                if fn.endswith((".py", ".hip", ".h", ".c")):
+                    text = open(os.path.join(dirpath, fn)).read()
+                    assert "open('/root/reference" not in text and 'np.load("/root/reference' not in text
