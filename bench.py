@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- candidate-intervention acquisitions/sec of the MI355X hot path.
+
+One "step" = one pass of the whole hot path of BASELINE.json's north_star over one batch of synthetic
+input, exactly what CBO.intervene() triggers each trial (/root/reference/src/CBO.py:152-164):
+    fit   : K(X,X) assembly -> jittered Cholesky (+ z = L^-1 r) -> alpha
+    sweep : K(X,X*) -> V = L^-1 K* (variance, mean) -> EI / cost -> arg-max over the rank's candidates
+    pick  : arg-max exchange across ranks (RCCL all-gather of 16 B per rank when --gpus > 1)
+Inputs (X, y, candidate grid) are resident in HBM before the timed region starts; the only host
+traffic inside it is the jitchol status word and the 16-byte winner.
+
+Workload at N=1 = BASELINE.json configs[1]: toy_graph box, d=3, 4096 observations, 16384-candidate
+regular grid (32x32x16), fp64.  For --gpus G the grid grows to G x 16384 (32x32x16G) and is cut into
+contiguous blocks, one per rank; the posterior is replicated (weak scaling: fixed work per GPU).
+
+usage: python bench.py [--gpus N] [--steps K] [--warmup W]
+       (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# torch first: its bundled HIP runtime must be the one libcbo_hip.so binds to when both live in a process
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import numpy as np  # noqa: E402
+
+N_OBS = 4096
+GRID_PER_GPU = (32, 32, 16)
+BOX = [(-5.0, 5.0), (-5.0, 20.0), (-5.0, 5.0)]        # toy ranges X, Z (+ a third axis, see graphs.ToyGraph)
+FP64_MFMA_PEAK_TFLOPS = 78.6                           # MI355X fp64 matrix peak (AMD datasheet; = vector peak)
+
+
+def make_problem(world):
+    from cbo_with_oop_amd.graphs import meshgrid_candidates
+    lo, hi = np.array([b[0] for b in BOX]), np.array([b[1] for b in BOX])
+    X = np.random.default_rng(0).uniform(lo, hi, (N_OBS, 3))
+    y = (np.cos(np.exp(-X[:, 0] / 3)) - np.exp(-X[:, 1] / 20) + 0.3 * np.sin(X[:, 2])
+         + 0.1 * np.random.default_rng(1).standard_normal(N_OBS))[:, None]
+    grid = (GRID_PER_GPU[0], GRID_PER_GPU[1], GRID_PER_GPU[2] * world)
+    return X, y, meshgrid_candidates(BOX, grid), grid
+
+
+def cpu_baseline(X, y, Xs, y_best, cost, sample):
+    """numpy/scipy restatement of the GPy/emukit path (oracle/gp_oracle.py) timed on this box's host
+    cores: the full fit, and the sweep on the first `sample` candidates scaled to the full grid."""
+    from oracle import gp_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count()
+    t0 = time.perf_counter()
+    post = O.fit(X, y)
+    t_fit = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.acquisition_sweep(post, Xs[:sample], y_best, cost=cost)
+    t_sweep = (time.perf_counter() - t0) * (Xs.shape[0] / sample)
+    return {"value": Xs.shape[0] / (t_fit + t_sweep), "unit": "acquisitions/s", "cores": int(threads),
+            "kind": "port",
+            "sample": f"full fit N={X.shape[0]} ({t_fit:.2f} s) + sweep of the first {sample} of {Xs.shape[0]} "
+                      f"candidates scaled x{Xs.shape[0] / sample:.0f} ({t_sweep:.2f} s); numpy/scipy restatement "
+                      f"of the GPy/emukit path, not GPy itself"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="candidates in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from cbo_with_oop_amd import CandidateGrid, CausalExpectedImprovement, _lib
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    from cbo_with_oop_amd.sharding import exchange_argmax, shard_bounds
+    import ctypes
+
+    ctx = _lib.Context.get(local_rank)
+    lib = _lib.load()
+    X, y, Xs, grid = make_problem(world)
+    y_best, cost = float(y.min()), 3.0                     # incumbent = best observation; type_cost 1 -> |set| = 3
+    begin, end = shard_bounds(Xs.shape[0], world, rank)
+
+    model = HipGaussianProcess(X, y, context=ctx)          # uploads X, y (and fits once: part of warm-up)
+    cands = CandidateGrid(Xs[begin:end], model, index_offset=begin, context=ctx)
+    ei = CausalExpectedImprovement(y_best, "min", model)
+    bv, bi = ctypes.c_double(), ctypes.c_int64()
+
+    def step():
+        _lib.check(lib.cbo_gp_fit(model._handle, None, None))
+        _lib.check(lib.cbo_acq_sweep(model._handle, cands._handle, y_best, 0, 0.0, cost, None, None, None,
+                                     ctypes.byref(bv), ctypes.byref(bi)))
+        return exchange_argmax(bv.value, bi.value)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        winner = step()
+    ctx.set_profiling(True)
+    ctx.reset_timers()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        winner = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timers = ctx.timers()
+    ctx.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        total_cands = Xs.shape[0]
+        launches = max(1, timers["n_trsm_launches"])
+        trsm_ms = timers["ms_trsm"] / launches
+        achieved = timers["trsm_flops"] / launches / (trsm_ms * 1e-3) / 1e12 if trsm_ms > 0 else 0.0
+        out = {
+            "metric": "candidate-intervention acquisitions/sec (16k grid, d=3)",
+            "value": total_cands / (elapsed / args.steps),
+            "unit": "acquisitions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "toy_graph box d=3, 4096 obs, 16384-candidate regular grid per GPU "
+                                   "(BASELINE.json configs[1]); step = GP refit + EI/cost sweep + argmax",
+                       "n_obs": N_OBS, "candidates_total": int(total_cands), "grid": list(grid),
+                       "candidates_per_gpu": int(total_cands // world), "parallelism": f"candidate shards x{world}, "
+                       "replicated posterior, RCCL all-gather of (val, idx)"},
+            "winner": {"index": int(winner[1]), "acq": float(winner[0])},
+            "phases_ms_per_step": {k[3:]: timers[k] / args.steps for k in
+                                   ("ms_kxx", "ms_chol", "ms_alpha", "ms_kstar", "ms_trsm", "ms_acq")},
+            "sweep_only_acq_per_s": (total_cands // world) / ((timers["ms_kstar"] + timers["ms_trsm"] + timers["ms_acq"])
+                                                              / args.steps * 1e-3) * world,
+            "roofline": {"kernel": "trsm_strip_kernel<128> (V = L^-1 K*, fused sum V^2 and V^T z)",
+                         "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_ms": trsm_ms,
+                         "algorithmic_flops_per_launch": timers["trsm_flops"] / launches},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(X, y, Xs, y_best, cost, min(args.cpu_sample, Xs.shape[0]))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

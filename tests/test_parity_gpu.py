@@ -246,7 +246,10 @@ def test_full_size_properties(hip):
     # (1) interpolation: at the training inputs the posterior mean returns y to O(noise) and the
     #     variance collapses to O(diag) -- exercises K*, TRSM and epilogue with M = N
     mean_tr, var_tr = m.predict(X[:1024])
-    assert np.max(np.abs(mean_tr - y[:1024])) < 1e-4 and np.max(var_tr) < 1e-6
+    _, alpha = m.posterior_state()
+    # K alpha = y - (noise + 1e-8) alpha exactly, so the interpolation residual is 1.01e-8 * alpha
+    assert np.allclose(mean_tr - y[:1024], -1.01e-8 * alpha[:1024], rtol=1e-3, atol=1e-9)
+    assert np.max(var_tr) < 1e-6
     # (2) shard invariance: the global winner of 4 contiguous shards (index offsets) equals the unsharded one,
     #     and per-candidate results do not depend on which strip/chunk a candidate lands in
     from cbo_with_oop_amd.sharding import reduce_pairs, shard_bounds
