@@ -397,7 +397,7 @@ extern "C" int cbo_gp_fit(cbo_gp *g, int *tries_out, double *jitter_out)
     }
     {
         PhaseScope ps(c, PH_ALPHA);
-        launch_backsolve(c->stream, g->A, g->lda, g->n_pad, g->alpha);
+        launch_backsolve(c->stream, g->A, g->lda, g->n_pad, g->invDt, g->alpha);
         // contiguous z for the sweep (alpha[n_pad..] held the working copy and is consumed by the solve)
         HIP_TRY(hipMemcpy2DAsync(g->z, sizeof(double), g->A + g->n_pad, sizeof(double) * g->lda, sizeof(double),
                                  (size_t)g->n_pad, hipMemcpyDeviceToDevice, c->stream));
@@ -566,7 +566,7 @@ static int enqueue_posterior(cbo_gp *g, cbo_cands *k)
         }
         {
             PhaseScope ps(c, PH_TRSM);
-            launch_trsm_strips(c->stream, g->A, g->lda, g->invDt, c->V, ldv, g->n_pad, cols, g->z, 1, c->q + c0,
+            launch_trsm_strips(c->stream, g->A, g->lda, g->invDt, c->V, ldv, g->n_pad, cols, g->z, c->q + c0,
                                c->mu + c0);
         }
         if (c->profiling) {

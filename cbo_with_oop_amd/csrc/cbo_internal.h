@@ -65,11 +65,11 @@ void launch_kstar(hipStream_t s, const PointSet &X, const PointSet &C, int64_t c
 // Recursive blocked Cholesky (upper) of A[0:n_pad, 0:n_pad] incl. forward solve of the rhs strip.
 void launch_cholesky(hipStream_t s, double *A, int64_t lda, int64_t n_pad, double *invDt, int *info_dev);
 // alpha = U^-1 z  (z = first rhs column of A).
-void launch_backsolve(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, double *alpha);
+void launch_backsolve(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt, double *alpha);
 
 // V <- L^-1 V on m_pad columns (64-column strips); optional q[c] = sum_i V[i][c]^2, mu[c] = sum_i V[i][c] z[i].
 void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const double *invDt, double *V, int64_t ldv,
-                        int64_t n, int64_t m_pad, const double *z, int64_t z_stride, double *q, double *mu);
+                        int64_t n, int64_t m_pad, const double *z, double *q, double *mu);
 
 struct AcqParams {
     double variance, noise_var, y_best, ei_jitter, cost;

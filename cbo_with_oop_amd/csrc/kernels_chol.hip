@@ -1,101 +1,199 @@
-// Recursive blocked Cholesky  Ky = U^T U  (upper factor, row-major) for gfx950, with the forward solve
-// z = L^-1 (y - m) carried along as an extra right-hand-side column, and the backward solve for alpha.
+// Blocked right-looking Cholesky  Ky = U^T U  (upper factor, row-major) for gfx950, with the forward
+// solve z = L^-1 (y - m) carried along as an extra right-hand-side column, and the backward solve for
+// alpha.
 //
 // Restates LAPACK dpotrf + dpotrs as reached by GPy's jitchol / dpotrs (GPy ExactGaussianInference;
 // the reference builds that model at /root/reference/src/GaussianProcessFactory.py:57-73).  A
 // non-positive (or NaN) pivot sets *info (first failing 1-based pivot index), which the host-side
 // jitter ladder reads after the factorisation.
 //
-//   potrf(r0, n):  n == 64 -> leaf kernel (one workgroup, LDS-resident 64x64 block + rhs column,
-//                             also emits the four 16x16 diagonal inverses the strip TRSM consumes)
-//                  else    -> potrf(r0, n1); panel = trsm_strips(U11, A12); syrk(A22 -= A12^T A12,
-//                             rhs -= A12^T z1); potrf(r0+n1, n2)
-// The SYRK is the fp64-MFMA-bound part (n^3/3 flops overall together with the panel solves).
+// Per 128-row panel k (rows r0 = 128 k):
+//   1. potrf_diag128_kernel   one workgroup factors the 128x128 diagonal block in LDS (16x16 tiles:
+//                             register Cholesky of the tile by one wave, substitution of the tile's row
+//                             panel by all threads, rank-16 MFMA updates by the other waves), solves the
+//                             rhs rows, emits the eight 16x16 diagonal inverses the strip TRSM consumes
+//   2. trsm_strip_kernel      U[r0:r0+128, r0+128:] = U_kk^-T A[...]    (64-column strips, n = 128)
+//   3. syrk_kernel            A[r0+128:, r0+128:] -= P^T P  on the upper 128x128 tiles (fp64 MFMA),
+//                             rhs[r0+128:] -= P^T z_k
+// The SYRK carries the n^3/3 flops; steps 1-2 are the serial chain.
 #include "cbo_internal.h"
 
 namespace cbo {
 
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-// ------------------------------------------------------------------------------------------------
-// Leaf: factor the 64x64 diagonal block at (r0, r0) in LDS, right-looking, with the rhs column as a
-// 65th column (so z_blk = U_bb^-T r_blk falls out of the same row scalings and rank-1 updates).
-constexpr int kLeafLd = 80;   // LDS row stride (doubles): rows r and r+1 are 32 banks apart
-
-__global__ __launch_bounds__(256) void potrf_leaf_kernel(double *A, int64_t lda, int r0, int rcol,
-                                                         double *__restrict__ invDt, int *info)
+__device__ __forceinline__ double readlane_f64(double v, int lane)
 {
-    __shared__ double S[64][kLeafLd];
-    __shared__ double Y[4][16][17];
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int kDiagLd = 144;   // LDS row stride (doubles): rows kq and kq+1 of a fragment are 32 banks apart
+
+struct DiagShared {
+    double S[128][kDiagLd];    // the block; upper triangle is meaningful
+    double rz[128];            // rhs column
+    double Ud[16][16];         // current 16x16 diagonal factor (upper)
+    double invd[16];           // reciprocals of its diagonal
+};
+
+// Register Cholesky of the 16x16 tile at (o, o): lane c (mod 16) owns column c.  Executed by one wave.
+__device__ __forceinline__ void diag_tile_factor(DiagShared &sh, int o, int lane, int pivot_base, int *info)
+{
+    const int c = lane & 15;
+    double a[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = (r <= c) ? sh.S[o + r][o + c] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        double pj = readlane_f64(a[j], j);
+        if (!(pj > 0.0)) {                        // LAPACK: ajj <= 0 or NaN -> info = j
+            if (lane == 0) atomicCAS(info, 0, pivot_base + o + j + 1);
+            pj = 1.0;                             // keep the arithmetic finite; the result is discarded
+        }
+        const double dj = sqrt(pj);
+        const double inv = 1.0 / dj;
+        a[j] = (c == j) ? dj : a[j] * inv;
+        if (lane == 0) sh.invd[j] = inv;
+#pragma unroll
+        for (int r = j + 1; r < 16; ++r) {
+            const double ujr = readlane_f64(a[j], r);
+            a[r] = fma(-ujr, a[j], a[r]);
+        }
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const double v = (r <= c) ? a[r] : 0.0;
+            sh.Ud[r][c] = v;
+            sh.S[o + r][o + c] = v;
+        }
+    }
+}
+
+// One 16x16 tile of the rank-16 update: S[r0.., c0..] -= U[o.., r0..]^T U[o.., c0..]
+__device__ __forceinline__ void diag_tile_update(DiagShared &sh, int o, int r0, int c0, int lc, int kq)
+{
+    d4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = sh.S[r0 + kq + 4 * r][c0 + lc];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const double a = sh.S[o + 4 * kk + kq][r0 + lc];
+        const double b = sh.S[o + 4 * kk + kq][c0 + lc];
+        acc = MFMA_F64(a, -b, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh.S[r0 + kq + 4 * r][c0 + lc] = acc[r];
+}
+
+__global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t lda, int r0, int rcol,
+                                                            double *__restrict__ invDt, int *info)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    DiagShared &sh = *reinterpret_cast<DiagShared *>(smem_raw);
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < 64 * 64; idx += 256) {
-        const int i = idx >> 6, j = idx & 63;
-        S[i][j] = A[(int64_t)(r0 + i) * lda + r0 + j];
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lc = lane & 15, kq = lane >> 4;
+
+    // load the upper triangle of the block (row-major, 16-byte loads) and the rhs rows
+    for (int idx = tid; idx < 128 * 64; idx += 256) {
+        const int i = idx >> 6, j2 = (idx & 63) * 2;
+        if (j2 + 1 >= i) {
+            const d2 v = *reinterpret_cast<const d2 *>(&A[(int64_t)(r0 + i) * lda + r0 + j2]);
+            sh.S[i][j2] = v[0];
+            sh.S[i][j2 + 1] = v[1];
+        }
     }
-    if (tid < 64) S[tid][64] = A[(int64_t)(r0 + tid) * lda + rcol];
+    if (tid < 128) sh.rz[tid] = A[(int64_t)(r0 + tid) * lda + rcol];
+    __syncthreads();
+    if (wave == 0) diag_tile_factor(sh, 0, lane, r0, info);
     __syncthreads();
 
-    const int tr = tid >> 4, tc = tid & 15;
-    for (int j = 0; j < 64; ++j) {
-        double ajj = S[j][j];
-        if (!(ajj > 0.0)) {                       // also catches NaN (LAPACK: ajj <= 0 or isnan)
-            if (tid == 0) atomicCAS(info, 0, r0 + j + 1);
-            ajj = 1.0;                            // keep going with finite numbers; result is discarded
+    for (int jb = 0; jb < 8; ++jb) {
+        const int o = 16 * jb;
+        const int ncols = 128 - o - 16;            // columns to the right of the tile
+        // ---- B: row panel  X = U_d^-T S[o:o+16, o+16:]  and the rhs rows, one column per thread
+        if (tid <= ncols) {
+            const bool is_rhs = (tid == ncols);
+            double x[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = is_rhs ? sh.rz[o + i] : sh.S[o + i][o + 16 + tid];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                double s = x[i];
+#pragma unroll
+                for (int k = 0; k < i; ++k) s = fma(-sh.Ud[k][i], x[k], s);
+                x[i] = s * sh.invd[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (is_rhs) sh.rz[o + i] = x[i];
+                else sh.S[o + i][o + 16 + tid] = x[i];
+            }
         }
-        const double d = sqrt(ajj);
-        if (tid > j && tid <= 64) S[j][tid] = S[j][tid] / d;   // columns j+1..63 and the rhs column 64
         __syncthreads();
-        // trailing update of the upper triangle (r > j, c >= r) and of the rhs column (c == 64)
+        if (jb == 7) break;
+        // ---- C: rank-16 update of the trailing upper tiles; wave 0 takes the next diagonal tile and
+        //         factors it right away while waves 1-3 update the rest
+        if (wave == 0) {
+            diag_tile_update(sh, o, o + 16, o + 16, lc, kq);
+            // its rhs rows:  rz[o+16 .. o+32) -= U[o.., r]^T z[o..]
+            if (lane < 16) {
+                double s = sh.rz[o + 16 + lane];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int r = tr + 16 * a;
-            if (r > j) {
-                const double ujr = S[j][r];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int c = tc + 16 * b;
-                    if (c >= r) S[r][c] = fma(-ujr, S[j][c], S[r][c]);
+                for (int k = 0; k < 16; ++k) s = fma(-sh.S[o + k][o + 16 + lane], sh.rz[o + k], s);
+                sh.rz[o + 16 + lane] = s;
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);    // lgkmcnt(0): the LDS stores above are visible to this wave's reads
+            diag_tile_factor(sh, o + 16, lane, r0, info);
+        } else {
+            int idx = 0;
+            for (int ti = jb + 1; ti < 8; ++ti)
+                for (int tj = ti; tj < 8; ++tj) {
+                    if (ti == jb + 1 && tj == jb + 1) continue;
+                    if (idx % 3 == wave - 1) diag_tile_update(sh, o, 16 * ti, 16 * tj, lc, kq);
+                    ++idx;
                 }
-                if (tc == 0) S[r][64] = fma(-ujr, S[j][64], S[r][64]);
+            // rhs rows below the next tile
+            const int t = tid - 64;                // 0..191
+            const int r = o + 32 + t;
+            if (r < 128) {
+                double s = sh.rz[r];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) s = fma(-sh.S[o + k][r], sh.rz[o + k], s);
+                sh.rz[r] = s;
             }
         }
         __syncthreads();
     }
-    // S[j][j] still holds the (updated) pivot a_jj; the factor's diagonal is its square root.
-    if (tid < 64) {
-        double ajj = S[tid][tid];
-        if (!(ajj > 0.0)) ajj = 1.0;
-        S[tid][65] = sqrt(ajj);                   // column 65: diagonal of U
-    }
-    __syncthreads();
 
-    // Inverses of the four 16x16 diagonal blocks of U (upper triangular), column by column with back
-    // substitution, so that U_bb * Y ~= I to working accuracy (the strip TRSM applies Y^T from the left).
-    if (tid < 64) {
-        const int blk = tid >> 4, j = tid & 15, o = 16 * blk;
+    // ---- outputs: factor (upper, zero below), z, and inv(U_bb) for the eight 16x16 diagonal tiles
+    for (int idx = tid; idx < 128 * 64; idx += 256) {
+        const int i = idx >> 6, j2 = (idx & 63) * 2;
+        d2 v;
+        v[0] = (j2 >= i) ? sh.S[i][j2] : 0.0;
+        v[1] = (j2 + 1 >= i) ? sh.S[i][j2 + 1] : 0.0;
+        *reinterpret_cast<d2 *>(&A[(int64_t)(r0 + i) * lda + r0 + j2]) = v;
+    }
+    if (tid < 128) {
+        A[(int64_t)(r0 + tid) * lda + rcol] = sh.rz[tid];
+        // column j of Y = inv(U_bb) by back substitution (U_bb Y = I to working accuracy; the strip
+        // TRSM applies Y^T from the left)
+        const int b = tid >> 4, j = tid & 15, o = 16 * b;
+        double y[16];
+#pragma unroll
         for (int i = 15; i >= 0; --i) {
-            double v;
-            if (i > j) {
-                v = 0.0;
-            } else {
-                double s = (i == j) ? 1.0 : 0.0;
-                for (int k = i + 1; k <= j; ++k) s = fma(-S[o + i][o + k], Y[blk][k][j], s);
-                v = s / S[o + i][65];
-            }
-            Y[blk][i][j] = v;
+            double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = i + 1; k < 16; ++k) s = fma(-sh.S[o + i][o + k], (k <= j) ? y[k] : 0.0, s);
+            y[i] = (i <= j) ? s / sh.S[o + i][o + i] : 0.0;
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) invDt[(int64_t)(r0 / 16 + b) * 256 + i * 16 + j] = y[i];
     }
-    __syncthreads();
-    for (int idx = tid; idx < 4 * 256; idx += 256) {
-        const int blk = idx >> 8, i = (idx >> 4) & 15, j = idx & 15;
-        invDt[(int64_t)(r0 / 16 + blk) * 256 + i * 16 + j] = Y[blk][i][j];
-    }
-    for (int idx = tid; idx < 64 * 64; idx += 256) {
-        const int i = idx >> 6, j = idx & 63;
-        const double v = (j > i) ? S[i][j] : ((j == i) ? S[i][65] : 0.0);
-        A[(int64_t)(r0 + i) * lda + r0 + j] = v;
-    }
-    if (tid < 64) A[(int64_t)(r0 + tid) * lda + rcol] = S[tid][64];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -142,17 +240,20 @@ __global__ __launch_bounds__(256) void syrk_kernel(double *A, int64_t lda, int r
         for (int nn = 0; nn < MT; ++nn) acc[m][nn] = d4{0.0, 0.0, 0.0, 0.0};
     const double *Pa = P + (int64_t)kq * lda + ib + lc;
     const double *Pb = P + (int64_t)kq * lda + jb + lc;
-#pragma unroll 2
+    // software pipeline: fragments of k-step k0+4 are in flight while the MFMAs of k0 issue
+    double a[MT], b[MT], an[MT], bn[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { a[m] = Pa[16 * m]; b[m] = Pb[16 * m]; }
     for (int k0 = 0; k0 < n1; k0 += 4) {
-        double a[MT], b[MT];
+        const int kn = (k0 + 4 < n1) ? k0 + 4 : k0;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a[m] = Pa[(int64_t)k0 * lda + 16 * m];
-#pragma unroll
-        for (int nn = 0; nn < MT; ++nn) b[nn] = Pb[(int64_t)k0 * lda + 16 * nn];
+        for (int m = 0; m < MT; ++m) { an[m] = Pa[(int64_t)kn * lda + 16 * m]; bn[m] = Pb[(int64_t)kn * lda + 16 * m]; }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int nn = 0; nn < MT; ++nn) acc[m][nn] = MFMA_F64(a[m], b[nn], acc[m][nn]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { a[m] = an[m]; b[m] = bn[m]; }
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -168,81 +269,84 @@ __global__ __launch_bounds__(256) void syrk_kernel(double *A, int64_t lda, int r
 static void launch_syrk(hipStream_t s, double *A, int64_t lda, int r0, int n1, int n2, int rcol)
 {
     const int c0 = r0 + n1;
-    if (n2 % 128 == 0) {
-        const int nt = n2 / 128;
-        hipLaunchKernelGGL(syrk_kernel<128>, dim3(nt + 1, nt), dim3(256), 0, s, A, lda, r0, n1, c0, nt, rcol);
-    } else {
-        const int nt = n2 / 64;
-        hipLaunchKernelGGL(syrk_kernel<64>, dim3(nt + 1, nt), dim3(256), 0, s, A, lda, r0, n1, c0, nt, rcol);
-    }
-}
-
-static void potrf_rec(hipStream_t s, double *A, int64_t lda, int r0, int n, int rcol, double *invDt, int *info)
-{
-    if (n == 64) {
-        hipLaunchKernelGGL(potrf_leaf_kernel, dim3(1), dim3(256), 0, s, A, lda, r0, rcol, invDt, info);
-        return;
-    }
-    // split at a multiple of 128 when possible so the panel solve can use 128-row blocks
-    int n1;
-    if (n >= 256) n1 = (int)round_up(n / 2, 128);
-    else if (n == 192) n1 = 128;
-    else n1 = 64;                                  // n == 128
-    const int n2 = n - n1;
-    potrf_rec(s, A, lda, r0, n1, rcol, invDt, info);
-    // panel: A12 <- U11^-T A12   (rows [r0, r0+n1), columns [r0+n1, r0+n))
-    launch_trsm_strips(s, A + (int64_t)r0 * lda + r0, lda, invDt + (int64_t)(r0 / 16) * 256,
-                       A + (int64_t)r0 * lda + r0 + n1, lda, n1, n2, nullptr, 0, nullptr, nullptr);
-    launch_syrk(s, A, lda, r0, n1, n2, rcol);
-    potrf_rec(s, A, lda, r0 + n1, n2, rcol, invDt, info);
+    const int nt = n2 / 128;
+    hipLaunchKernelGGL(syrk_kernel<128>, dim3(nt + 1, nt), dim3(256), 0, s, A, lda, r0, n1, c0, nt, rcol);
 }
 
 void launch_cholesky(hipStream_t s, double *A, int64_t lda, int64_t n_pad, double *invDt, int *info_dev)
 {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag128_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DiagShared));
+        attr_set = true;
+    }
     hipMemsetAsync(info_dev, 0, sizeof(int), s);
-    potrf_rec(s, A, lda, 0, (int)n_pad, (int)n_pad, invDt, info_dev);
+    const int rcol = (int)n_pad;
+    for (int r0 = 0; r0 < (int)n_pad; r0 += 128) {
+        hipLaunchKernelGGL(potrf_diag128_kernel, dim3(1), dim3(256), sizeof(DiagShared), s, A, lda, r0, rcol, invDt,
+                           info_dev);
+        const int n2 = (int)n_pad - r0 - 128;
+        if (n2 <= 0) break;
+        launch_trsm_strips(s, A + (int64_t)r0 * lda + r0, lda, invDt + (int64_t)(r0 / 16) * 256,
+                           A + (int64_t)r0 * lda + r0 + 128, lda, 128, n2, nullptr, nullptr, nullptr);
+        launch_syrk(s, A, lda, r0, 128, n2, rcol);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward solve U alpha = z, 64-row blocks from the bottom.  One launch per block: every workgroup
-// first solves the 64x64 diagonal system redundantly (one wave, lane = row, no barriers inside), then
-// workgroup g folds alpha_blk into the 64 rows of block g above it:  zt[g] -= U[g, blk] alpha_blk.
-// zt is a contiguous working copy of z.
-__global__ __launch_bounds__(256) void backsolve_step_kernel(const double *__restrict__ A, int64_t lda, int blk,
-                                                             double *zt, double *__restrict__ alpha)
+// Backward solve U alpha = z, 128-row blocks from the bottom, one launch per block.  Every workgroup
+// first solves the 128x128 diagonal system redundantly in LDS (16-row sub-blocks: multiply by the
+// stored inv(U_bb), then fold into the rows above), then workgroup g folds alpha_blk into the 128 rows
+// of block g above it:  zt[g] -= U[g, blk] alpha_blk.  zt is a contiguous working copy of z.
+__global__ __launch_bounds__(256) void backsolve_step_kernel(const double *__restrict__ A, int64_t lda,
+                                                             const double *__restrict__ invDt, int blk, double *zt,
+                                                             double *__restrict__ alpha)
 {
-    __shared__ double D[64][65];
-    __shared__ double al[64];
+    __shared__ double zs[128];
+    __shared__ double al[128];
     const int tid = threadIdx.x;
-    const int b0 = blk * 64;
-    for (int idx = tid; idx < 64 * 64; idx += 256) {
-        const int i = idx >> 6, j = idx & 63;
-        D[i][j] = A[(int64_t)(b0 + i) * lda + b0 + j];
-    }
+    const int lane = tid & 63, wave = tid >> 6;
+    const int b0 = blk * 128;
+    if (tid < 128) zs[tid] = zt[b0 + tid];
     __syncthreads();
-    if (tid < 64) {
-        double zi = zt[b0 + tid];
-        const double dii = D[tid][tid];
-        for (int c = 63; c >= 0; --c) {
-            const double ac = __shfl(zi, c) / __shfl(dii, c);     // alpha_c (lane c's residual is final)
-            if (tid == c) al[c] = ac;
-            if (tid < c) zi = fma(-D[tid][c], ac, zi);
+    for (int s = 7; s >= 0; --s) {
+        const int o = 16 * s;
+        // alpha_s = inv(U_ss) zs_s : 16 outputs, thread (i, part) sums 4 of the 16 terms
+        if (tid < 64) {
+            const int i = tid >> 2, part = tid & 3;
+            const double *Y = invDt + (int64_t)(b0 / 16 + s) * 256;      // Y[i][k] = inv(U_ss)[i][k]
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = fma(Y[i * 16 + 4 * part + k], zs[o + 4 * part + k], acc);
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            if (part == 0) al[o + i] = acc;
         }
+        __syncthreads();
+        // rows above inside the block: zs[r] -= sum_c U[b0+r][b0+o+c] al[o+c], r < o
+        if (tid < o) {
+            const double *row = A + (int64_t)(b0 + tid) * lda + b0 + o;
+            double acc = zs[tid];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc = fma(-row[c], al[o + c], acc);
+            zs[tid] = acc;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const int g = blockIdx.x;
     if (g == blk) {
-        if (tid < 64) alpha[b0 + tid] = al[tid];
+        if (tid < 128) alpha[b0 + tid] = al[tid];
         return;
     }
-    const int i = tid >> 2, part = tid & 3;
-    const double *row = A + (int64_t)(g * 64 + i) * lda + b0 + 16 * part;
-    double s = 0.0;
+    // one row per wave iteration: 64 lanes x 2 columns, wave-level reduction
+    for (int i = wave; i < 128; i += 4) {
+        const d2 u = *reinterpret_cast<const d2 *>(&A[(int64_t)(g * 128 + i) * lda + b0 + 2 * lane]);
+        double acc = fma(u[0], al[2 * lane], u[1] * al[2 * lane + 1]);
 #pragma unroll
-    for (int c = 0; c < 16; ++c) s = fma(row[c], al[16 * part + c], s);
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    if (part == 0) zt[g * 64 + i] -= s;
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) zt[g * 128 + i] -= acc;
+    }
 }
 
 __global__ void copy_strided_kernel(const double *__restrict__ src, int64_t stride, int64_t n, double *__restrict__ dst)
@@ -251,17 +355,15 @@ __global__ void copy_strided_kernel(const double *__restrict__ src, int64_t stri
     if (i < n) dst[i] = src[i * stride];
 }
 
-// alpha doubles as the working copy: first alpha <- z, then blocks are finalised bottom-up.
-void launch_backsolve(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, double *alpha)
+// The caller provides alpha with 2*n_pad doubles: [0, n_pad) result, [n_pad, 2 n_pad) working copy of z.
+void launch_backsolve(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt, double *alpha)
 {
-    // zt lives in alpha's upper half?  No: keep a separate contiguous copy so alpha is written once.
-    // The caller provides alpha with 2*n_pad doubles: [0, n_pad) result, [n_pad, 2 n_pad) working z.
     double *zt = alpha + n_pad;
     hipLaunchKernelGGL(copy_strided_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, A + n_pad, lda,
                        n_pad, zt);
-    const int nb = (int)(n_pad / 64);
+    const int nb = (int)(n_pad / 128);
     for (int blk = nb - 1; blk >= 0; --blk)
-        hipLaunchKernelGGL(backsolve_step_kernel, dim3(blk + 1), dim3(256), 0, s, A, lda, blk, zt, alpha);
+        hipLaunchKernelGGL(backsolve_step_kernel, dim3(blk + 1), dim3(256), 0, s, A, lda, invDt, blk, zt, alpha);
 }
 
 }  // namespace cbo

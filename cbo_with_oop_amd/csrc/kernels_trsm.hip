@@ -1,7 +1,7 @@
 // Strip-parallel forward substitution  V <- L^-1 V  on fp64 MFMA (v_mfma_f64_16x16x4_f64), gfx950.
 //
 // This is the dominant kernel of the acquisition sweep (predictive variance = kss - |L^-1 k*|^2,
-// GPy Posterior._raw_predict, triangular form) and also the panel solve of the recursive Cholesky.
+// GPy Posterior._raw_predict, triangular form) and also the panel solve of the blocked Cholesky.
 //
 // Decomposition: one 256-thread workgroup per strip of 64 right-hand-side columns; wave w owns the
 // 16 columns [16w, 16w+16) of the strip for ALL rows, so the four waves never exchange V data and a
@@ -10,10 +10,11 @@
 //             V[blk] = L[blk,blk]^-1 R                 (16x16 diagonal inverses + MFMA updates)
 // The L operand is the transposed factor U (U[k][i] = L[i][k], row-major) so an A fragment
 // "A[i = lane&15][k = lane>>4]" is a read of 4 row segments of 128 B; U tiles of 32 x RB are staged
-// through LDS (double-buffered, shared by the four waves).  The B fragment "B[k = lane>>4][j = lane&15]"
+// through LDS (double-buffered, shared by the four waves), and the diagonal block's 16x16 tiles are
+// staged through the same LDS for the in-block phase.  The B fragment "B[k = lane>>4][j = lane&15]"
 // comes straight from V in global memory.  The f64 MFMA result map (row = (lane>>4) + 4*reg, col =
 // lane&15) is exactly the B-operand map of k-step `reg`, so results feed the next MFMA with no data
-// movement.
+// movement.  A fragments of k-step j+1 are read from LDS while the MFMAs of k-step j issue.
 //
 // Roofline: fp64 MFMA bound.  Algorithmic work n^2 flops per column (n^2/2 FMAs); V re-read traffic is
 // n^2/(2*RB) * 8 B per column (left-looking), U traffic n^2/2*8 B per strip served from L2/MALL.
@@ -25,10 +26,18 @@ namespace cbo {
 
 constexpr int kKB = 32;   // rows of U staged per LDS stage (8 MFMA k-steps)
 
-template <int RB>
+// position of the 16x16 tile (s, t), s <= t, in the in-block LDS image: the T diagonal inverses first,
+// then the strictly-upper tiles row by row
+template <int T>
+__host__ __device__ constexpr int tile_slot(int s, int t)
+{
+    return (s == t) ? s : T + s * (2 * T - 1 - s) / 2 + (t - s - 1);
+}
+
+template <int RB, bool SWEEP>
 __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restrict__ U, int64_t ldu,
                                                          const double *__restrict__ invDt, double *V, int64_t ldv,
-                                                         int n, const double *__restrict__ z, int64_t z_stride,
+                                                         int n, const double *__restrict__ z,
                                                          double *__restrict__ q_out, double *__restrict__ mu_out)
 {
     constexpr int T = RB / 16;            // 16-row tiles per row block
@@ -36,7 +45,9 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
     constexpr int TPR = RB / 2;           // threads per staged row (16 B each)
     constexpr int RPP = 256 / TPR;        // rows per staging pass
     constexpr int NP = kKB / RPP;         // staging passes per stage
-    __shared__ double lds[2][kKB][LDS_LD];
+    constexpr int NTILE = T + T * (T - 1) / 2;
+    static_assert(NTILE * 256 <= 2 * kKB * LDS_LD, "in-block tile image must fit the stage buffers");
+    __shared__ __align__(16) double lds[2 * kKB * LDS_LD];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -44,6 +55,7 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
     const int64_t col = (int64_t)blockIdx.x * kStrip + wave * 16 + lc;
     double *Vc = V + col;
     const int s_rr = tid / TPR, s_cc = (tid % TPR) * 2;
+    const int frag_off = kq * LDS_LD + lc;                 // + (4 j) * LDS_LD + 16 t within a stage buffer
 
     double qacc = 0.0, macc = 0.0;
 
@@ -57,98 +69,139 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
         const int nst = i0 / kKB;
         if (nst > 0) {
             d2 st[NP];
-            double bcur[8], bnext[8];
+            double bA[8], bB[8];
+            const double *Ug = U + (int64_t)s_rr * ldu + i0 + s_cc;
+            auto load_stage = [&](int k1, double (&bv)[8]) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
-                st[p] = *reinterpret_cast<const d2 *>(&U[(int64_t)(p * RPP + s_rr) * ldu + i0 + s_cc]);
+                for (int p = 0; p < NP; ++p)
+                    st[p] = *reinterpret_cast<const d2 *>(&Ug[(int64_t)(k1 + p * RPP) * ldu]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bcur[j] = Vc[(int64_t)(4 * j + kq) * ldv];
+                for (int j = 0; j < 8; ++j) bv[j] = Vc[(int64_t)(k1 + 4 * j + kq) * ldv];
+            };
+            auto store_stage = [&](int buf) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p) *reinterpret_cast<d2 *>(&lds[0][p * RPP + s_rr][s_cc]) = st[p];
-            __syncthreads();
-            for (int s = 0; s < nst; ++s) {
-                const int cur = s & 1;
-                const bool more = (s + 1) < nst;
-                if (more) {
-                    const int k1 = (s + 1) * kKB;
+                for (int p = 0; p < NP; ++p)
+                    *reinterpret_cast<d2 *>(&lds[buf * kKB * LDS_LD + (p * RPP + s_rr) * LDS_LD + s_cc]) = st[p];
+            };
+            auto compute_stage = [&](int buf, const double (&bv)[8]) {
+                const double *base = &lds[buf * kKB * LDS_LD + frag_off];
+                double af[2][T];
 #pragma unroll
-                    for (int p = 0; p < NP; ++p)
-                        st[p] = *reinterpret_cast<const d2 *>(&U[(int64_t)(k1 + p * RPP + s_rr) * ldu + i0 + s_cc]);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) bnext[j] = Vc[(int64_t)(k1 + 4 * j + kq) * ldv];
-                }
+                for (int t = 0; t < T; ++t) af[0][t] = base[16 * t];
+                __builtin_amdgcn_sched_group_barrier(0x100, T, 0);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const double nb = -bcur[j];
+                    if (j < 7) {
 #pragma unroll
-                    for (int t = 0; t < T; ++t) {
-                        const double a = lds[cur][4 * j + kq][16 * t + lc];
-                        acc[t] = MFMA_F64(a, nb, acc[t]);
+                        for (int t = 0; t < T; ++t) af[(j + 1) & 1][t] = base[4 * (j + 1) * LDS_LD + 16 * t];
                     }
-                }
-                if (more) {
+                    const double nb = -bv[j];
 #pragma unroll
-                    for (int p = 0; p < NP; ++p)
-                        *reinterpret_cast<d2 *>(&lds[cur ^ 1][p * RPP + s_rr][s_cc]) = st[p];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) bcur[j] = bnext[j];
+                    for (int t = 0; t < T; ++t) acc[t] = MFMA_F64(af[j & 1][t], nb, acc[t]);
+                    // pin "LDS reads of step j+1, then the MFMAs of step j": the reads complete under the MFMAs
+                    if (j < 7) __builtin_amdgcn_sched_group_barrier(0x100, T, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, T, 0);
                 }
+            };
+            load_stage(0, bA);
+            store_stage(0);
+            __syncthreads();
+            int s = 0;
+            for (;;) {
+                bool more = (s + 1) < nst;
+                if (more) load_stage((s + 1) * kKB, bB);
+                compute_stage(0, bA);
+                if (more) store_stage(1);
                 __syncthreads();
+                if (++s >= nst) break;
+                more = (s + 1) < nst;
+                if (more) load_stage((s + 1) * kKB, bA);
+                compute_stage(1, bB);
+                if (more) store_stage(0);
+                __syncthreads();
+                if (++s >= nst) break;
             }
         }
 
-        // Diagonal block: X_s = inv(L_ss) R_s, then R_t -= L_ts X_s for the tiles below.
-        const double *Ud = U + (int64_t)i0 * ldu + i0;
-        const double *iD = invDt + (int64_t)(i0 / 16) * 256;
-#pragma unroll
-        for (int s = 0; s < T; ++s) {
-            d4 x = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const double a = iD[s * 256 + (4 * kk + kq) * 16 + lc];
-                x = MFMA_F64(a, acc[s][kk], x);
+        // ---- diagonal block: stage its 16x16 tiles (inverses of the diagonal ones) through LDS
+        {
+            const double *Ud = U + (int64_t)i0 * ldu + i0;
+            const double *iD = invDt + (int64_t)(i0 / 16) * 256;
+            for (int idx = tid; idx < NTILE * 128; idx += 256) {
+                const int p = idx >> 7, e = idx & 127;
+                const int k = e >> 3, i2 = (e & 7) * 2;
+                const double *src;
+                if (p < T) {
+                    src = iD + p * 256 + k * 16 + i2;
+                } else {
+                    // invert tile_slot: find (s, t) with slot p
+                    int s = 0, rem = p - T;
+                    while (rem >= T - 1 - s) { rem -= T - 1 - s; ++s; }
+                    const int t = s + 1 + rem;
+                    src = Ud + (int64_t)(16 * s + k) * ldu + 16 * t + i2;
+                }
+                *reinterpret_cast<d2 *>(&lds[p * 256 + k * 16 + i2]) = *reinterpret_cast<const d2 *>(src);
             }
+            __syncthreads();
+            const double *tl = &lds[kq * 16 + lc];           // + slot*256 + (4 kk)*16
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = i0 + 16 * s + kq + 4 * r;
-                Vc[(int64_t)row * ldv] = x[r];
-                qacc = fma(x[r], x[r], qacc);
-                if (z) macc = fma(x[r], z[(int64_t)row * z_stride], macc);
-            }
+            for (int s = 0; s < T; ++s) {
+                d4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int t = s + 1; t < T; ++t) {
+                for (int kk = 0; kk < 4; ++kk) x = MFMA_F64(tl[tile_slot<T>(s, s) * 256 + 64 * kk], acc[s][kk], x);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const double a = Ud[(int64_t)(16 * s + 4 * kk + kq) * ldu + 16 * t + lc];
-                    acc[t] = MFMA_F64(a, -x[kk], acc[t]);
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i0 + 16 * s + kq + 4 * r;
+                    Vc[(int64_t)row * ldv] = x[r];
+                    if (SWEEP) {
+                        qacc = fma(x[r], x[r], qacc);
+                        macc = fma(x[r], z[row], macc);
+                    }
+                }
+#pragma unroll
+                for (int t = s + 1; t < T; ++t) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        acc[t] = MFMA_F64(tl[tile_slot<T>(s, t) * 256 + 64 * kk], -x[kk], acc[t]);
                 }
             }
+            __syncthreads();                                  // the next block's staging reuses the LDS
         }
     }
 
-    if (q_out) {
+    if (SWEEP) {
         qacc += __shfl_xor(qacc, 16);
         qacc += __shfl_xor(qacc, 32);
         macc += __shfl_xor(macc, 16);
         macc += __shfl_xor(macc, 32);
         if (kq == 0) {
             q_out[col] = qacc;
-            if (mu_out) mu_out[col] = macc;
+            mu_out[col] = macc;
         }
     }
 }
 
 void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const double *invDt, double *V, int64_t ldv,
-                        int64_t n, int64_t m_pad, const double *z, int64_t z_stride, double *q, double *mu)
+                        int64_t n, int64_t m_pad, const double *z, double *q, double *mu)
 {
     if (n <= 0 || m_pad <= 0) return;
     const dim3 grid((unsigned)(m_pad / kStrip));
-    if (n % 128 == 0)
-        hipLaunchKernelGGL(trsm_strip_kernel<128>, grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, z_stride,
-                           q, mu);
-    else
-        hipLaunchKernelGGL(trsm_strip_kernel<64>, grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, z_stride, q,
-                           mu);
+    const bool sweep = q != nullptr;
+    if (n % 128 == 0) {
+        if (sweep)
+            hipLaunchKernelGGL((trsm_strip_kernel<128, true>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z,
+                               q, mu);
+        else
+            hipLaunchKernelGGL((trsm_strip_kernel<128, false>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n,
+                               z, q, mu);
+    } else {
+        if (sweep)
+            hipLaunchKernelGGL((trsm_strip_kernel<64, true>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z,
+                               q, mu);
+        else
+            hipLaunchKernelGGL((trsm_strip_kernel<64, false>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z,
+                               q, mu);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
