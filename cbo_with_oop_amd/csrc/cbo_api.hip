@@ -68,6 +68,7 @@ struct cbo_gp {
     double *z = nullptr;             // [n_pad] contiguous copy of L^-1 r
     int *info = nullptr;
     bool fitted = false;
+    bool alpha_ready = false;
     int tries = 0;
     double jitter = 0.0;
 };
@@ -395,20 +396,33 @@ extern "C" int cbo_gp_fit(cbo_gp *g, int *tries_out, double *jitter_out)
         if (tries > 5 || !std::isfinite(jitter))
             return fail(CBO_ERR_NOT_PD, "not positive definite, even with jitter.");
     }
-    {
-        PhaseScope ps(c, PH_ALPHA);
-        launch_backsolve(c->stream, g->A, g->lda, g->n_pad, g->invDt, g->alpha);
-        // contiguous z for the sweep (alpha[n_pad..] held the working copy and is consumed by the solve)
-        HIP_TRY(hipMemcpy2DAsync(g->z, sizeof(double), g->A + g->n_pad, sizeof(double) * g->lda, sizeof(double),
-                                 (size_t)g->n_pad, hipMemcpyDeviceToDevice, c->stream));
-    }
+    // contiguous z = L^-1 (y - m) for the sweep: the posterior mean is (L^-1 k*)^T z, so the backward
+    // solve for alpha = L^-T z is not on the sweep's path and is materialised on first use (ensure_alpha)
+    HIP_TRY(hipMemcpy2DAsync(g->z, sizeof(double), g->A + g->n_pad, sizeof(double) * g->lda, sizeof(double),
+                             (size_t)g->n_pad, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipGetLastError());
     g->fitted = true;
+    g->alpha_ready = false;
     g->tries = tries;
     g->jitter = jitter;
     if (c->profiling) c->timers.n_fit += 1;
     if (tries_out) *tries_out = tries;
     if (jitter_out) *jitter_out = jitter;
+    return CBO_OK;
+}
+
+// GPy's woodbury_vector alpha = Ky^-1 (y - m) = L^-T z (dpotrs): needed by posterior export and by
+// prediction gradients, not by predict / the acquisition sweep.
+static int ensure_alpha(cbo_gp *g)
+{
+    if (g->alpha_ready) return CBO_OK;
+    cbo_ctx *c = g->ctx;
+    {
+        PhaseScope ps(c, PH_ALPHA);
+        launch_backsolve(c->stream, g->A, g->lda, g->n_pad, g->invDt, g->alpha);
+    }
+    HIP_TRY(hipGetLastError());
+    g->alpha_ready = true;
     return CBO_OK;
 }
 
@@ -439,6 +453,8 @@ extern "C" int cbo_gp_get_posterior(cbo_gp *g, double *L_out, double *alpha_out)
         HIP_TRY(e);
     }
     if (alpha_out) {
+        const int rc = ensure_alpha(g);
+        if (rc != CBO_OK) return rc;
         HIP_TRY(hipMemcpyAsync(alpha_out, g->alpha, sizeof(double) * g->n, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }

@@ -36,7 +36,7 @@ struct DiagShared {
     double S[128][kDiagLd];    // the block; upper triangle is meaningful
     double rz[128];            // rhs column
     double Ud[16][16];         // current 16x16 diagonal factor (upper)
-    double invd[16];           // reciprocals of its diagonal
+    double invd[128];          // reciprocals of the factor's diagonal
 };
 
 // Register Cholesky of the 16x16 tile at (o, o): lane c (mod 16) owns column c.  Executed by one wave.
@@ -53,15 +53,17 @@ __device__ __forceinline__ void diag_tile_factor(DiagShared &sh, int o, int lane
             if (lane == 0) atomicCAS(info, 0, pivot_base + o + j + 1);
             pj = 1.0;                             // keep the arithmetic finite; the result is discarded
         }
-        const double dj = sqrt(pj);
-        const double inv = 1.0 / dj;
+        // d = sqrt(p) and 1/d from one reciprocal square root (1-2 ulp; the row is scaled by the same 1/d)
+        const double inv = rsqrt(pj);
+        const double dj = pj * inv;
         a[j] = (c == j) ? dj : a[j] * inv;
-        if (lane == 0) sh.invd[j] = inv;
+        if (lane == 0) sh.invd[o + j] = inv;
 #pragma unroll
         for (int r = j + 1; r < 16; ++r) {
             const double ujr = readlane_f64(a[j], r);
             a[r] = fma(-ujr, a[j], a[r]);
         }
+        __builtin_amdgcn_sched_barrier(0);        // keep the broadcast scalars of one pivot step live at a time
     }
     if (lane < 16) {
 #pragma unroll
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t l
                 double s = x[i];
 #pragma unroll
                 for (int k = 0; k < i; ++k) s = fma(-sh.Ud[k][i], x[k], s);
-                x[i] = s * sh.invd[i];
+                x[i] = s * sh.invd[o + i];
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t l
             double s = (i == j) ? 1.0 : 0.0;
 #pragma unroll
             for (int k = i + 1; k < 16; ++k) s = fma(-sh.S[o + i][o + k], (k <= j) ? y[k] : 0.0, s);
-            y[i] = (i <= j) ? s / sh.S[o + i][o + i] : 0.0;
+            y[i] = (i <= j) ? s * sh.invd[o + i] : 0.0;
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) invDt[(int64_t)(r0 / 16 + b) * 256 + i * 16 + j] = y[i];
@@ -269,8 +271,8 @@ __global__ __launch_bounds__(256) void syrk_kernel(double *A, int64_t lda, int r
 static void launch_syrk(hipStream_t s, double *A, int64_t lda, int r0, int n1, int n2, int rcol)
 {
     const int c0 = r0 + n1;
-    const int nt = n2 / 128;
-    hipLaunchKernelGGL(syrk_kernel<128>, dim3(nt + 1, nt), dim3(256), 0, s, A, lda, r0, n1, c0, nt, rcol);
+    const int nt = n2 / 64;
+    hipLaunchKernelGGL(syrk_kernel<64>, dim3(nt + 1, nt), dim3(256), 0, s, A, lda, r0, n1, c0, nt, rcol);
 }
 
 void launch_cholesky(hipStream_t s, double *A, int64_t lda, int64_t n_pad, double *invDt, int *info_dev)
