@@ -24,119 +24,122 @@ namespace cbo {
 
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-constexpr int kKB = 32;   // rows of U staged per LDS stage (8 MFMA k-steps)
+#define SCHED_DS(n) __builtin_amdgcn_sched_group_barrier(0x100, (n), 0)
+#define SCHED_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, (n), 0)
 
-// position of the 16x16 tile (s, t), s <= t, in the in-block LDS image: the T diagonal inverses first,
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
+// LDS-DMA: 64 lanes x 16 B land at (wave-uniform LDS base) + lane * 16; the global address is per lane.
+#define GLDS16(gptr, lptr) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gptr), (lds_ptr_t)(lptr), 16, 0, 0)
+
+constexpr int kRB = 128;                  // rows per block
+constexpr int kT = kRB / 16;              // 16-row tiles per block
+constexpr int kKB = 32;                   // rows of U / V per pipeline stage (8 MFMA k-steps)
+constexpr int kLdsLd = kRB + 16;          // U-tile row stride: rows kq and kq+1 land 32 banks apart (ds_read_b64)
+constexpr int kNBuf = 3;                  // pipeline depth: DMA of stage s+2 is in flight while stage s computes
+constexpr int kABuf = kKB * kLdsLd;       // doubles per U stage buffer
+constexpr int kBBuf = 4 * kKB * 16;       // doubles per V stage buffer (4 waves x [32 k][16 cols])
+constexpr int kDmaPerStage = 8 + 4;       // LDS-DMA instructions a wave issues per stage (8 U rows + 4 V pieces)
+constexpr int kNTile = kT + kT * (kT - 1) / 2;
+static_assert(kNTile * 256 <= kNBuf * kABuf, "in-block tile image must fit the U stage buffers");
+
+// position of the 16x16 tile (s, t), s <= t, in the in-block LDS image: the kT diagonal inverses first,
 // then the strictly-upper tiles row by row
-template <int T>
 __host__ __device__ constexpr int tile_slot(int s, int t)
 {
-    return (s == t) ? s : T + s * (2 * T - 1 - s) / 2 + (t - s - 1);
+    return (s == t) ? s : kT + s * (2 * kT - 1 - s) / 2 + (t - s - 1);
 }
 
-template <int RB, bool SWEEP>
+template <bool SWEEP>
 __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restrict__ U, int64_t ldu,
                                                          const double *__restrict__ invDt, double *V, int64_t ldv,
                                                          int n, const double *__restrict__ z,
                                                          double *__restrict__ q_out, double *__restrict__ mu_out)
 {
-    constexpr int T = RB / 16;            // 16-row tiles per row block
-    constexpr int LDS_LD = RB + 16;       // row stride: rows kq and kq+1 land 32 banks apart (ds_read_b64)
-    constexpr int TPR = RB / 2;           // threads per staged row (16 B each)
-    constexpr int RPP = 256 / TPR;        // rows per staging pass
-    constexpr int NP = kKB / RPP;         // staging passes per stage
-    constexpr int NTILE = T + T * (T - 1) / 2;
-    static_assert(NTILE * 256 <= 2 * kKB * LDS_LD, "in-block tile image must fit the stage buffers");
-    __shared__ __align__(16) double lds[2 * kKB * LDS_LD];
+    __shared__ __align__(16) double lds[kNBuf * (kABuf + kBBuf)];      // 159,744 B of the CU's 160 KiB
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, kq = lane >> 4;
-    const int64_t col = (int64_t)blockIdx.x * kStrip + wave * 16 + lc;
-    double *Vc = V + col;
-    const int s_rr = tid / TPR, s_cc = (tid % TPR) * 2;
-    const int frag_off = kq * LDS_LD + lc;                 // + (4 j) * LDS_LD + 16 t within a stage buffer
+    const int64_t colw = (int64_t)blockIdx.x * kStrip + wave * 16;     // first column of this wave
+    double *Vc = V + colw + lc;
+    double *ldsB = lds + kNBuf * kABuf;
 
     double qacc = 0.0, macc = 0.0;
 
-    for (int i0 = 0; i0 < n; i0 += RB) {
-        d4 acc[T];
+    for (int i0 = 0; i0 < n; i0 += kRB) {
+        d4 acc[kT];
 #pragma unroll
-        for (int t = 0; t < T; ++t)
+        for (int t = 0; t < kT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[t][r] = Vc[(int64_t)(i0 + 16 * t + kq + 4 * r) * ldv];
 
         const int nst = i0 / kKB;
         if (nst > 0) {
-            d2 st[NP];
-            double bA[8], bB[8];
-            const double *Ug = U + (int64_t)s_rr * ldu + i0 + s_cc;
-            auto load_stage = [&](int k1, double (&bv)[8]) {
+            // Every operand of the K-loop reaches LDS by LDS-DMA (no register staging), three stages deep.
+            const double *ug = U + (int64_t)(wave * 8) * ldu + i0 + lane * 2;
+            const double *vg = V + (int64_t)(lane >> 3) * ldv + colw + 2 * (lane & 7);
+            auto issue_stage = [&](int k1, int buf) __attribute__((always_inline)) {
+                double *la = lds + buf * kABuf + (wave * 8) * kLdsLd;
+                const double *g = ug + (int64_t)k1 * ldu;
 #pragma unroll
-                for (int p = 0; p < NP; ++p)
-                    st[p] = *reinterpret_cast<const d2 *>(&Ug[(int64_t)(k1 + p * RPP) * ldu]);
+                for (int p = 0; p < 8; ++p) GLDS16(g + (int64_t)p * ldu, la + p * kLdsLd);   // one 1 KiB row each
+                double *lb = ldsB + buf * kBBuf + wave * (kKB * 16);
+                const double *gv = vg + (int64_t)k1 * ldv;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bv[j] = Vc[(int64_t)(k1 + 4 * j + kq) * ldv];
+                for (int p = 0; p < 4; ++p) GLDS16(gv + (int64_t)(8 * p) * ldv, lb + p * 128);   // 8 rows x 128 B each
             };
-            auto store_stage = [&](int buf) {
+            auto compute_stage = [&](int buf) __attribute__((always_inline)) {
+                const double *abase = lds + buf * kABuf + kq * kLdsLd + lc;
+                const double *bbase = ldsB + buf * kBBuf + wave * (kKB * 16) + kq * 16 + lc;
+                double af[2][kT], bf[2];
 #pragma unroll
-                for (int p = 0; p < NP; ++p)
-                    *reinterpret_cast<d2 *>(&lds[buf * kKB * LDS_LD + (p * RPP + s_rr) * LDS_LD + s_cc]) = st[p];
-            };
-            auto compute_stage = [&](int buf, const double (&bv)[8]) {
-                const double *base = &lds[buf * kKB * LDS_LD + frag_off];
-                double af[2][T];
-#pragma unroll
-                for (int t = 0; t < T; ++t) af[0][t] = base[16 * t];
-                __builtin_amdgcn_sched_group_barrier(0x100, T, 0);
+                for (int t = 0; t < kT; ++t) af[0][t] = abase[16 * t];
+                bf[0] = bbase[0];
+                SCHED_DS(kT + 1);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (j < 7) {
 #pragma unroll
-                        for (int t = 0; t < T; ++t) af[(j + 1) & 1][t] = base[4 * (j + 1) * LDS_LD + 16 * t];
+                        for (int t = 0; t < kT; ++t) af[(j + 1) & 1][t] = abase[4 * (j + 1) * kLdsLd + 16 * t];
+                        bf[(j + 1) & 1] = bbase[4 * (j + 1) * 16];
                     }
-                    const double nb = -bv[j];
+                    const double nb = -bf[j & 1];
 #pragma unroll
-                    for (int t = 0; t < T; ++t) acc[t] = MFMA_F64(af[j & 1][t], nb, acc[t]);
+                    for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[j & 1][t], nb, acc[t]);
                     // pin "LDS reads of step j+1, then the MFMAs of step j": the reads complete under the MFMAs
-                    if (j < 7) __builtin_amdgcn_sched_group_barrier(0x100, T, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, T, 0);
+                    if (j < 7) { SCHED_DS(kT + 1); }
+                    SCHED_MFMA(kT);
                 }
             };
-            load_stage(0, bA);
-            store_stage(0);
-            __syncthreads();
-            int s = 0;
-            for (;;) {
-                bool more = (s + 1) < nst;
-                if (more) load_stage((s + 1) * kKB, bB);
-                compute_stage(0, bA);
-                if (more) store_stage(1);
-                __syncthreads();
-                if (++s >= nst) break;
-                more = (s + 1) < nst;
-                if (more) load_stage((s + 1) * kKB, bA);
-                compute_stage(1, bB);
-                if (more) store_stage(0);
-                __syncthreads();
-                if (++s >= nst) break;
+            issue_stage(0, 0);
+            if (nst > 1) issue_stage(kKB, 1);
+            for (int s = 0; s < nst; ++s) {
+                // this wave's DMA of stage s has landed once at most stage s+1's instructions are outstanding
+                // (vmcnt retires in order); the barrier then publishes every wave's share of the stage and
+                // guarantees that buffer (s+2)%3, read during stage s-1, may be overwritten
+                if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerStage) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (s + 2 < nst) issue_stage((s + 2) * kKB, (s + 2) % kNBuf);
+                compute_stage(s % kNBuf);
             }
+            __syncthreads();                                  // all reads of the last stage done before LDS reuse
         }
 
         // ---- diagonal block: stage its 16x16 tiles (inverses of the diagonal ones) through LDS
         {
             const double *Ud = U + (int64_t)i0 * ldu + i0;
             const double *iD = invDt + (int64_t)(i0 / 16) * 256;
-            for (int idx = tid; idx < NTILE * 128; idx += 256) {
+            for (int idx = tid; idx < kNTile * 128; idx += 256) {
                 const int p = idx >> 7, e = idx & 127;
                 const int k = e >> 3, i2 = (e & 7) * 2;
                 const double *src;
-                if (p < T) {
+                if (p < kT) {
                     src = iD + p * 256 + k * 16 + i2;
                 } else {
-                    // invert tile_slot: find (s, t) with slot p
-                    int s = 0, rem = p - T;
-                    while (rem >= T - 1 - s) { rem -= T - 1 - s; ++s; }
+                    int s = 0, rem = p - kT;                  // invert tile_slot: find (s, t) with slot p
+                    while (rem >= kT - 1 - s) { rem -= kT - 1 - s; ++s; }
                     const int t = s + 1 + rem;
                     src = Ud + (int64_t)(16 * s + k) * ldu + 16 * t + i2;
                 }
@@ -145,10 +148,10 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
             __syncthreads();
             const double *tl = &lds[kq * 16 + lc];           // + slot*256 + (4 kk)*16
 #pragma unroll
-            for (int s = 0; s < T; ++s) {
+            for (int s = 0; s < kT; ++s) {
                 d4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) x = MFMA_F64(tl[tile_slot<T>(s, s) * 256 + 64 * kk], acc[s][kk], x);
+                for (int kk = 0; kk < 4; ++kk) x = MFMA_F64(tl[tile_slot(s, s) * 256 + 64 * kk], acc[s][kk], x);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = i0 + 16 * s + kq + 4 * r;
@@ -159,13 +162,13 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
                     }
                 }
 #pragma unroll
-                for (int t = s + 1; t < T; ++t) {
+                for (int t = s + 1; t < kT; ++t) {
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
-                        acc[t] = MFMA_F64(tl[tile_slot<T>(s, t) * 256 + 64 * kk], -x[kk], acc[t]);
+                        acc[t] = MFMA_F64(tl[tile_slot(s, t) * 256 + 64 * kk], -x[kk], acc[t]);
                 }
             }
-            __syncthreads();                                  // the next block's staging reuses the LDS
+            __syncthreads();                                  // the next block's DMA reuses the LDS
         }
     }
 
@@ -175,8 +178,8 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
         macc += __shfl_xor(macc, 16);
         macc += __shfl_xor(macc, 32);
         if (kq == 0) {
-            q_out[col] = qacc;
-            mu_out[col] = macc;
+            q_out[colw + lc] = qacc;
+            mu_out[colw + lc] = macc;
         }
     }
 }
@@ -185,23 +188,12 @@ void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const doubl
                         int64_t n, int64_t m_pad, const double *z, double *q, double *mu)
 {
     if (n <= 0 || m_pad <= 0) return;
+    // n is a multiple of 128 at every call site (n_pad of the sweep, the 128-row Cholesky panel)
     const dim3 grid((unsigned)(m_pad / kStrip));
-    const bool sweep = q != nullptr;
-    if (n % 128 == 0) {
-        if (sweep)
-            hipLaunchKernelGGL((trsm_strip_kernel<128, true>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z,
-                               q, mu);
-        else
-            hipLaunchKernelGGL((trsm_strip_kernel<128, false>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n,
-                               z, q, mu);
-    } else {
-        if (sweep)
-            hipLaunchKernelGGL((trsm_strip_kernel<64, true>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z,
-                               q, mu);
-        else
-            hipLaunchKernelGGL((trsm_strip_kernel<64, false>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z,
-                               q, mu);
-    }
+    if (q != nullptr)
+        hipLaunchKernelGGL(trsm_strip_kernel<true>, grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu);
+    else
+        hipLaunchKernelGGL(trsm_strip_kernel<false>, grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu);
 }
 
 // ------------------------------------------------------------------------------------------------
