@@ -26,6 +26,7 @@ namespace cbo {
 
 #define SCHED_DS(n) __builtin_amdgcn_sched_group_barrier(0x100, (n), 0)
 #define SCHED_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, (n), 0)
+#define SCHED_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x010, (n), 0)
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
@@ -40,15 +41,21 @@ constexpr int kNBuf = 3;                  // pipeline depth: DMA of stage s+2 is
 constexpr int kABuf = kKB * kLdsLd;       // doubles per U stage buffer
 constexpr int kBBuf = 4 * kKB * 16;       // doubles per V stage buffer (4 waves x [32 k][16 cols])
 constexpr int kDmaPerStage = 8 + 4;       // LDS-DMA instructions a wave issues per stage (8 U rows + 4 V pieces)
-constexpr int kNTile = kT + kT * (kT - 1) / 2;
-static_assert(kNTile * 256 <= kNBuf * kABuf, "in-block tile image must fit the U stage buffers");
+// One continuous software pipeline over "stages" of 32 U-rows.  Row block b (rows i0 = 128 b) consists
+// of nst = i0/32 regular stages (k rows [32 j, 32 j + 32) against the block's 128 columns) followed by four
+// diagonal stages (k rows i0 + 32 m: the block's own upper-triangular part).  Every stage's U tile
+// [32][128] is fetched by the same LDS-DMA pattern; the per-wave B region receives V rows (regular
+// stages) or the two 16x16 diagonal inverses (diagonal stages).  The DMA of stage g+2 is issued while
+// stage g computes, across block boundaries, so the pipeline never drains.
+struct StageCursor {
+    int i0, j, lim;                       // block origin, stage index within the block, stages in the block
+    __device__ __forceinline__ void advance()
+    {
+        if (++j == lim) { i0 += kRB; j = 0; lim = i0 / kKB + 4; }
+    }
+};
 
-// position of the 16x16 tile (s, t), s <= t, in the in-block LDS image: the kT diagonal inverses first,
-// then the strictly-upper tiles row by row
-__host__ __device__ constexpr int tile_slot(int s, int t)
-{
-    return (s == t) ? s : kT + s * (2 * kT - 1 - s) / 2 + (t - s - 1);
-}
+constexpr int kStoresPerDiagStage = 8;    // V stores a wave issues per diagonal stage (2 tiles x 4 rows)
 
 template <bool SWEEP>
 __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restrict__ U, int64_t ldu,
@@ -64,32 +71,63 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
     const int64_t colw = (int64_t)blockIdx.x * kStrip + wave * 16;     // first column of this wave
     double *Vc = V + colw + lc;
     double *ldsB = lds + kNBuf * kABuf;
+    const double *ug = U + (int64_t)(wave * 8) * ldu + lane * 2;
+    const double *vg = V + (int64_t)(lane >> 3) * ldv + colw + 2 * (lane & 7);
 
+    // LDS-DMA of one stage into buffer `buf` (12 instructions per wave, branch-free; a cursor past the end is
+    // clamped to the last stage, whose buffer is free by then, so the in-flight counts stay uniform)
+    auto issue_stage = [&](const StageCursor &c, int buf) __attribute__((always_inline)) {
+        const bool past = c.i0 >= n;
+        const int ai0 = past ? n - kRB : c.i0;
+        const int aj = past ? (n - kRB) / kKB + 3 : c.j;
+        const int nreg = ai0 / kKB;
+        double *la = lds + buf * kABuf + (wave * 8) * kLdsLd;
+        const double *g = ug + (int64_t)(kKB * aj) * ldu + ai0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) GLDS16(g + (int64_t)p * ldu, la + p * kLdsLd);       // one 1 KiB row each
+        const bool diag = aj >= nreg;
+        const double *bsrc = diag ? invDt + ((int64_t)(ai0 / 16) + 2 * (aj - nreg)) * 256 + lane * 2
+                                  : vg + (int64_t)(kKB * aj) * ldv;
+        const int64_t bstride = diag ? 128 : 8 * ldv;
+        double *lb = ldsB + buf * kBBuf + wave * (kKB * 16);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) GLDS16(bsrc + p * bstride, lb + p * 128);            // 1 KiB pieces
+    };
+
+    d4 acc[kT], accn[kT];
+#pragma unroll
+    for (int t = 0; t < kT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = Vc[(int64_t)(16 * t + kq + 4 * r) * ldv];
+
+    StageCursor ahead{0, 0, 4};
+    issue_stage(ahead, 0);
+    ahead.advance();
+    issue_stage(ahead, 1);
+    ahead.advance();
+    int buf = 0;                 // buffer of the current stage; stage g+2 goes to (buf + 2) % 3
+    int extra_prev = 0;          // VMEM operations the previous stage issued after its DMA (its V stores)
     double qacc = 0.0, macc = 0.0;
 
-    for (int i0 = 0; i0 < n; i0 += kRB) {
-        d4 acc[kT];
-#pragma unroll
-        for (int t = 0; t < kT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[t][r] = Vc[(int64_t)(i0 + 16 * t + kq + 4 * r) * ldv];
+    // top of a stage: this wave's DMA of the stage has landed once only the next stage's 12 DMA instructions
+    // (plus whatever the previous stage issued after them) are outstanding -- vmcnt retires in order; the
+    // barrier publishes every wave's share and frees buffer (buf+2)%3, read during the previous stage
+#define STAGE_TOP()                                                                                       \
+    do {                                                                                                  \
+        if (extra_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerStage + kStoresPerDiagStage) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerStage) : "memory");                          \
+        __builtin_amdgcn_s_barrier();                                                                     \
+    } while (0)
 
+    for (int i0 = 0; i0 < n; i0 += kRB) {
         const int nst = i0 / kKB;
-        if (nst > 0) {
-            // Every operand of the K-loop reaches LDS by LDS-DMA (no register staging), three stages deep.
-            const double *ug = U + (int64_t)(wave * 8) * ldu + i0 + lane * 2;
-            const double *vg = V + (int64_t)(lane >> 3) * ldv + colw + 2 * (lane & 7);
-            auto issue_stage = [&](int k1, int buf) __attribute__((always_inline)) {
-                double *la = lds + buf * kABuf + (wave * 8) * kLdsLd;
-                const double *g = ug + (int64_t)k1 * ldu;
-#pragma unroll
-                for (int p = 0; p < 8; ++p) GLDS16(g + (int64_t)p * ldu, la + p * kLdsLd);   // one 1 KiB row each
-                double *lb = ldsB + buf * kBBuf + wave * (kKB * 16);
-                const double *gv = vg + (int64_t)k1 * ldv;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) GLDS16(gv + (int64_t)(8 * p) * ldv, lb + p * 128);   // 8 rows x 128 B each
-            };
-            auto compute_stage = [&](int buf) __attribute__((always_inline)) {
+        for (int j = 0; j < nst; ++j) {
+            STAGE_TOP();
+            const int bnext = (buf >= 1) ? buf - 1 : 2;       // (buf + 2) % 3
+            issue_stage(ahead, bnext);
+            ahead.advance();
+            extra_prev = 0;
+            {
                 const double *abase = lds + buf * kABuf + kq * kLdsLd + lc;
                 const double *bbase = ldsB + buf * kBBuf + wave * (kKB * 16) + kq * 16 + lc;
                 double af[2][kT], bf[2];
@@ -98,79 +136,82 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
                 bf[0] = bbase[0];
                 SCHED_DS(kT + 1);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (j < 7) {
+                for (int jj = 0; jj < 8; ++jj) {
+                    if (jj < 7) {
 #pragma unroll
-                        for (int t = 0; t < kT; ++t) af[(j + 1) & 1][t] = abase[4 * (j + 1) * kLdsLd + 16 * t];
-                        bf[(j + 1) & 1] = bbase[4 * (j + 1) * 16];
+                        for (int t = 0; t < kT; ++t) af[(jj + 1) & 1][t] = abase[4 * (jj + 1) * kLdsLd + 16 * t];
+                        bf[(jj + 1) & 1] = bbase[4 * (jj + 1) * 16];
                     }
-                    const double nb = -bf[j & 1];
+                    const double nb = -bf[jj & 1];
 #pragma unroll
-                    for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[j & 1][t], nb, acc[t]);
-                    // pin "LDS reads of step j+1, then the MFMAs of step j": the reads complete under the MFMAs
-                    if (j < 7) { SCHED_DS(kT + 1); }
+                    for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[jj & 1][t], nb, acc[t]);
+                    // pin "LDS reads of step jj+1, then the MFMAs of step jj" (the reads complete under the
+                    // MFMAs) and spread the stage's DMA instructions over the first k-steps
+                    if (jj < 7) { SCHED_DS(kT + 1); }
                     SCHED_MFMA(kT);
+                    if (jj < 4) { SCHED_VMEM(3); }
                 }
-            };
-            issue_stage(0, 0);
-            if (nst > 1) issue_stage(kKB, 1);
-            for (int s = 0; s < nst; ++s) {
-                // this wave's DMA of stage s has landed once at most stage s+1's instructions are outstanding
-                // (vmcnt retires in order); the barrier then publishes every wave's share of the stage and
-                // guarantees that buffer (s+2)%3, read during stage s-1, may be overwritten
-                if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerStage) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (s + 2 < nst) issue_stage((s + 2) * kKB, (s + 2) % kNBuf);
-                compute_stage(s % kNBuf);
             }
-            __syncthreads();                                  // all reads of the last stage done before LDS reuse
+            buf = (buf == 2) ? 0 : buf + 1;
         }
 
-        // ---- diagonal block: stage its 16x16 tiles (inverses of the diagonal ones) through LDS
-        {
-            const double *Ud = U + (int64_t)i0 * ldu + i0;
-            const double *iD = invDt + (int64_t)(i0 / 16) * 256;
-            for (int idx = tid; idx < kNTile * 128; idx += 256) {
-                const int p = idx >> 7, e = idx & 127;
-                const int k = e >> 3, i2 = (e & 7) * 2;
-                const double *src;
-                if (p < kT) {
-                    src = iD + p * 256 + k * 16 + i2;
-                } else {
-                    int s = 0, rem = p - kT;                  // invert tile_slot: find (s, t) with slot p
-                    while (rem >= kT - 1 - s) { rem -= kT - 1 - s; ++s; }
-                    const int t = s + 1 + rem;
-                    src = Ud + (int64_t)(16 * s + k) * ldu + 16 * t + i2;
-                }
-                *reinterpret_cast<d2 *>(&lds[p * 256 + k * 16 + i2]) = *reinterpret_cast<const d2 *>(src);
-            }
-            __syncthreads();
-            const double *tl = &lds[kq * 16 + lc];           // + slot*256 + (4 kk)*16
+        // ---- four diagonal stages: X_s = inv(L_ss) R_s, then R_t -= L_ts X_s for the tiles below
 #pragma unroll
-            for (int s = 0; s < kT; ++s) {
+        for (int m = 0; m < 4; ++m) {
+            STAGE_TOP();
+            if (m == 0 && i0 + kRB < n) {
+                // next block's right-hand sides (K* rows) -- issued before this stage's DMA so that the
+                // DMA waits further down never have to cover them early
+#pragma unroll
+                for (int t = 0; t < kT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accn[t][r] = Vc[(int64_t)(i0 + kRB + 16 * t + kq + 4 * r) * ldv];
+            }
+            // z rows of this stage, fetched ahead of the DMA issue so they are older than it in vmcnt order
+            double zr[2][4];
+            if (SWEEP) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) zr[h][r] = z[i0 + 32 * m + 16 * h + kq + 4 * r];
+                asm volatile("" ::: "memory");
+            }
+            const int bnext = (buf >= 1) ? buf - 1 : 2;
+            issue_stage(ahead, bnext);
+            ahead.advance();
+            const double *abase = lds + buf * kABuf + kq * kLdsLd + lc;
+            const double *ibase = ldsB + buf * kBBuf + wave * (kKB * 16) + kq * 16 + lc;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int s = 2 * m + h;
                 d4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) x = MFMA_F64(tl[tile_slot(s, s) * 256 + 64 * kk], acc[s][kk], x);
+                for (int kk = 0; kk < 4; ++kk) x = MFMA_F64(ibase[h * 256 + 64 * kk], acc[s][kk], x);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = i0 + 16 * s + kq + 4 * r;
                     Vc[(int64_t)row * ldv] = x[r];
                     if (SWEEP) {
                         qacc = fma(x[r], x[r], qacc);
-                        macc = fma(x[r], z[row], macc);
+                        macc = fma(x[r], zr[h][r], macc);
                     }
                 }
 #pragma unroll
                 for (int t = s + 1; t < kT; ++t) {
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
-                        acc[t] = MFMA_F64(tl[tile_slot(s, t) * 256 + 64 * kk], -x[kk], acc[t]);
+                        acc[t] = MFMA_F64(abase[(16 * h + 4 * kk) * kLdsLd + 16 * t], -x[kk], acc[t]);
                 }
             }
-            __syncthreads();                                  // the next block's DMA reuses the LDS
+            extra_prev = 1;
+            buf = (buf == 2) ? 0 : buf + 1;
         }
+#pragma unroll
+        for (int t = 0; t < kT; ++t) acc[t] = accn[t];
     }
+#undef STAGE_TOP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the clamped tail DMA before the LDS goes away
+    __builtin_amdgcn_s_barrier();
 
     if (SWEEP) {
         qacc += __shfl_xor(qacc, 16);
