@@ -29,9 +29,18 @@ namespace cbo {
 #define SCHED_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x010, (n), 0)
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
-typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
-// LDS-DMA: 64 lanes x 16 B land at (wave-uniform LDS base) + lane * 16; the global address is per lane.
-#define GLDS16(gptr, lptr) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gptr), (lds_ptr_t)(lptr), 16, 0, 0)
+// LDS-DMA: 64 lanes x 16 B land at (wave-uniform LDS byte address) + lane * 16; the global address is per
+// lane.  Issued through inline asm (M0 written in the same statement, cdna_hip_programming.md 5.7) so that
+// hipcc does not track it: with the builtin in the MFMA block every LDS-read wait degrades to lgkmcnt(0) and
+// the fragment prefetch stops overlapping the MFMAs.  Completion is counted by hand (STAGE_TOP).
+__device__ __forceinline__ void glds16(const double *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
 
 constexpr int kRB = 128;                  // rows per block
 constexpr int kT = kRB / 16;              // 16-row tiles per block
@@ -49,10 +58,9 @@ constexpr int kDmaPerStage = 8 + 4;       // LDS-DMA instructions a wave issues 
 // stage g computes, across block boundaries, so the pipeline never drains.
 struct StageCursor {
     int i0, j, lim;                       // block origin, stage index within the block, stages in the block
-    __device__ __forceinline__ void advance()
-    {
-        if (++j == lim) { i0 += kRB; j = 0; lim = i0 / kKB + 4; }
-    }
+    const double *a_src;                  // per-lane source of the U tile's first row handled by this wave
+    const double *b_src;                  // per-lane source of the wave's first B piece
+    int64_t b_stride;                     // doubles between consecutive B pieces
 };
 
 constexpr int kStoresPerDiagStage = 8;    // V stores a wave issues per diagonal stage (2 tiles x 4 rows)
@@ -66,45 +74,66 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
     __shared__ __align__(16) double lds[kNBuf * (kABuf + kBBuf)];      // 159,744 B of the CU's 160 KiB
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform: LDS bases stay scalar
     const int lc = lane & 15, kq = lane >> 4;
     const int64_t colw = (int64_t)blockIdx.x * kStrip + wave * 16;     // first column of this wave
     double *Vc = V + colw + lc;
     double *ldsB = lds + kNBuf * kABuf;
+    const unsigned lds_byte0 = (unsigned)(unsigned long)(lds_ptr_t)lds;      // LDS byte address of lds[0]
     const double *ug = U + (int64_t)(wave * 8) * ldu + lane * 2;
     const double *vg = V + (int64_t)(lane >> 3) * ldv + colw + 2 * (lane & 7);
 
-    // LDS-DMA of one stage into buffer `buf` (12 instructions per wave, branch-free; a cursor past the end is
-    // clamped to the last stage, whose buffer is free by then, so the in-flight counts stay uniform)
-    auto issue_stage = [&](const StageCursor &c, int buf) __attribute__((always_inline)) {
+    // Sources of the stage the cursor points at (scalar bookkeeping, done off the MFMA path).  A cursor past
+    // the end is clamped to the last stage, whose buffer is free by then, so in-flight counts stay uniform.
+    auto locate = [&](StageCursor &c) __attribute__((always_inline)) {
         const bool past = c.i0 >= n;
         const int ai0 = past ? n - kRB : c.i0;
         const int aj = past ? (n - kRB) / kKB + 3 : c.j;
         const int nreg = ai0 / kKB;
-        double *la = lds + buf * kABuf + (wave * 8) * kLdsLd;
-        const double *g = ug + (int64_t)(kKB * aj) * ldu + ai0;
+        c.a_src = ug + (int64_t)(kKB * aj) * ldu + ai0;
+        if (aj >= nreg) {               // diagonal stage: the two 16x16 diagonal inverses go to the B region
+            c.b_src = invDt + ((int64_t)(ai0 / 16) + 2 * (aj - nreg)) * 256 + lane * 2;
+            c.b_stride = 128;
+        } else {                        // regular stage: V rows [32 aj, 32 aj + 32) of this wave's 16 columns
+            c.b_src = vg + (int64_t)(kKB * aj) * ldv;
+            c.b_stride = 8 * ldv;
+        }
+    };
+    auto advance = [&](StageCursor &c) __attribute__((always_inline)) {
+        if (++c.j == c.lim) { c.i0 += kRB; c.j = 0; c.lim = c.i0 / kKB + 4; }
+        locate(c);
+    };
+    // the 12 LDS-DMA instructions of a stage, split so they can sit between MFMAs: pieces 0..3 -> 3 each
+    auto issue_part = [&](const StageCursor &c, int buf, int part) __attribute__((always_inline)) {
+        const unsigned la = __builtin_amdgcn_readfirstlane(lds_byte0 + 8u * (unsigned)(buf * kABuf + (wave * 8) * kLdsLd));
+        const unsigned lb = __builtin_amdgcn_readfirstlane(
+            lds_byte0 + 8u * (unsigned)(kNBuf * kABuf + buf * kBBuf + wave * (kKB * 16)));
 #pragma unroll
-        for (int p = 0; p < 8; ++p) GLDS16(g + (int64_t)p * ldu, la + p * kLdsLd);       // one 1 KiB row each
-        const bool diag = aj >= nreg;
-        const double *bsrc = diag ? invDt + ((int64_t)(ai0 / 16) + 2 * (aj - nreg)) * 256 + lane * 2
-                                  : vg + (int64_t)(kKB * aj) * ldv;
-        const int64_t bstride = diag ? 128 : 8 * ldv;
-        double *lb = ldsB + buf * kBBuf + wave * (kKB * 16);
+        for (int q = 0; q < 2; ++q) {
+            const int p = 2 * part + q;
+            glds16(c.a_src + (int64_t)p * ldu, la + 8u * (unsigned)(p * kLdsLd));   // one 1 KiB U row
+        }
+        glds16(c.b_src + part * c.b_stride, lb + 8u * (unsigned)(part * 128));      // one 1 KiB B piece
+    };
+    auto issue_stage = [&](const StageCursor &c, int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) GLDS16(bsrc + p * bstride, lb + p * 128);            // 1 KiB pieces
+        for (int part = 0; part < 4; ++part) issue_part(c, buf, part);
     };
 
+    // acc holds the NEGATED residual  L[blk, 0:k] V[0:k] - V[blk]  so the K-loop needs no operand negation
     d4 acc[kT], accn[kT];
 #pragma unroll
     for (int t = 0; t < kT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = Vc[(int64_t)(16 * t + kq + 4 * r) * ldv];
+        for (int r = 0; r < 4; ++r) acc[t][r] = -Vc[(int64_t)(16 * t + kq + 4 * r) * ldv];
 
-    StageCursor ahead{0, 0, 4};
+    StageCursor ahead{0, 0, 4, nullptr, nullptr, 0};
+    locate(ahead);
     issue_stage(ahead, 0);
-    ahead.advance();
+    advance(ahead);
     issue_stage(ahead, 1);
-    ahead.advance();
+    advance(ahead);
     int buf = 0;                 // buffer of the current stage; stage g+2 goes to (buf + 2) % 3
     int extra_prev = 0;          // VMEM operations the previous stage issued after its DMA (its V stores)
     double qacc = 0.0, macc = 0.0;
@@ -124,8 +153,6 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
         for (int j = 0; j < nst; ++j) {
             STAGE_TOP();
             const int bnext = (buf >= 1) ? buf - 1 : 2;       // (buf + 2) % 3
-            issue_stage(ahead, bnext);
-            ahead.advance();
             extra_prev = 0;
             {
                 const double *abase = lds + buf * kABuf + kq * kLdsLd + lc;
@@ -142,16 +169,17 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
                         for (int t = 0; t < kT; ++t) af[(jj + 1) & 1][t] = abase[4 * (jj + 1) * kLdsLd + 16 * t];
                         bf[(jj + 1) & 1] = bbase[4 * (jj + 1) * 16];
                     }
-                    const double nb = -bf[jj & 1];
+                    if (jj < 4) issue_part(ahead, bnext, jj);             // stage g+2's DMA rides under the MFMAs
 #pragma unroll
-                    for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[jj & 1][t], nb, acc[t]);
-                    // pin "LDS reads of step jj+1, then the MFMAs of step jj" (the reads complete under the
-                    // MFMAs) and spread the stage's DMA instructions over the first k-steps
+                    for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[jj & 1][t], bf[jj & 1], acc[t]);
+                    // pin "LDS reads of step jj+1, DMA, then the MFMAs of step jj": reads and DMA issue complete
+                    // under the MFMAs
                     if (jj < 7) { SCHED_DS(kT + 1); }
-                    SCHED_MFMA(kT);
                     if (jj < 4) { SCHED_VMEM(3); }
+                    SCHED_MFMA(kT);
                 }
             }
+            advance(ahead);
             buf = (buf == 2) ? 0 : buf + 1;
         }
 
@@ -165,7 +193,7 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
 #pragma unroll
                 for (int t = 0; t < kT; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) accn[t][r] = Vc[(int64_t)(i0 + kRB + 16 * t + kq + 4 * r) * ldv];
+                    for (int r = 0; r < 4; ++r) accn[t][r] = -Vc[(int64_t)(i0 + kRB + 16 * t + kq + 4 * r) * ldv];
             }
             // z rows of this stage, fetched ahead of the DMA issue so they are older than it in vmcnt order
             double zr[2][4];
@@ -178,7 +206,7 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
             }
             const int bnext = (buf >= 1) ? buf - 1 : 2;
             issue_stage(ahead, bnext);
-            ahead.advance();
+            advance(ahead);
             const double *abase = lds + buf * kABuf + kq * kLdsLd + lc;
             const double *ibase = ldsB + buf * kBBuf + wave * (kKB * 16) + kq * 16 + lc;
 #pragma unroll
@@ -186,7 +214,7 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
                 const int s = 2 * m + h;
                 d4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) x = MFMA_F64(ibase[h * 256 + 64 * kk], acc[s][kk], x);
+                for (int kk = 0; kk < 4; ++kk) x = MFMA_F64(ibase[h * 256 + 64 * kk], -acc[s][kk], x);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = i0 + 16 * s + kq + 4 * r;
@@ -200,7 +228,7 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
                 for (int t = s + 1; t < kT; ++t) {
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
-                        acc[t] = MFMA_F64(abase[(16 * h + 4 * kk) * kLdsLd + 16 * t], -x[kk], acc[t]);
+                        acc[t] = MFMA_F64(abase[(16 * h + 4 * kk) * kLdsLd + 16 * t], x[kk], acc[t]);
                 }
             }
             extra_prev = 1;
