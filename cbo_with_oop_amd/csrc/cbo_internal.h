@@ -13,6 +13,26 @@ namespace cbo {
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+// LDS-DMA (global_load_lds_dwordx4): 64 lanes x 16 B land at (wave-uniform LDS byte address) + lane * 16;
+// the global address is per lane.  Issued through inline asm with M0 written in the same statement
+// (cdna_hip_programming.md 5.7) so that hipcc does not track it: with the builtin next to ds_reads every
+// LDS-read wait degrades to lgkmcnt(0).  The caller counts completion by hand (s_waitcnt vmcnt + barrier).
+__device__ __forceinline__ void glds16(const double *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_byte_address(const void *p)
+{
+    return (unsigned)(unsigned long)(lds_ptr_t)p;
+}
+#endif
+
 // ---- data layout in HBM ------------------------------------------------------
 // * Points: SoA, coordinate k of point i at xs[k * ld + i]; squared norms sq[i]; sqrt(v(x_i)) sv[i].
 // * Ky and its Cholesky factor share one row-major buffer A[n_pad][lda].  Only the UPPER triangle is

@@ -39,39 +39,50 @@ struct DiagShared {
     double invd[128];          // reciprocals of the factor's diagonal
 };
 
-// Register Cholesky of the 16x16 tile at (o, o): lane c (mod 16) owns column c.  Executed by one wave.
+// Register Cholesky of the 16x16 tile at (o, o), executed by one wave with the tile in the fp64-MFMA
+// accumulator layout: lane (kq = lane>>4, lc = lane&15) holds d[r] = D[kq + 4r][lc].  Rows 4b..4b+3 are
+// then register d[b] of the four lane groups, so after the four pivots of sub-block b that register IS
+// both MFMA operands of the rank-4 update  D -= U_b^T U_b  (A[i][k] = U[4b+k][i], B[k][j] = U[4b+k][j]).
+// Per pivot: one broadcast of the pivot (readlane), one reciprocal square root, two lane permutes.
 __device__ __forceinline__ void diag_tile_factor(DiagShared &sh, int o, int lane, int pivot_base, int *info)
 {
-    const int c = lane & 15;
-    double a[16];
+    const int lc = lane & 15, kq = lane >> 4;
+    d4 d;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = (r <= c) ? sh.S[o + r][o + c] : 0.0;
+    for (int r = 0; r < 4; ++r) d[r] = (kq + 4 * r <= lc) ? sh.S[o + kq + 4 * r][o + lc] : 0.0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        double pj = readlane_f64(a[j], j);
-        if (!(pj > 0.0)) {                        // LAPACK: ajj <= 0 or NaN -> info = j
-            if (lane == 0) atomicCAS(info, 0, pivot_base + o + j + 1);
-            pj = 1.0;                             // keep the arithmetic finite; the result is discarded
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piv = 4 * b + j;                          // row (kq == j, register b), column lc == piv
+            double pj = readlane_f64(d[b], 16 * j + piv);
+            if (!(pj > 0.0)) {                                  // LAPACK: ajj <= 0 or NaN -> info = j
+                if (lane == 0) atomicCAS(info, 0, pivot_base + o + piv + 1);
+                pj = 1.0;                                       // keep the arithmetic finite; result is discarded
+            }
+            // d = sqrt(p) and 1/d from one reciprocal square root (1-2 ulp; the row is scaled by the same 1/d)
+            const double inv = rsqrt(pj);
+            const double dj = pj * inv;
+            if (lane == 0) sh.invd[o + piv] = inv;
+            const double scaled = (lc > piv) ? d[b] * inv : ((lc == piv) ? dj : 0.0);
+            if (kq == j) d[b] = scaled;                          // row piv is final (zeros left of the diagonal)
+            if (j < 3) {
+                const double ujc = __shfl(d[b], 16 * j + lc);            // U[piv][lc]
+                const double ujr = __shfl(d[b], 16 * j + 4 * b + kq);    // U[piv][row of this lane]
+                if (kq > j) d[b] = fma(-ujr, ujc, d[b]);                 // rows piv+1 .. 4b+3
+            }
         }
-        // d = sqrt(p) and 1/d from one reciprocal square root (1-2 ulp; the row is scaled by the same 1/d)
-        const double inv = rsqrt(pj);
-        const double dj = pj * inv;
-        a[j] = (c == j) ? dj : a[j] * inv;
-        if (lane == 0) sh.invd[o + j] = inv;
+        if (b < 3) {
+            const d4 keep = d;
+            d = MFMA_F64(d[b], -d[b], d);                        // rows below the sub-block: D -= U_b^T U_b
 #pragma unroll
-        for (int r = j + 1; r < 16; ++r) {
-            const double ujr = readlane_f64(a[j], r);
-            a[r] = fma(-ujr, a[j], a[r]);
+            for (int r = 0; r <= b; ++r) d[r] = keep[r];         // finished rows stay as they are
         }
-        __builtin_amdgcn_sched_barrier(0);        // keep the broadcast scalars of one pivot step live at a time
     }
-    if (lane < 16) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const double v = (r <= c) ? a[r] : 0.0;
-            sh.Ud[r][c] = v;
-            sh.S[o + r][o + c] = v;
-        }
+    for (int r = 0; r < 4; ++r) {
+        sh.Ud[kq + 4 * r][lc] = d[r];
+        sh.S[o + kq + 4 * r][o + lc] = d[r];
     }
 }
 
@@ -100,16 +111,18 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t l
     const int lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, kq = lane >> 4;
 
-    // load the upper triangle of the block (row-major, 16-byte loads) and the rhs rows
-    for (int idx = tid; idx < 128 * 64; idx += 256) {
-        const int i = idx >> 6, j2 = (idx & 63) * 2;
-        if (j2 + 1 >= i) {
-            const d2 v = *reinterpret_cast<const d2 *>(&A[(int64_t)(r0 + i) * lda + r0 + j2]);
-            sh.S[i][j2] = v[0];
-            sh.S[i][j2 + 1] = v[1];
-        }
+    // load the block by LDS-DMA: one 1 KiB row per instruction, 32 rows per wave, all in flight at once
+    // (the part below the diagonal comes along and is never read)
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const unsigned s0 = lds_byte_address(&sh.S[0][0]);
+        const double *g = A + (int64_t)(r0 + wv * 32) * lda + r0 + lane * 2;
+#pragma unroll 8
+        for (int p = 0; p < 32; ++p)
+            glds16(g + (int64_t)p * lda, __builtin_amdgcn_readfirstlane(s0 + 8u * (unsigned)((wv * 32 + p) * kDiagLd)));
     }
     if (tid < 128) sh.rz[tid] = A[(int64_t)(r0 + tid) * lda + rcol];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (wave == 0) diag_tile_factor(sh, 0, lane, r0, info);
     __syncthreads();
@@ -242,20 +255,33 @@ __global__ __launch_bounds__(256) void syrk_kernel(double *A, int64_t lda, int r
         for (int nn = 0; nn < MT; ++nn) acc[m][nn] = d4{0.0, 0.0, 0.0, 0.0};
     const double *Pa = P + (int64_t)kq * lda + ib + lc;
     const double *Pb = P + (int64_t)kq * lda + jb + lc;
-    // software pipeline: fragments of k-step k0+4 are in flight while the MFMAs of k0 issue
-    double a[MT], b[MT], an[MT], bn[MT];
+    // software pipeline over chunks of CH k-steps: the fragments of chunk c+1 are in flight (L2 latency)
+    // while the MFMAs of chunk c issue; n1 is a multiple of 4*CH at every call site (128-row panels)
+    constexpr int CH = 4;
+    double a[2][CH][MT], b[2][CH][MT];
+    auto load_chunk = [&](int k0, double (&aa)[CH][MT], double (&bb)[CH][MT]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) { a[m] = Pa[16 * m]; b[m] = Pb[16 * m]; }
-    for (int k0 = 0; k0 < n1; k0 += 4) {
-        const int kn = (k0 + 4 < n1) ? k0 + 4 : k0;
+        for (int ks = 0; ks < CH; ++ks)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { an[m] = Pa[(int64_t)kn * lda + 16 * m]; bn[m] = Pb[(int64_t)kn * lda + 16 * m]; }
+            for (int m = 0; m < MT; ++m) {
+                aa[ks][m] = Pa[(int64_t)(k0 + 4 * ks) * lda + 16 * m];
+                bb[ks][m] = Pb[(int64_t)(k0 + 4 * ks) * lda + 16 * m];
+            }
+    };
+    auto mfma_chunk = [&](const double (&aa)[CH][MT], const double (&bb)[CH][MT]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int ks = 0; ks < CH; ++ks)
 #pragma unroll
-            for (int nn = 0; nn < MT; ++nn) acc[m][nn] = MFMA_F64(a[m], b[nn], acc[m][nn]);
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { a[m] = an[m]; b[m] = bn[m]; }
+                for (int nn = 0; nn < MT; ++nn) acc[m][nn] = MFMA_F64(aa[ks][m], bb[ks][nn], acc[m][nn]);
+    };
+    load_chunk(0, a[0], b[0]);
+    for (int k0 = 0; k0 < n1; k0 += 8 * CH) {
+        if (k0 + 4 * CH < n1) load_chunk(k0 + 4 * CH, a[1], b[1]);
+        mfma_chunk(a[0], b[0]);
+        if (k0 + 8 * CH < n1) load_chunk(k0 + 8 * CH, a[0], b[0]);
+        if (k0 + 4 * CH < n1) mfma_chunk(a[1], b[1]);
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)

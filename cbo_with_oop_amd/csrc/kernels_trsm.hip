@@ -28,20 +28,6 @@ namespace cbo {
 #define SCHED_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, (n), 0)
 #define SCHED_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x010, (n), 0)
 
-typedef __attribute__((address_space(3))) void *lds_ptr_t;
-// LDS-DMA: 64 lanes x 16 B land at (wave-uniform LDS byte address) + lane * 16; the global address is per
-// lane.  Issued through inline asm (M0 written in the same statement, cdna_hip_programming.md 5.7) so that
-// hipcc does not track it: with the builtin in the MFMA block every LDS-read wait degrades to lgkmcnt(0) and
-// the fragment prefetch stops overlapping the MFMAs.  Completion is counted by hand (STAGE_TOP).
-__device__ __forceinline__ void glds16(const double *gsrc, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
-
 constexpr int kRB = 128;                  // rows per block
 constexpr int kT = kRB / 16;              // 16-row tiles per block
 constexpr int kKB = 32;                   // rows of U / V per pipeline stage (8 MFMA k-steps)
@@ -80,7 +66,7 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
     const int64_t colw = (int64_t)blockIdx.x * kStrip + wave * 16;     // first column of this wave
     double *Vc = V + colw + lc;
     double *ldsB = lds + kNBuf * kABuf;
-    const unsigned lds_byte0 = (unsigned)(unsigned long)(lds_ptr_t)lds;      // LDS byte address of lds[0]
+    const unsigned lds_byte0 = lds_byte_address(lds);      // LDS byte address of lds[0]
     const double *ug = U + (int64_t)(wave * 8) * ldu + lane * 2;
     const double *vg = V + (int64_t)(lane >> 3) * ldv + colw + 2 * (lane & 7);
 
