@@ -69,12 +69,25 @@ def cpu_baseline(X, y, Xs, y_best, cost, sample):
                       f"of the GPy/emukit path, not GPy itself"}
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/trsm_pmc.json, written by scripts/pmc_to_json.py from separate FETCH_SIZE / WRITE_SIZE runs of
+    this same command).  gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md HBM)."""
+    path = os.path.join(ROOT, "profiles", "trsm_pmc.json")
+    try:
+        d = json.load(open(path))
+        return d["fetch_size_kb"] * 1024 * 2 + d["write_size_kb"] * 1024
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-sample", type=int, default=4096, help="candidates in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -84,17 +97,20 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from cbo_with_oop_amd import CandidateGrid, CausalExpectedImprovement, _lib
     from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
     from cbo_with_oop_amd.sharding import exchange_argmax, shard_bounds
     import ctypes
 
-    ctx = _lib.Context.get(local_rank)
+    ctx = _lib.Context.get(local_rank % max(1, _lib.device_count()))
     lib = _lib.load()
     X, y, Xs, grid = make_problem(world)
     y_best, cost = float(y.min()), 3.0                     # incumbent = best observation; type_cost 1 -> |set| = 3
@@ -130,7 +146,7 @@ def main():
     timers = ctx.timers()
     ctx.set_profiling(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -160,7 +176,7 @@ def main():
                                                               / args.steps * 1e-3) * world,
             "roofline": {"kernel": "trsm_strip_kernel<128> (V = L^-1 K*, fused sum V^2 and V^T z)",
                          "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic_bytes(),
                          "avg_launch_ms": trsm_ms,
                          "algorithmic_flops_per_launch": timers["trsm_flops"] / launches},
         }
