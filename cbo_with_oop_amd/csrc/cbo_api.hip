@@ -36,6 +36,8 @@ struct EventPair {
 struct cbo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;        // look-ahead stream of the Cholesky
+    std::vector<hipEvent_t> chol_events;
     bool profiling = false;
     std::vector<EventPair> pending;
     std::vector<hipEvent_t> pool;
@@ -175,6 +177,7 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
     c->device = device_id;
     std::snprintf(c->name, sizeof(c->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&c->part_val, 2048 * sizeof(double)));
     HIP_TRY(hipMalloc(&c->part_idx, 2048 * sizeof(int64_t)));
     HIP_TRY(hipMalloc(&c->best_val, sizeof(double)));
@@ -198,6 +201,8 @@ extern "C" void cbo_shutdown(cbo_ctx *c)
     hipFree(c->V); hipFree(c->q); hipFree(c->mu); hipFree(c->mean); hipFree(c->var); hipFree(c->acq);
     hipFree(c->part_val); hipFree(c->part_idx); hipFree(c->best_val); hipFree(c->best_idx);
     hipHostFree(c->h_best_val); hipHostFree(c->h_best_idx); hipHostFree(c->h_info);
+    for (auto e : c->chol_events) hipEventDestroy(e);
+    hipStreamDestroy(c->side_stream);
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -357,7 +362,7 @@ static void enqueue_factor(cbo_gp *g, double jitter)
     }
     {
         PhaseScope ps(c, PH_CHOL);
-        launch_cholesky(c->stream, g->A, g->lda, g->n_pad, g->invDt, g->info);
+        launch_cholesky(c->stream, c->side_stream, c->chol_events, g->A, g->lda, g->n_pad, g->invDt, g->info);
     }
 }
 

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 #include "cbo_hip.h"
 
@@ -83,7 +84,8 @@ void launch_kstar(hipStream_t s, const PointSet &X, const PointSet &C, int64_t c
                   const KernelHyper &h, double *V, int64_t ldv, int64_t n_pad);
 
 // Recursive blocked Cholesky (upper) of A[0:n_pad, 0:n_pad] incl. forward solve of the rhs strip.
-void launch_cholesky(hipStream_t s, double *A, int64_t lda, int64_t n_pad, double *invDt, int *info_dev);
+void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &events, double *A, int64_t lda,
+                     int64_t n_pad, double *invDt, int *info_dev);
 // alpha = U^-1 z  (z = first rhs column of A).
 void launch_backsolve(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt, double *alpha);
 

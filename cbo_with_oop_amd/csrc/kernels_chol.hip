@@ -16,11 +16,28 @@
 //   3. syrk_kernel            A[r0+128:, r0+128:] -= P^T P  on the upper 128x128 tiles (fp64 MFMA),
 //                             rhs[r0+128:] -= P^T z_k
 // The SYRK carries the n^3/3 flops; steps 1-2 are the serial chain.
+#include <vector>
+
 #include "cbo_internal.h"
 
 namespace cbo {
 
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// Timing-only build (make DIAG=1 -> libcbo_hip_diag.so): CBO_DBG_CHOL is a bit mask of phases to skip so
+// that rocprofv3 --stats prices each one; results are wrong by construction.  Not compiled into the product.
+#ifdef CBO_DIAG_KNOBS
+#include <cstdlib>
+static int chol_dbg_mask()
+{
+    static int m = -1;
+    if (m < 0) { const char *e = std::getenv("CBO_DBG_CHOL"); m = e ? std::atoi(e) : 0; }
+    return m;
+}
+#define DBG_SKIP(bit) (dbg & (bit))
+#else
+#define DBG_SKIP(bit) false
+#endif
 
 __device__ __forceinline__ double readlane_f64(double v, int lane)
 {
@@ -103,7 +120,7 @@ __device__ __forceinline__ void diag_tile_update(DiagShared &sh, int o, int r0, 
 }
 
 __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t lda, int r0, int rcol,
-                                                            double *__restrict__ invDt, int *info)
+                                                            double *__restrict__ invDt, int *info, int dbg)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     DiagShared &sh = *reinterpret_cast<DiagShared *>(smem_raw);
@@ -124,24 +141,26 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t l
     if (tid < 128) sh.rz[tid] = A[(int64_t)(r0 + tid) * lda + rcol];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (wave == 0) diag_tile_factor(sh, 0, lane, r0, info);
+    if (wave == 0 && !DBG_SKIP(1)) diag_tile_factor(sh, 0, lane, r0, info);
     __syncthreads();
 
     for (int jb = 0; jb < 8; ++jb) {
+        if (DBG_SKIP(32)) break;
         const int o = 16 * jb;
         const int ncols = 128 - o - 16;            // columns to the right of the tile
         // ---- B: row panel  X = U_d^-T S[o:o+16, o+16:]  and the rhs rows, one column per thread
-        if (tid <= ncols) {
+        if (tid <= ncols && !DBG_SKIP(2)) {
             const bool is_rhs = (tid == ncols);
             double x[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) x[i] = is_rhs ? sh.rz[o + i] : sh.S[o + i][o + 16 + tid];
+            // right-looking order: once x[k] is final the 15-k updates below it are independent (short
+            // dependency chain: 16 x (mul + fma) instead of 136 chained fmas)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                double s = x[i];
+            for (int k = 0; k < 16; ++k) {
+                x[k] *= sh.invd[o + k];
 #pragma unroll
-                for (int k = 0; k < i; ++k) s = fma(-sh.Ud[k][i], x[k], s);
-                x[i] = s * sh.invd[o + i];
+                for (int i = k + 1; i < 16; ++i) x[i] = fma(-sh.Ud[k][i], x[k], x[i]);
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -163,8 +182,8 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t l
                 sh.rz[o + 16 + lane] = s;
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);    // lgkmcnt(0): the LDS stores above are visible to this wave's reads
-            diag_tile_factor(sh, o + 16, lane, r0, info);
-        } else {
+            if (!DBG_SKIP(1)) diag_tile_factor(sh, o + 16, lane, r0, info);
+        } else if (!DBG_SKIP(4)) {
             int idx = 0;
             for (int ti = jb + 1; ti < 8; ++ti)
                 for (int tj = ti; tj < 8; ++tj) {
@@ -186,25 +205,26 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t l
     }
 
     // ---- outputs: factor (upper, zero below), z, and inv(U_bb) for the eight 16x16 diagonal tiles
-    for (int idx = tid; idx < 128 * 64; idx += 256) {
+    for (int idx = tid; idx < 128 * 64 && !DBG_SKIP(16); idx += 256) {
         const int i = idx >> 6, j2 = (idx & 63) * 2;
         d2 v;
         v[0] = (j2 >= i) ? sh.S[i][j2] : 0.0;
         v[1] = (j2 + 1 >= i) ? sh.S[i][j2 + 1] : 0.0;
         *reinterpret_cast<d2 *>(&A[(int64_t)(r0 + i) * lda + r0 + j2]) = v;
     }
-    if (tid < 128) {
+    if (tid < 128 && !DBG_SKIP(8)) {
         A[(int64_t)(r0 + tid) * lda + rcol] = sh.rz[tid];
         // column j of Y = inv(U_bb) by back substitution (U_bb Y = I to working accuracy; the strip
         // TRSM applies Y^T from the left)
         const int b = tid >> 4, j = tid & 15, o = 16 * b;
         double y[16];
 #pragma unroll
-        for (int i = 15; i >= 0; --i) {
-            double s = (i == j) ? 1.0 : 0.0;
+        for (int i = 0; i < 16; ++i) y[i] = (i == j) ? 1.0 : 0.0;
 #pragma unroll
-            for (int k = i + 1; k < 16; ++k) s = fma(-sh.S[o + i][o + k], (k <= j) ? y[k] : 0.0, s);
-            y[i] = (i <= j) ? s * sh.invd[o + i] : 0.0;
+        for (int k = 15; k >= 0; --k) {             // right-looking back substitution (rows below j stay 0)
+            y[k] *= sh.invd[o + k];
+#pragma unroll
+            for (int i = 0; i < k; ++i) y[i] = fma(-sh.S[o + i][o + k], y[k], y[i]);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) invDt[(int64_t)(r0 / 16 + b) * 256 + i * 16 + j] = y[i];
@@ -217,9 +237,10 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t l
 // both operand fragments read straight from the panel rows (4 row segments of 128 B per load).
 // Extra blocks (blockIdx.x == nt) update the rhs column: r[i] -= sum_k P[k][i] z[k].
 template <int TS>
-__global__ __launch_bounds__(256) void syrk_kernel(double *A, int64_t lda, int r0, int n1, int c0, int nt, int rcol)
+__global__ __launch_bounds__(256) void syrk_kernel(double *A, int64_t lda, int r0, int n1, int c0, int nt, int rcol,
+                                                   int ti_begin, int dbg)
 {
-    const int tj = blockIdx.x, ti = blockIdx.y;
+    const int tj = blockIdx.x, ti = blockIdx.y + ti_begin;
     const int tid = threadIdx.x;
     const double *P = A + (int64_t)r0 * lda;
     if (tj == nt) {
@@ -228,8 +249,20 @@ __global__ __launch_bounds__(256) void syrk_kernel(double *A, int64_t lda, int r
         __shared__ double part[256];
         const int i = tid % TS, g = tid / TS;
         const int64_t gi = c0 + (int64_t)ti * TS + i;
+        // all loads of a 16-step batch are issued before the first use (L2 latency paid once per batch)
         double s = 0.0;
-        for (int k = g; k < n1; k += G) s = fma(P[(int64_t)k * lda + gi], P[(int64_t)k * lda + rcol], s);
+        for (int k0 = g; k0 < n1; k0 += 16 * G) {
+            double pv[16], zv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = k0 + u * G;
+                const bool ok = k < n1;
+                pv[u] = ok ? P[(int64_t)k * lda + gi] : 0.0;
+                zv[u] = ok ? P[(int64_t)k * lda + rcol] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s = fma(pv[u], zv[u], s);
+        }
         part[tid] = s;
         __syncthreads();
         if (g == 0) {
@@ -242,33 +275,35 @@ __global__ __launch_bounds__(256) void syrk_kernel(double *A, int64_t lda, int r
     }
     if (tj < ti) return;
     constexpr int WT = TS / 2, MT = WT / 16;
+    static_assert(MT == 2, "the 16-byte interleaved fragment map below is written for 32x32 wave tiles");
     const int lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, kq = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;
     if (ti == tj && wr == 1 && wc == 0) return;      // strictly-lower quadrant of a diagonal tile
     const int64_t ib = c0 + (int64_t)ti * TS + wr * WT;
     const int64_t jb = c0 + (int64_t)tj * TS + wc * WT;
+    // Interleaved tile map: MFMA tile (m, nn) of the wave's 32x32 block covers rows ib + 2i + m and columns
+    // jb + 2j + nn, so one 16-byte load per lane yields the fragments of both m (resp. nn) and every access
+    // to C is 16 bytes per lane as well.
     d4 acc[MT][MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int nn = 0; nn < MT; ++nn) acc[m][nn] = d4{0.0, 0.0, 0.0, 0.0};
-    const double *Pa = P + (int64_t)kq * lda + ib + lc;
-    const double *Pb = P + (int64_t)kq * lda + jb + lc;
+    const double *Pa = P + (int64_t)kq * lda + ib + 2 * lc;
+    const double *Pb = P + (int64_t)kq * lda + jb + 2 * lc;
     // software pipeline over chunks of CH k-steps: the fragments of chunk c+1 are in flight (L2 latency)
     // while the MFMAs of chunk c issue; n1 is a multiple of 4*CH at every call site (128-row panels)
     constexpr int CH = 4;
-    double a[2][CH][MT], b[2][CH][MT];
-    auto load_chunk = [&](int k0, double (&aa)[CH][MT], double (&bb)[CH][MT]) __attribute__((always_inline)) {
+    d2 a[2][CH], b[2][CH];
+    auto load_chunk = [&](int k0, d2 (&aa)[CH], d2 (&bb)[CH]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ks = 0; ks < CH; ++ks)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                aa[ks][m] = Pa[(int64_t)(k0 + 4 * ks) * lda + 16 * m];
-                bb[ks][m] = Pb[(int64_t)(k0 + 4 * ks) * lda + 16 * m];
-            }
+        for (int ks = 0; ks < CH; ++ks) {
+            aa[ks] = *reinterpret_cast<const d2 *>(&Pa[(int64_t)(k0 + 4 * ks) * lda]);
+            bb[ks] = *reinterpret_cast<const d2 *>(&Pb[(int64_t)(k0 + 4 * ks) * lda]);
+        }
     };
-    auto mfma_chunk = [&](const double (&aa)[CH][MT], const double (&bb)[CH][MT]) __attribute__((always_inline)) {
+    auto mfma_chunk = [&](const d2 (&aa)[CH], const d2 (&bb)[CH]) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < CH; ++ks)
 #pragma unroll
@@ -277,31 +312,57 @@ __global__ __launch_bounds__(256) void syrk_kernel(double *A, int64_t lda, int r
                 for (int nn = 0; nn < MT; ++nn) acc[m][nn] = MFMA_F64(aa[ks][m], bb[ks][nn], acc[m][nn]);
     };
     load_chunk(0, a[0], b[0]);
-    for (int k0 = 0; k0 < n1; k0 += 8 * CH) {
+    // the C tile is fetched up front so that its (MALL/HBM) latency hides under the MFMAs
+    d2 cv[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            cv[m][r] = *reinterpret_cast<const d2 *>(&A[(ib + 2 * (kq + 4 * r) + m) * lda + jb + 2 * lc]);
+    for (int k0 = 0; k0 < n1 && !DBG_SKIP(64); k0 += 8 * CH) {
         if (k0 + 4 * CH < n1) load_chunk(k0 + 4 * CH, a[1], b[1]);
         mfma_chunk(a[0], b[0]);
         if (k0 + 8 * CH < n1) load_chunk(k0 + 8 * CH, a[0], b[0]);
         if (k0 + 4 * CH < n1) mfma_chunk(a[1], b[1]);
     }
+    if (DBG_SKIP(128)) {
+        if (acc[0][0][0] == 12345.678) A[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];   // keep acc live
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int nn = 0; nn < MT; ++nn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double *c = &A[(ib + 16 * m + kq + 4 * r) * lda + jb + 16 * nn + lc];
-                *c -= acc[m][nn][r];
-            }
+        for (int r = 0; r < 4; ++r) {
+            d2 o = cv[m][r];
+            o[0] -= acc[m][0][r];
+            o[1] -= acc[m][1][r];
+            *reinterpret_cast<d2 *>(&A[(ib + 2 * (kq + 4 * r) + m) * lda + jb + 2 * lc]) = o;
+        }
 }
 
-static void launch_syrk(hipStream_t s, double *A, int64_t lda, int r0, int n1, int n2, int rcol)
+// tile rows [ti_begin, ti_end) of the trailing update (64-row tiles counted from the first trailing row)
+static void launch_syrk(hipStream_t s, double *A, int64_t lda, int r0, int n1, int n2, int rcol, int ti_begin,
+                        int ti_end)
 {
     const int c0 = r0 + n1;
     const int nt = n2 / 64;
-    hipLaunchKernelGGL(syrk_kernel<64>, dim3(nt + 1, nt), dim3(256), 0, s, A, lda, r0, n1, c0, nt, rcol);
+    if (ti_end > nt) ti_end = nt;
+    if (ti_end <= ti_begin) return;
+#ifdef CBO_DIAG_KNOBS
+    const int dbg = chol_dbg_mask();
+    if (dbg & 256) return;
+#else
+    const int dbg = 0;
+#endif
+    hipLaunchKernelGGL(syrk_kernel<64>, dim3(nt + 1, ti_end - ti_begin), dim3(256), 0, s, A, lda, r0, n1, c0, nt, rcol,
+                       ti_begin, dbg);
 }
 
-void launch_cholesky(hipStream_t s, double *A, int64_t lda, int64_t n_pad, double *invDt, int *info_dev)
+// Look-ahead: the bulk of panel k-1's trailing update (tile rows below the next panel) runs on the side
+// stream while the main stream factors the diagonal block of panel k and solves its row panel; the two
+// meet again before the next panel's own rows are updated.
+void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &events, double *A, int64_t lda,
+                     int64_t n_pad, double *invDt, int *info_dev)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -311,15 +372,46 @@ void launch_cholesky(hipStream_t s, double *A, int64_t lda, int64_t n_pad, doubl
     }
     hipMemsetAsync(info_dev, 0, sizeof(int), s);
     const int rcol = (int)n_pad;
-    for (int r0 = 0; r0 < (int)n_pad; r0 += 128) {
+#ifdef CBO_DIAG_KNOBS
+    const int dbg = chol_dbg_mask();
+#else
+    const int dbg = 0;
+#endif
+    const int np = (int)(n_pad / 128);
+    while ((int)events.size() < 2 * np + 2) {
+        hipEvent_t e;
+        hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        events.push_back(e);
+    }
+    // the side stream starts after everything queued on the main stream so far (K assembly, rhs)
+    hipEventRecord(events[2 * np], s);
+    hipStreamWaitEvent(side, events[2 * np], 0);
+    bool rest_pending = false;
+    for (int k = 0; k < np; ++k) {
+        const int r0 = 128 * k;
         hipLaunchKernelGGL(potrf_diag128_kernel, dim3(1), dim3(256), sizeof(DiagShared), s, A, lda, r0, rcol, invDt,
-                           info_dev);
+                           info_dev, dbg);
         const int n2 = (int)n_pad - r0 - 128;
         if (n2 <= 0) break;
         launch_trsm_strips(s, A + (int64_t)r0 * lda + r0, lda, invDt + (int64_t)(r0 / 16) * 256,
                            A + (int64_t)r0 * lda + r0 + 128, lda, 128, n2, nullptr, nullptr, nullptr);
-        launch_syrk(s, A, lda, r0, 128, n2, rcol);
+        // rows of the next panel: wait for the previous bulk update (it touches them too), then update
+        if (rest_pending) hipStreamWaitEvent(s, events[2 * (k - 1) + 1], 0);
+        launch_syrk(s, A, lda, r0, 128, n2, rcol, 0, 2);
+        if (n2 > 128) {
+            hipEventRecord(events[2 * k], s);                 // panel k solved and next-panel rows updated
+            hipStreamWaitEvent(side, events[2 * k], 0);
+            launch_syrk(side, A, lda, r0, 128, n2, rcol, 2, n2 / 64);
+            hipEventRecord(events[2 * k + 1], side);
+            rest_pending = true;
+        } else {
+            rest_pending = false;
+        }
     }
+    // nothing is left on the side stream that the main stream has not waited for (the last bulk update is
+    // awaited before the following panel's syrk); make that explicit for robustness
+    hipEventRecord(events[2 * np + 1], side);
+    hipStreamWaitEvent(s, events[2 * np + 1], 0);
 }
 
 // ------------------------------------------------------------------------------------------------
