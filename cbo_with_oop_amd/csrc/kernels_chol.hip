@@ -52,8 +52,7 @@ constexpr int kDiagLd = 144;   // LDS row stride (doubles): rows kq and kq+1 of 
 struct DiagShared {
     double S[128][kDiagLd];    // the block; upper triangle is meaningful
     double rz[128];            // rhs column
-    double Ud[16][16];         // current 16x16 diagonal factor (upper)
-    double invd[128];          // reciprocals of the factor's diagonal
+    double Yt[16][16];         // inverse of the current 16x16 diagonal factor: Yt[k][i] = inv(L_d)[i][k]
 };
 
 // Register Cholesky of the 16x16 tile at (o, o), executed by one wave with the tile in the fp64-MFMA
@@ -61,12 +60,17 @@ struct DiagShared {
 // then register d[b] of the four lane groups, so after the four pivots of sub-block b that register IS
 // both MFMA operands of the rank-4 update  D -= U_b^T U_b  (A[i][k] = U[4b+k][i], B[k][j] = U[4b+k][j]).
 // Per pivot: one broadcast of the pivot (readlane), one reciprocal square root, two lane permutes.
-__device__ __forceinline__ void diag_tile_factor(DiagShared &sh, int o, int lane, int pivot_base, int *info)
+__device__ __forceinline__ void diag_tile_factor(DiagShared &sh, int o, int lane, int pivot_base, int *info,
+                                                 double *__restrict__ invDt_tile)
 {
     const int lc = lane & 15, kq = lane >> 4;
-    d4 d;
+    // d: the tile; e: the identity carried through the same row operations, ending as inv(L_d) = inv(U_d)^T
+    d4 d, e;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) d[r] = (kq + 4 * r <= lc) ? sh.S[o + kq + 4 * r][o + lc] : 0.0;
+    for (int r = 0; r < 4; ++r) {
+        d[r] = (kq + 4 * r <= lc) ? sh.S[o + kq + 4 * r][o + lc] : 0.0;
+        e[r] = (kq + 4 * r == lc) ? 1.0 : 0.0;
+    }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
 #pragma unroll
@@ -80,26 +84,35 @@ __device__ __forceinline__ void diag_tile_factor(DiagShared &sh, int o, int lane
             // d = sqrt(p) and 1/d from one reciprocal square root (1-2 ulp; the row is scaled by the same 1/d)
             const double inv = rsqrt(pj);
             const double dj = pj * inv;
-            if (lane == 0) sh.invd[o + piv] = inv;
             const double scaled = (lc > piv) ? d[b] * inv : ((lc == piv) ? dj : 0.0);
-            if (kq == j) d[b] = scaled;                          // row piv is final (zeros left of the diagonal)
+            if (kq == j) {                                       // row piv is final (zeros left of the diagonal)
+                d[b] = scaled;
+                e[b] *= inv;
+            }
             if (j < 3) {
                 const double ujc = __shfl(d[b], 16 * j + lc);            // U[piv][lc]
+                const double ejc = __shfl(e[b], 16 * j + lc);            // E[piv][lc]
                 const double ujr = __shfl(d[b], 16 * j + 4 * b + kq);    // U[piv][row of this lane]
-                if (kq > j) d[b] = fma(-ujr, ujc, d[b]);                 // rows piv+1 .. 4b+3
+                if (kq > j) {                                            // rows piv+1 .. 4b+3
+                    d[b] = fma(-ujr, ujc, d[b]);
+                    e[b] = fma(-ujr, ejc, e[b]);
+                }
             }
         }
         if (b < 3) {
-            const d4 keep = d;
-            d = MFMA_F64(d[b], -d[b], d);                        // rows below the sub-block: D -= U_b^T U_b
+            const d4 keep = d, keep_e = e;
+            const double na = -d[b];
+            d = MFMA_F64(na, d[b], d);                           // rows below the sub-block: D -= U_b^T U_b
+            e = MFMA_F64(na, e[b], e);                           //                           E -= U_b^T E_b
 #pragma unroll
-            for (int r = 0; r <= b; ++r) d[r] = keep[r];         // finished rows stay as they are
+            for (int r = 0; r <= b; ++r) { d[r] = keep[r]; e[r] = keep_e[r]; }   // finished rows stay
         }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        sh.Ud[kq + 4 * r][lc] = d[r];
         sh.S[o + kq + 4 * r][o + lc] = d[r];
+        sh.Yt[lc][kq + 4 * r] = e[r];                            // Yt[k][i] = E[i][k]
+        invDt_tile[lc * 16 + kq + 4 * r] = e[r];                 // = inv(U_d) row-major, what the strip TRSM reads
     }
 }
 
@@ -141,31 +154,32 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t l
     if (tid < 128) sh.rz[tid] = A[(int64_t)(r0 + tid) * lda + rcol];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (wave == 0 && !DBG_SKIP(1)) diag_tile_factor(sh, 0, lane, r0, info);
+    if (wave == 0 && !DBG_SKIP(1)) diag_tile_factor(sh, 0, lane, r0, info, invDt + (int64_t)(r0 / 16) * 256);
     __syncthreads();
 
     for (int jb = 0; jb < 8; ++jb) {
         if (DBG_SKIP(32)) break;
         const int o = 16 * jb;
-        const int ncols = 128 - o - 16;            // columns to the right of the tile
-        // ---- B: row panel  X = U_d^-T S[o:o+16, o+16:]  and the rhs rows, one column per thread
-        if (tid <= ncols && !DBG_SKIP(2)) {
-            const bool is_rhs = (tid == ncols);
-            double x[16];
+        // ---- B: row panel  X = inv(L_d) S[o:o+16, o+16:]  by MFMA (16x16 tiles round-robin over the waves)
+        //         and the rhs rows by 16 threads
+        if (!DBG_SKIP(2)) {
+            double af[4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) x[i] = is_rhs ? sh.rz[o + i] : sh.S[o + i][o + 16 + tid];
-            // right-looking order: once x[k] is final the 15-k updates below it are independent (short
-            // dependency chain: 16 x (mul + fma) instead of 136 chained fmas)
+            for (int kk = 0; kk < 4; ++kk) af[kk] = sh.Yt[4 * kk + kq][lc];
+            for (int ct = jb + 1 + wave; ct < 8; ct += 4) {
+                d4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                x[k] *= sh.invd[o + k];
+                for (int kk = 0; kk < 4; ++kk) x = MFMA_F64(af[kk], sh.S[o + 4 * kk + kq][16 * ct + lc], x);
 #pragma unroll
-                for (int i = k + 1; i < 16; ++i) x[i] = fma(-sh.Ud[k][i], x[k], x[i]);
+                for (int r = 0; r < 4; ++r) sh.S[o + kq + 4 * r][16 * ct + lc] = x[r];
             }
+            if (tid >= 240) {                                   // last 16 lanes of wave 3: z_blk = inv(L_d) r_blk
+                const int i = tid - 240;
+                double s = 0.0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (is_rhs) sh.rz[o + i] = x[i];
-                else sh.S[o + i][o + 16 + tid] = x[i];
+                for (int k = 0; k < 16; ++k) s = fma(sh.Yt[k][i], sh.rz[o + k], s);
+                // every lane has read the old rhs rows before any lane overwrites them (same wave, in order)
+                sh.rz[o + i] = s;
             }
         }
         __syncthreads();
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t l
                 sh.rz[o + 16 + lane] = s;
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);    // lgkmcnt(0): the LDS stores above are visible to this wave's reads
-            if (!DBG_SKIP(1)) diag_tile_factor(sh, o + 16, lane, r0, info);
+            if (!DBG_SKIP(1)) diag_tile_factor(sh, o + 16, lane, r0, info, invDt + (int64_t)(r0 / 16 + jb + 1) * 256);
         } else if (!DBG_SKIP(4)) {
             int idx = 0;
             for (int ti = jb + 1; ti < 8; ++ti)
@@ -212,23 +226,7 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t l
         v[1] = (j2 + 1 >= i) ? sh.S[i][j2 + 1] : 0.0;
         *reinterpret_cast<d2 *>(&A[(int64_t)(r0 + i) * lda + r0 + j2]) = v;
     }
-    if (tid < 128 && !DBG_SKIP(8)) {
-        A[(int64_t)(r0 + tid) * lda + rcol] = sh.rz[tid];
-        // column j of Y = inv(U_bb) by back substitution (U_bb Y = I to working accuracy; the strip
-        // TRSM applies Y^T from the left)
-        const int b = tid >> 4, j = tid & 15, o = 16 * b;
-        double y[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) y[i] = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 15; k >= 0; --k) {             // right-looking back substitution (rows below j stay 0)
-            y[k] *= sh.invd[o + k];
-#pragma unroll
-            for (int i = 0; i < k; ++i) y[i] = fma(-sh.S[o + i][o + k], y[k], y[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) invDt[(int64_t)(r0 / 16 + b) * 256 + i * 16 + j] = y[i];
-    }
+    if (tid < 128) A[(int64_t)(r0 + tid) * lda + rcol] = sh.rz[tid];
 }
 
 // ------------------------------------------------------------------------------------------------
