@@ -273,3 +273,75 @@ def test_full_size_properties(hip):
     assert np.array_equal(va, vb) and np.array_equal(va, full["var"][::16])
     # (5) variances are within [noise, prior]
     assert full["var"].min() >= 1e-10 and full["var"].max() <= 1.0 + 1e-10 + 1e-12
+
+
+# ---------------------------------------------------------------------------------- edge cases
+@pytest.mark.parametrize("n,m,d", [(1, 1, 1), (2, 3, 2), (63, 65, 3), (64, 64, 1), (127, 129, 5), (128, 1, 8),
+                                   (129, 200, 7), (300, 1000, 4)])
+def test_ragged_sizes_and_dims(hip, n, m, d):
+    """Sizes around the 64/128 padding boundaries, single points, every input dimension up to CBO_MAX_DIM."""
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    rng = np.random.default_rng(100 * n + m + d)
+    X = rng.uniform(-3, 3, (n, d))
+    y = np.sin(X).sum(1, keepdims=True) + 0.01 * rng.standard_normal((n, 1))
+    Xs = rng.uniform(-3, 3, (m, d))
+    g = HipGaussianProcess(X, y, variance=1.3, lengthscale=0.9, noise_var=1e-4)
+    mean, var = g.predict(Xs)
+    post = O.fit(X, y, variance=1.3, lengthscale=0.9, noise_var=1e-4)
+    mu, v = O.predict(post, Xs)
+    assert np.allclose(mean, mu, rtol=1e-7, atol=1e-9) and np.allclose(var, v, rtol=1e-6)
+    L, alpha = g.posterior_state()
+    assert np.allclose(L, post.L, rtol=1e-9, atol=1e-12) and np.allclose(alpha, post.alpha, rtol=1e-6, atol=1e-9)
+
+
+def test_argmax_ties_and_nan_like_numpy(hip):
+    """Lowest index wins exact ties (candidates duplicated); a NaN score is maximal, as numpy.argmax has it."""
+    from cbo_with_oop_amd import CausalExpectedImprovement
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    f = load_fixture("toy_bo_d2")
+    m = make_model(hip, f)
+    Xs = np.vstack([f["Xs"], f["Xs"], f["Xs"][::-1]])            # every candidate appears three times
+    res = CausalExpectedImprovement(float(f["y_best"]), "min", m).sweep(Xs, cost=1.0, want_acq=True)
+    assert res["best_idx"] == int(np.argmax(res["acq"][:, 0])) == int(f["best_idx"])
+    # NaN: a causal model whose prior variance is negative at one candidate (sqrt -> NaN in CausalRBF.K)
+    c = load_fixture("causal_d2")
+    bad = 17
+    vXs = c["vXs"].copy()
+    vXs[bad] = -1.0
+    lut = lambda tab_x, tab_v: {tuple(r): v for r, v in zip(map(tuple, tab_x), tab_v[:, 0])}
+    lm = {**lut(c["X"], c["mX"]), **lut(c["Xs"], c["mXs"])}
+    lv = {**lut(c["X"], c["vX"]), **lut(c["Xs"], vXs)}
+    g = HipGaussianProcess(c["X"], c["y"], mean_function=lambda a: np.array([[lm[tuple(r)]] for r in a]),
+                           variance_adjustment=lambda a: np.array([[lv[tuple(r)]] for r in a]))
+    with np.errstate(invalid="ignore"):
+        res = CausalExpectedImprovement(float(c["y_best"]), "min", g).sweep(c["Xs"], cost=1.0, want_acq=True)
+        post = O.fit(c["X"], c["y"], c["mX"], c["vX"])
+        acq, _, idx, _, _ = O.acquisition_sweep(post, c["Xs"], float(c["y_best"]), c["mXs"], vXs)
+    assert np.isnan(acq[bad, 0]) and idx == bad
+    assert np.isnan(res["acq"][bad, 0]) and res["best_idx"] == bad and np.isnan(res["best_val"])
+
+
+def test_c3_size_against_oracle_subsample(hip):
+    """BASELINE config 3 shape per GPU: N=8192 observations, a 32768-candidate shard (64x32x16 of the 64x32x32
+    grid), complete-graph box.  The oracle checks a 512-candidate subsample (full sweep = minutes of CPU)."""
+    from cbo_with_oop_amd import CausalExpectedImprovement
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    from cbo_with_oop_amd.graphs import CompleteGraph, meshgrid_candidates
+    box = CompleteGraph.bounds(["B", "D", "E"])
+    lo, hi = np.array([b[0] for b in box], float), np.array([b[1] for b in box], float)
+    rng = np.random.default_rng(8192)
+    X = rng.uniform(lo, hi, (8192, 3))
+    y = (np.sin(X[:, 0]) * np.cos(X[:, 1] / 2) + 0.2 * X[:, 2] + 0.1 * rng.standard_normal(8192))[:, None]
+    Xs = meshgrid_candidates(box, [64, 32, 32])[:32768]
+    m = HipGaussianProcess(X, y)
+    res = CausalExpectedImprovement(float(y.min()), "min", m).sweep(Xs, cost=3.0, want_acq=True, want_posterior=True)
+    post = O.fit(X, y)
+    assert m.jitter_tries == post.tries
+    sub = np.unique(np.concatenate([np.arange(0, 32768, 67), [res["best_idx"]]]))
+    mu, var = O.predict(post, Xs[sub])
+    assert np.max(np.abs(res["var"][sub] - var) / var) < 1e-5
+    assert np.max(np.abs(res["mean"][sub] - mu)) < 1e-5 * np.max(np.abs(y))
+    acq = O.expected_improvement(mu, var, float(y.min())) / 3.0
+    big = acq[:, 0] > 1e-6 * acq.max()
+    assert np.max(np.abs(res["acq"][sub][big] - acq[big]) / acq[big]) < 1e-4
+    assert int(np.argmax(res["acq"][:, 0])) == res["best_idx"]
