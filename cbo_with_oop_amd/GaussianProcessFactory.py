@@ -123,6 +123,21 @@ class HipGaussianProcess:
                                             int(include_likelihood), _lib.dptr(mean), _lib.dptr(var)))
         return mean[:, None], var[:, None]
 
+    def predict_grouped(self, x, group, include_likelihood=True):
+        """Predict at ``x`` ((M*group, d)) and average mean and variance over each consecutive run of ``group``
+        rows on the device: (mean (M,1), var (M,1)).  This is the do-calculus reduction of
+        src/DoCalculus.py:59-60 (np.mean over the observed rows of one intervention)."""
+        x = _lib.as_f64(x)
+        if x.ndim != 2 or x.shape[1] != self.input_dim or x.shape[0] % group:
+            raise ValueError(f"x must be (M*group, {self.input_dim})")
+        m = x.shape[0] // group
+        pm, pv = self._prior(x)
+        mean = np.empty(m)
+        var = np.empty(m)
+        _lib.check(self._lib.cbo_gp_predict_grouped(self._handle, m, group, _lib.dptr(x), _lib.dptr(pm), _lib.dptr(pv),
+                                                    int(include_likelihood), _lib.dptr(mean), _lib.dptr(var)))
+        return mean[:, None], var[:, None]
+
     def predict_noiseless(self, x):
         return self.predict(x, include_likelihood=False)
 

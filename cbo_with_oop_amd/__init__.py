@@ -5,5 +5,6 @@ from .GaussianProcessFactory import GaussianProcessFactory, GaussianProcessType,
 from .utils_functions import (CandidateGrid, CausalExpectedImprovement, Cost, find_current_global,  # noqa: F401
                               find_next_y_point, total_cost)
 from .CBO import CBOAcquisitionPath  # noqa: F401
+from .DoCalculus import DoCalculus, do_prior_functions  # noqa: F401
 
 __version__ = "0.1.0"

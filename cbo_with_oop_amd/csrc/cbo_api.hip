@@ -683,6 +683,39 @@ extern "C" int cbo_gp_predict(cbo_gp *g, int64_t m, const double *Xs, const doub
     return rc;
 }
 
+extern "C" int cbo_gp_predict_grouped(cbo_gp *g, int64_t m_groups, int64_t group, const double *Xs, const double *pm,
+                                      const double *pv, int include_noise, double *mean_out, double *var_out)
+{
+    if (!g || !mean_out || !var_out || !Xs) return fail(CBO_ERR_INVALID, "NULL argument");
+    if (m_groups <= 0 || group <= 0) return fail(CBO_ERR_INVALID, "m_groups and group must be positive");
+    if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
+    const bool causal = g->X.sv != nullptr;
+    if (causal && (!pm || !pv)) return fail(CBO_ERR_INVALID, "causal gp needs candidate prior mean/variance");
+    cbo_ctx *c = g->ctx;
+    const int64_t m = m_groups * group;
+    cbo_cands *k = nullptr;
+    int rc = cbo_cands_create(c, m, g->d, Xs, causal ? pm : nullptr, causal ? pv : nullptr, 0, &k);
+    if (rc != CBO_OK) return rc;
+    rc = enqueue_posterior(g, k);
+    if (rc == CBO_OK) {
+        AcqParams p;
+        p.variance = g->h.variance; p.noise_var = g->noise_var; p.y_best = 0.0; p.ei_jitter = 0.0; p.cost = 1.0;
+        p.task = CBO_TASK_MIN; p.include_noise = include_noise ? 1 : 0; p.want_ei = 0;
+        launch_acq(c->stream, c->q, c->mu, k->pm, k->pv, m, p, c->mean, c->var, nullptr, c->part_val, c->part_idx, 0,
+                   acq_blocks_for(m));
+        // group means into the (now free) q / mu vectors
+        launch_group_mean(c->stream, c->mean, m_groups, group, c->q);
+        launch_group_mean(c->stream, c->var, m_groups, group, c->mu);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(mean_out, c->q, sizeof(double) * m_groups, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(var_out, c->mu, sizeof(double) * m_groups, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(CBO_ERR_HIP, std::string("cbo_gp_predict_grouped: ") + hipGetErrorString(e));
+    }
+    cbo_cands_destroy(k);
+    return rc;
+}
+
 // ---- tiny host-side reductions -------------------------------------------------------------------
 static bool host_better(double va, int64_t ia, double vb, int64_t ib)
 {

@@ -104,6 +104,8 @@ void launch_acq(hipStream_t s, const double *q, const double *mu, const double *
 void launch_argmax_final(hipStream_t s, const double *part_val, const int64_t *part_idx, int n, double *best_val,
                          int64_t *best_idx);
 int acq_blocks_for(int64_t m);
+// out[g] = mean of in[g*group .. (g+1)*group)
+void launch_group_mean(hipStream_t s, const double *in, int64_t n_groups, int64_t group, double *out);
 
 void launch_gather_diag(hipStream_t s, const double *A, int64_t lda, int64_t n, double *diag);
 void launch_export_lower(hipStream_t s, const double *A, int64_t lda, int64_t n, double *L_rowmajor);

@@ -118,6 +118,27 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restr
     block_argmax(bv, bi, best_val, best_idx);
 }
 
+// Mean of consecutive runs (np.mean over the observed rows of one intervention, DoCalculus.py:59-60): one
+// wave per run, 16-byte-free strided reads (runs are short: N_obs ~ 100..1000), shuffle reduction.
+__global__ __launch_bounds__(256) void group_mean_kernel(const double *__restrict__ in, int64_t n_groups,
+                                                         int64_t group, double *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= n_groups) return;
+    const double *p = in + g * group;
+    double s = 0.0;
+    for (int64_t i = lane; i < group; i += 64) s += p[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) out[g] = s / (double)group;
+}
+
+void launch_group_mean(hipStream_t s, const double *in, int64_t n_groups, int64_t group, double *out)
+{
+    hipLaunchKernelGGL(group_mean_kernel, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, s, in, n_groups, group, out);
+}
+
 int acq_blocks_for(int64_t m)
 {
     int64_t b = (m + 255) / 256;

@@ -2,4 +2,4 @@
 (/root/reference/src/utils_functions/__init__.py star-imports the same modules)."""
 from .causal_acquisition_functions import CausalExpectedImprovement, CandidateGrid  # noqa: F401
 from .cost_functions import Cost, total_cost  # noqa: F401
-from .utils import find_current_global, find_next_y_point  # noqa: F401
+from .utils import find_current_global, find_next_y_point, fit_gaussian_process  # noqa: F401

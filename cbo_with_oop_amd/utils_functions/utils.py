@@ -32,6 +32,15 @@ def find_current_global(current_y, dict_interventions, task):
     return dict_values[opt_variable]
 
 
+def fit_gaussian_process(x, y, parameter_list):
+    """utils.py:40-45: graph-level GP, RBF(lengthscale=p[0], variance=p[1], ARD=p[3]), noise fixed 1e-2.
+    ``gp.optimize()`` (hyper-parameter MLE) is called as in the reference."""
+    from ..GaussianProcessFactory import GaussianProcessFactory, GaussianProcessType
+    gp = GaussianProcessFactory.create(GaussianProcessType.GRAPH_GP, x, y, parameter_list)
+    gp.optimize()
+    return gp
+
+
 def space_bounds(space):
     """[(lo, hi)] from an emukit ParameterSpace (``get_bounds()``), from objects with ``.parameters``
     carrying ``.min/.max`` (graph_functions.py:80-93 builds ContinuousParameter(name, min, max)), or

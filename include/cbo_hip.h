@@ -100,6 +100,15 @@ int cbo_gp_set_data(cbo_gp *gp, int64_t n, const double *X, const double *y,
 int cbo_gp_predict(cbo_gp *gp, int64_t m, const double *Xs, const double *prior_mean_s,
                    const double *prior_var_s, int include_noise, double *mean_out, double *var_out);
 
+/* Do-calculus prior (src/DoCalculus.py:34-89): predict at m_groups * group points and
+ * average the predictive mean and variance over each consecutive run of `group` rows -- one run per
+ * candidate intervention, its rows being the observed inputs with the intervened columns overwritten
+ * (DoCalculus.compute_do / get_intervened_inputs, then np.mean over the rows, :59-60).  The reduction runs
+ * on the device; only m_groups values per output come back. */
+int cbo_gp_predict_grouped(cbo_gp *gp, int64_t m_groups, int64_t group, const double *Xs,
+                           const double *prior_mean_s, const double *prior_var_s, int include_noise,
+                           double *mean_out /* m_groups */, double *var_out /* m_groups */);
+
 /* Posterior state for inspection / tests (GPy posterior.woodbury_chol, .woodbury_vector).
  * L_out: n*n row-major lower triangle (upper part zero); alpha_out: n. Either may be NULL. */
 int cbo_gp_get_posterior(cbo_gp *gp, double *L_out, double *alpha_out);

@@ -345,3 +345,53 @@ def test_c3_size_against_oracle_subsample(hip):
     big = acq[:, 0] > 1e-6 * acq.max()
     assert np.max(np.abs(res["acq"][sub][big] - acq[big]) / acq[big]) < 1e-4
     assert int(np.argmax(res["acq"][:, 0])) == res["best_idx"]
+
+
+# ---------------------------------------------------------------------------------- do-calculus prior (f1)
+def test_do_calculus_prior_matches_oracle(hip):
+    """Graph-level GP (ARD RBF, noise 1e-2) -> do-calculus mean/variance closures -> causal GP -> sweep,
+    against the oracle's row-by-row restatement of src/DoCalculus.py:34-89."""
+    import warnings
+    from cbo_with_oop_amd import (CausalExpectedImprovement, DoCalculus, GaussianProcessFactory, GaussianProcessType,
+                                  do_prior_functions)
+    from cbo_with_oop_amd.utils_functions import fit_gaussian_process
+    rng = np.random.default_rng(77)
+    n_obs = 120
+    obs = {"B": rng.uniform(-5, 4, (n_obs, 1)), "D": rng.uniform(-5, 5, (n_obs, 1)), "C": rng.normal(0, 1, (n_obs, 1))}
+    yobs = np.sin(obs["B"]) + 0.3 * obs["D"] ** 2 / 5 + 0.5 * obs["C"] + 0.05 * rng.standard_normal((n_obs, 1))
+    deps = ["B", "D", "C"]                                  # graph GP inputs; we intervene on (B, D), C stays observed
+    params = [np.array([1.2, 0.8, 1.5]), 1.4, 1e-2, True]   # [lengthscales, variance, noise, ARD]
+    xin = np.hstack([obs[v] for v in deps])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)     # optimize() is a documented no-op in this round
+        ggp = fit_gaussian_process(xin, yobs, params)
+    gpost = O.fit(xin, yobs, variance=1.4, lengthscale=params[0], noise_var=1e-2)
+    mean_fn, var_fn = do_prior_functions(ggp, xin, [0, 1, -1])
+    vals = rng.uniform([-5, -5], [4, 5], (37, 2))
+    m_ref = O.do_prior(gpost, xin, [0, 1, -1], vals, 0)
+    v_ref = O.do_prior(gpost, xin, [0, 1, -1], vals, 1)
+    assert np.allclose(mean_fn(vals), m_ref, rtol=1e-8, atol=1e-10) and mean_fn(vals).shape == (37, 1)
+    assert np.allclose(var_fn(vals), v_ref, rtol=1e-7)
+
+    # the reference-shaped class gives the same closures
+    class G:
+        fit_dependencies = [deps]
+        @staticmethod
+        def get_gp_name(iv): return "gp_" + "_".join(iv)
+    class C:
+        exploration_set = [["B", "D"]]; es_size = 1; measurements = obs; graph = G()
+    fns = DoCalculus(C()).update_all_do_functions({"gp_B_D": ggp})
+    assert np.array_equal(fns[0][0](vals), mean_fn(vals)) and np.array_equal(fns[1][0](vals), var_fn(vals))
+
+    # causal GP on interventional data with that prior, 400-candidate sweep
+    Xi = rng.uniform([-5, -5], [4, 5], (25, 2))
+    yi = np.sin(Xi[:, :1]) + 0.3 * Xi[:, 1:] ** 2 / 5 + 0.02 * rng.standard_normal((25, 1))
+    model = GaussianProcessFactory.create(GaussianProcessType.CAUSAL_GP, Xi, yi, [mean_fn, var_fn], emukit_wrapper=True)
+    Xs = rng.uniform([-5, -5], [4, 5], (400, 2))
+    res = CausalExpectedImprovement(float(yi.min()), "min", model).sweep(Xs, cost=2.0, want_acq=True, want_posterior=True)
+    pm = lambda a: O.do_prior(gpost, xin, [0, 1, -1], a, 0)
+    pv = lambda a: O.do_prior(gpost, xin, [0, 1, -1], a, 1)
+    post = O.fit(Xi, yi, pm(Xi), pv(Xi))
+    acq, bval, bidx, mu, var = O.acquisition_sweep(post, Xs, float(yi.min()), pm(Xs), pv(Xs), cost=2.0)
+    assert res["best_idx"] == bidx
+    assert np.allclose(res["mean"], mu, rtol=1e-6, atol=1e-8) and np.allclose(res["var"], var, rtol=1e-5)
