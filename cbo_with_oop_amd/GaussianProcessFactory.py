@@ -44,7 +44,7 @@ class HipGaussianProcess:
     """
 
     def __init__(self, x, y, *, variance=1.0, lengthscale=1.0, ard=False, noise_var=1e-10, mean_function=None,
-                 variance_adjustment=None, zero_diag=None, context=None):
+                 variance_adjustment=None, zero_diag=None, context=None, fix_noise=False):
         if (mean_function is None) != (variance_adjustment is None):
             raise ValueError("mean_function and variance_adjustment must be given together")
         self._lib = _lib.load()
@@ -55,6 +55,7 @@ class HipGaussianProcess:
         self.variance = float(variance)
         self.noise_var = float(noise_var)
         self.ard = bool(ard)
+        self.fix_noise = bool(fix_noise)
         x = _lib.as_f64(x)
         if x.ndim != 2:
             raise ValueError("x must be (N, d)")
@@ -154,11 +155,54 @@ class HipGaussianProcess:
 
     set_XY = set_data
 
-    def optimize(self, *args, **kwargs):
-        """Hyper-parameter MLE (emukit -> GPy optimize_restarts, src/CBO.py:173) is outside this round's
-        hot-path scope: the kernel keeps the reference's initial values."""
-        warnings.warn("HipGaussianProcess.optimize: hyper-parameter MLE is not part of the MI355X hot path yet; "
-                      "hyper-parameters are left unchanged", RuntimeWarning, stacklevel=2)
+    def log_likelihood(self):
+        """GPy ``model.log_likelihood()``: log marginal likelihood of the fitted model (device reduction over
+        the factor's diagonal and z = L^-1 (y - m))."""
+        out = ctypes.c_double(0.0)
+        _lib.check(self._lib.cbo_gp_log_marginal(self._handle, ctypes.byref(out)))
+        return out.value
+
+    def set_hyperparameters(self, variance, lengthscale, noise_var):
+        """Replace kernel variance, lengthscale(s) and Gaussian noise variance and refit."""
+        ls = np.atleast_1d(np.asarray(lengthscale, dtype=np.float64))
+        if self.ard and ls.size == 1:
+            ls = np.full(self.input_dim, ls[0])
+        ls = np.ascontiguousarray(ls)
+        _lib.check(self._lib.cbo_gp_set_hyper(self._handle, float(variance), _lib.dptr(ls), float(noise_var)))
+        self.variance, self.lengthscale, self.noise_var = float(variance), ls, float(noise_var)
+        self._fit()
+
+    def _objective(self, log_theta):
+        """Negative log marginal likelihood at exp(log_theta) = [variance, lengthscale(s), (noise)]."""
+        theta = np.exp(log_theta)
+        nl = self.lengthscale.size
+        noise = self.noise_var if self.fix_noise else theta[1 + nl]
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                self.set_hyperparameters(theta[0], theta[1:1 + nl], noise)
+            return -self.log_likelihood()
+        except np.linalg.LinAlgError:
+            return 1e25                       # GPy's optimiser treats a failed Cholesky as a rejected step
+
+    def optimize(self, max_iters=1000, **kwargs):
+        """Hyper-parameter MLE (emukit ``GPyModelWrapper.optimize`` -> GPy ``optimize_restarts(1)``, src/CBO.py:173;
+        ``gp.optimize()`` in src/utils_functions/utils.py:44): maximise the log marginal likelihood over kernel
+        variance, lengthscale(s) and -- unless fixed, as for graph-level GPs -- the noise variance.  Host logic:
+        scipy L-BFGS-B (GPy's default optimiser) in log-parameter space with finite-difference gradients, every
+        objective evaluation being a device refit + device likelihood reduction.  GPy uses analytic gradients and
+        a softplus transform; the optimum is the same stationary point, reached to optimiser tolerance."""
+        from scipy.optimize import minimize
+        x0 = [self.variance, *self.lengthscale]
+        if not self.fix_noise:
+            x0.append(self.noise_var)
+        x0 = np.log(np.asarray(x0, dtype=np.float64))
+        f0 = self._objective(x0)
+        res = minimize(self._objective, x0, method="L-BFGS-B", options={"maxiter": int(max_iters), "maxfun": 15000})
+        best = res.x if res.fun <= f0 else x0
+        self._objective(best)                 # leave the model fitted at the optimum
+        self.optimization_result = res
+        return res
 
     def get_prediction_gradients(self, x):
         raise NotImplementedError("prediction gradients (SURVEY.md §8 f3) are not part of the grid-sweep path")
@@ -208,7 +252,7 @@ class GaussianProcessFactory:
     def create_graph_gp(x, y, parameters):
         """:49-54  RBF(lengthscale=p[0], variance=p[1], ARD=p[3]), noise fixed to 1e-2 after construction."""
         return HipGaussianProcess(x, y, variance=parameters[1], lengthscale=parameters[0], ard=parameters[3],
-                                  noise_var=1e-2)
+                                  noise_var=1e-2, fix_noise=True)
 
     @staticmethod
     def create_non_causal_gp(x, y, _):

@@ -683,6 +683,47 @@ extern "C" int cbo_gp_predict(cbo_gp *g, int64_t m, const double *Xs, const doub
     return rc;
 }
 
+extern "C" int cbo_gp_set_hyper(cbo_gp *g, double variance, const double *lengthscale, double noise_var)
+{
+    if (!g || !lengthscale) return fail(CBO_ERR_INVALID, "NULL argument");
+    cbo_ctx *c = g->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    g->h.variance = variance;
+    g->noise_var = noise_var;
+    g->fitted = false;
+    g->alpha_ready = false;
+    if (g->h.ard) {
+        g->ls.assign(lengthscale, lengthscale + g->d);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(g->ls_dev, lengthscale, sizeof(double) * g->d, hipMemcpyHostToDevice));
+        // GPy ARD scales the inputs: re-derive the scaled SoA coordinates and their squared norms
+        launch_prep_points(c->stream, g->raw, g->n, g->d, g->ls_dev, g->X.sv ? g->X.pv : nullptr, g->X.xs, g->n_pad,
+                           g->X.sq, g->X.sv);
+        HIP_TRY(hipGetLastError());
+    } else {
+        g->ls.assign(lengthscale, lengthscale + 1);
+        g->h.lengthscale = lengthscale[0];
+    }
+    return CBO_OK;
+}
+
+extern "C" int cbo_gp_log_marginal(cbo_gp *g, double *lml_out)
+{
+    if (!g || !lml_out) return fail(CBO_ERR_INVALID, "NULL argument");
+    if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
+    cbo_ctx *c = g->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    double h2[2];
+    // part_val is a free 2048-double device scratch between sweeps
+    launch_lml_terms(c->stream, g->A, g->lda, g->n_pad, g->z, c->part_val);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h2, c->part_val, sizeof(h2), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // GPy: 0.5 * (-n log(2 pi) - W_logdet - sum(alpha * (Y - m))),  W_logdet = 2 sum log L_ii
+    *lml_out = 0.5 * (-(double)g->n * 1.8378770664093453 - 2.0 * h2[1] - h2[0]);
+    return CBO_OK;
+}
+
 extern "C" int cbo_gp_predict_grouped(cbo_gp *g, int64_t m_groups, int64_t group, const double *Xs, const double *pm,
                                       const double *pv, int include_noise, double *mean_out, double *var_out)
 {

@@ -107,6 +107,8 @@ int acq_blocks_for(int64_t m);
 // out[g] = mean of in[g*group .. (g+1)*group)
 void launch_group_mean(hipStream_t s, const double *in, int64_t n_groups, int64_t group, double *out);
 
+// out[0] = sum z_i^2, out[1] = sum log U_ii over the n_pad rows (padding contributes 0)
+void launch_lml_terms(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *z, double *out2);
 void launch_gather_diag(hipStream_t s, const double *A, int64_t lda, int64_t n, double *diag);
 void launch_export_lower(hipStream_t s, const double *A, int64_t lda, int64_t n, double *L_rowmajor);
 void launch_export_sym(hipStream_t s, const double *A, int64_t lda, int64_t n, double *K_rowmajor);

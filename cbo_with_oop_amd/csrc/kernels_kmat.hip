@@ -246,6 +246,35 @@ void launch_gather_diag(hipStream_t s, const double *A, int64_t lda, int64_t n, 
     hipLaunchKernelGGL(gather_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A, lda, n, diag);
 }
 
+// Terms of GPy's log marginal likelihood from the factor: sum z^2 (= r^T Ky^-1 r) and sum log U_ii.
+__global__ __launch_bounds__(256) void lml_terms_kernel(const double *__restrict__ A, int64_t lda, int64_t n_pad,
+                                                        const double *__restrict__ z, double *__restrict__ out2)
+{
+    __shared__ double s1[256], s2[256];
+    double a = 0.0, b = 0.0;
+    for (int64_t i = threadIdx.x; i < n_pad; i += 256) {
+        const double zi = z[i];
+        a = __fma_rn(zi, zi, a);
+        b = __dadd_rn(b, log(A[i * lda + i]));
+    }
+    s1[threadIdx.x] = a;
+    s2[threadIdx.x] = b;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            s1[threadIdx.x] = __dadd_rn(s1[threadIdx.x], s1[threadIdx.x + st]);
+            s2[threadIdx.x] = __dadd_rn(s2[threadIdx.x], s2[threadIdx.x + st]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out2[0] = s1[0]; out2[1] = s2[0]; }
+}
+
+void launch_lml_terms(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *z, double *out2)
+{
+    hipLaunchKernelGGL(lml_terms_kernel, dim3(1), dim3(256), 0, s, A, lda, n_pad, z, out2);
+}
+
 // L (row-major lower, upper zero) from the upper factor U: L[i][k] = U[k][i].
 __global__ void export_lower_kernel(const double *__restrict__ A, int64_t lda, int64_t n, double *__restrict__ L)
 {

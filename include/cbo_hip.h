@@ -85,7 +85,9 @@ int cbo_gp_create(cbo_ctx *ctx, int dtype, int64_t n, int d, const double *X, co
 void cbo_gp_destroy(cbo_gp *gp);
 
 /* GPy ExactGaussianInference.inference + util.linalg.jitchol: K(X,X) assembly, Ky = K+(noise+1e-8)I,
- * jittered Cholesky (retry ladder mean(diag)*1e-6 x10, <= 5 retries), alpha.  Everything runs on the
+ * jittered Cholesky (retry ladder mean(diag)*1e-6 x10, <= 5 retries) with the forward solve
+ * z = L^-1 (y - m) carried through the factorisation.  GPy's alpha = L^-T z is materialised on first use
+ * (cbo_gp_get_posterior): predict and the sweep form the mean as (L^-1 k*)^T z.  Everything runs on the
  * device from the resident X, y.  jitter_tries_out / jitter_out may be NULL. */
 int cbo_gp_fit(cbo_gp *gp, int *jitter_tries_out, double *jitter_out);
 
@@ -99,6 +101,14 @@ int cbo_gp_set_data(cbo_gp *gp, int64_t n, const double *X, const double *y,
  * mean = K*^T Ky^-1 (y-m) + m(X*), var = clip(Kdiag - |L^-1 K*|^2, 1e-15) (+ noise). */
 int cbo_gp_predict(cbo_gp *gp, int64_t m, const double *Xs, const double *prior_mean_s,
                    const double *prior_var_s, int include_noise, double *mean_out, double *var_out);
+
+/* Hyper-parameter MLE support (GPy model.optimize() reached from src/CBO.py:173 and
+ * src/utils_functions/utils.py:44).  cbo_gp_set_hyper replaces kernel variance, lengthscale(s) and noise
+ * variance (the model must be refitted with cbo_gp_fit); cbo_gp_log_marginal returns GPy's
+ * log_marginal_likelihood of the fitted model, 0.5*(-n log 2pi - logdet Ky - r^T Ky^-1 r), computed on the
+ * device from the factor's diagonal and z = L^-1 r.  The optimiser loop itself is host logic. */
+int cbo_gp_set_hyper(cbo_gp *gp, double variance, const double *lengthscale, double noise_var);
+int cbo_gp_log_marginal(cbo_gp *gp, double *lml_out);
 
 /* Do-calculus prior (src/DoCalculus.py:34-89): predict at m_groups * group points and
  * average the predictive mean and variance over each consecutive run of `group` rows -- one run per

@@ -197,6 +197,42 @@ def predict(post, Xs, mXs=None, vXs=None, include_noise=True, var_form="trtrs"):
     return mu, var
 
 
+def log_marginal_likelihood(post):
+    """GPy ``ExactGaussianInference.inference``: 0.5*(-n log 2pi - W_logdet - sum(alpha * (Y - m))),
+    W_logdet = 2 sum log diag(L)."""
+    r = post.y if post.mX is None else post.y - np.asarray(post.mX, dtype=np.float64).reshape(-1, 1)
+    n = post.y.shape[0]
+    return float(0.5 * (-n * np.log(2 * np.pi) - 2.0 * np.sum(np.log(np.diag(post.L))) - np.sum(post.alpha * r)))
+
+
+def optimize_hyperparameters(X, y, mX=None, vX=None, variance=REF_VARIANCE, lengthscale=REF_LENGTHSCALE,
+                             noise_var=REF_NOISE_VAR, fix_noise=False, max_iters=1000):
+    """Counterpart of GPy ``model.optimize()`` (src/CBO.py:173, src/utils_functions/utils.py:44) for the
+    product's host-side optimiser: same objective, same scipy L-BFGS-B call in log-parameter space with
+    finite-difference gradients.  (GPy itself uses analytic gradients and a softplus transform -- not
+    reproducible here, 'parity unpinned'.)  Returns (variance, lengthscale array, noise_var, lml)."""
+    from scipy.optimize import minimize
+    ls0 = np.atleast_1d(np.asarray(lengthscale, dtype=np.float64))
+    nl = ls0.size
+
+    def unpack(x):
+        th = np.exp(x)
+        return th[0], (th[1] if nl == 1 else th[1:1 + nl]), (noise_var if fix_noise else th[1 + nl])
+
+    def f(x):
+        v, l, nz = unpack(x)
+        try:
+            return -log_marginal_likelihood(fit(X, y, mX, vX, v, l, nz))
+        except np.linalg.LinAlgError:
+            return 1e25
+
+    x0 = np.log(np.asarray([variance, *ls0] + ([] if fix_noise else [noise_var]), dtype=np.float64))
+    res = minimize(f, x0, method="L-BFGS-B", options={"maxiter": int(max_iters), "maxfun": 15000})
+    best = res.x if res.fun <= f(x0) else x0
+    v, l, nz = unpack(best)
+    return float(v), np.atleast_1d(l), float(nz), -f(best)
+
+
 # --------------------------------------------------------------------------- acquisition
 def standard_normal_pdf_cdf(x, mean, standard_deviation):
     """src/utils_functions/causal_acquisition_functions.py:77-88."""

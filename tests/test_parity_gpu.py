@@ -362,10 +362,9 @@ def test_do_calculus_prior_matches_oracle(hip):
     deps = ["B", "D", "C"]                                  # graph GP inputs; we intervene on (B, D), C stays observed
     params = [np.array([1.2, 0.8, 1.5]), 1.4, 1e-2, True]   # [lengthscales, variance, noise, ARD]
     xin = np.hstack([obs[v] for v in deps])
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore", RuntimeWarning)     # optimize() is a documented no-op in this round
-        ggp = fit_gaussian_process(xin, yobs, params)
-    gpost = O.fit(xin, yobs, variance=1.4, lengthscale=params[0], noise_var=1e-2)
+    ggp = fit_gaussian_process(xin, yobs, params)           # includes gp.optimize() as in the reference
+    assert ggp.noise_var == 1e-2 and ggp.fix_noise
+    gpost = O.fit(xin, yobs, variance=ggp.variance, lengthscale=ggp.lengthscale, noise_var=1e-2)
     mean_fn, var_fn = do_prior_functions(ggp, xin, [0, 1, -1])
     vals = rng.uniform([-5, -5], [4, 5], (37, 2))
     m_ref = O.do_prior(gpost, xin, [0, 1, -1], vals, 0)
@@ -395,3 +394,42 @@ def test_do_calculus_prior_matches_oracle(hip):
     acq, bval, bidx, mu, var = O.acquisition_sweep(post, Xs, float(yi.min()), pm(Xs), pv(Xs), cost=2.0)
     assert res["best_idx"] == bidx
     assert np.allclose(res["mean"], mu, rtol=1e-6, atol=1e-8) and np.allclose(res["var"], var, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------- hyper-parameter MLE (f2)
+def test_log_marginal_likelihood_matches_oracle(hip, golden):
+    f = golden
+    m = make_model(hip, f)
+    post = O.fit(f["X"], f["y"], f["mX"], f["vX"], float(f["variance"]), f["lengthscale_arg"], float(f["noise_var"]))
+    ref = O.log_marginal_likelihood(post)
+    # r^T Ky^-1 r carries the eps*cond(Ky) error of any fp64 solve; logdet is benign
+    tol = 1e-9 + 50 * np.max(np.abs(f["alpha"][:, 0] - f["alpha_truth"]) / np.abs(f["alpha_truth"]).clip(1e-300))
+    assert np.isclose(m.log_likelihood(), ref, rtol=tol), (m.log_likelihood(), ref, golden["name"])
+
+
+def test_optimize_reaches_the_oracle_optimum(hip):
+    """model.optimize() (src/CBO.py:173): same objective and optimiser call on both sides."""
+    from cbo_with_oop_amd.GaussianProcessFactory import GaussianProcessFactory, GaussianProcessType
+    rng = np.random.default_rng(5)
+    X = rng.uniform(-4, 4, (60, 2))
+    y = np.sin(1.3 * X[:, :1]) * np.cos(0.7 * X[:, 1:]) + 0.05 * rng.standard_normal((60, 1))
+    m = GaussianProcessFactory.create(GaussianProcessType.NON_CAUSAL_GP, X, y, None, emukit_wrapper=True)
+    l0 = m.log_likelihood()
+    m.optimize()
+    v, ls, nz, lml = O.optimize_hyperparameters(X, y)
+    assert m.log_likelihood() > l0 + 1.0
+    assert np.isclose(m.log_likelihood(), lml, rtol=1e-5, atol=1e-4)
+    assert np.isclose(m.variance, v, rtol=2e-2) and np.allclose(m.lengthscale, ls, rtol=2e-2)
+    mean, var = m.predict(X[:5])
+    mu, vv = O.predict(O.fit(X, y, variance=m.variance, lengthscale=float(m.lengthscale[0]), noise_var=m.noise_var), X[:5])
+    assert np.allclose(mean, mu, rtol=1e-6, atol=1e-8) and np.allclose(var, vv, rtol=1e-5)
+    # graph-level GP: ARD lengthscales, noise fixed at 1e-2 (src/utils_functions/utils.py:40-45)
+    Xg = rng.uniform(-2, 2, (80, 3))
+    yg = (np.cos(Xg[:, 0]) + 0.5 * Xg[:, 1])[:, None] + 0.1 * rng.standard_normal((80, 1))
+    g = GaussianProcessFactory.create(GaussianProcessType.GRAPH_GP, Xg, yg, [1.0, 1.0, 1e-2, True])
+    g.optimize()
+    v, ls, nz, lml = O.optimize_hyperparameters(Xg, yg, variance=1.0, lengthscale=np.ones(3), noise_var=1e-2,
+                                                fix_noise=True)
+    assert g.noise_var == 1e-2 and nz == 1e-2
+    assert np.isclose(g.log_likelihood(), lml, rtol=1e-5, atol=1e-4)
+    assert ls[2] > 3 * ls[0] and g.lengthscale[2] > 3 * g.lengthscale[0]      # the irrelevant input is switched off
