@@ -433,3 +433,77 @@ def test_optimize_reaches_the_oracle_optimum(hip):
     assert g.noise_var == 1e-2 and nz == 1e-2
     assert np.isclose(g.log_likelihood(), lml, rtol=1e-5, atol=1e-4)
     assert ls[2] > 3 * ls[0] and g.lengthscale[2] > 3 * g.lengthscale[0]      # the irrelevant input is switched off
+
+
+# ---------------------------------------------------------------------------------- trajectories
+def _toy_trajectory(fit_predict_sweep, n_trials=12):
+    """The reference's intervene() loop on the toy graph (src/CBO.py:143-173 without the monitor): refit the
+    GP(s), score each exploration set on its 200-point grid, pick the set (first max), evaluate the SEM target
+    there, append the point.  `fit_predict_sweep(X, y, Xs, y_best)` -> (best_val, best_idx)."""
+    from cbo_with_oop_amd.graphs import ToyGraph, meshgrid_candidates
+    fx, fz = load_fixture("toy_init_X"), load_fixture("toy_init_Z")
+    data_x, data_y = [fx["X"].copy(), fz["X"].copy()], [fx["y"].copy(), fz["y"].copy()]
+    grids = [meshgrid_candidates(ToyGraph.bounds(["X"]), [200]), meshgrid_candidates(ToyGraph.bounds(["Z"]), [200])]
+    target = [ToyGraph.target_do_x, ToyGraph.target_do_z]
+    best_y = {"X": [np.inf, float(data_y[0].min())], "Z": [np.inf, float(data_y[1].min())]}
+    history = []
+    for _ in range(n_trials):
+        y_star = O.find_current_global(best_y, ["X", "Z"], "min")
+        scores = [fit_predict_sweep(data_x[s], data_y[s], grids[s], y_star) for s in range(2)]
+        s = O.select_next_intervention([np.array([[v]]) for v, _ in scores])
+        idx = scores[s][1]
+        x_new = grids[s][idx][None, :]
+        y_new = target[s](x_new)
+        data_x[s] = np.vstack([data_x[s], x_new])
+        data_y[s] = np.vstack([data_y[s], y_new])
+        best_y["XZ"[s]].append(float(y_new[0, 0]))
+        history.append((s, idx, scores[s][0]))
+    return history
+
+
+def test_toy_graph_intervention_trajectory_matches_oracle(hip):
+    """'identical intervention choices to the reference on toy_graph' (BASELINE.json north_star), trial after
+    trial, against the oracle run through the same loop (the reference itself cannot run toy_graph)."""
+    from cbo_with_oop_amd import CausalExpectedImprovement
+    from cbo_with_oop_amd.GaussianProcessFactory import GaussianProcessFactory, GaussianProcessType
+
+    def hip_side(X, y, Xs, y_star):
+        m = GaussianProcessFactory.create(GaussianProcessType.NON_CAUSAL_GP, X, y, None, emukit_wrapper=True)
+        r = CausalExpectedImprovement(y_star, "min", m).sweep(Xs, cost=1.0)
+        return r["best_val"], r["best_idx"]
+
+    def oracle_side(X, y, Xs, y_star):
+        _, val, idx, _, _ = O.acquisition_sweep(O.fit(X, y), Xs, y_star, cost=1.0)
+        return val, idx
+
+    h, o = _toy_trajectory(hip_side), _toy_trajectory(oracle_side)
+    assert [(s, i) for s, i, _ in h] == [(s, i) for s, i, _ in o], (h, o)
+    assert np.allclose([v for _, _, v in h], [v for _, _, v in o], rtol=1e-4)
+    assert len({s for s, _, _ in h}) >= 1
+
+
+def test_c4_size_chunked_workspace(hip):
+    """BASELINE config 4 shape per GPU: N=16384 observations, 32768 candidates (one 8th of the 64^3 grid), coral
+    box -- the V workspace (4.3 GB) exceeds the 4 GiB default and is processed in two chunks.  The oracle
+    checks a 128-candidate subsample (fp64 dpotrf of a 16384^2 matrix on the host, ~0.5 min)."""
+    from cbo_with_oop_amd import CausalExpectedImprovement
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    from cbo_with_oop_amd.graphs import SimplifiedCoralGraph, meshgrid_candidates
+    box = SimplifiedCoralGraph.bounds(["N", "O", "C"])
+    lo, hi = np.array([b[0] for b in box], float), np.array([b[1] for b in box], float)
+    rng = np.random.default_rng(16384)
+    X = rng.uniform(lo, hi, (16384, 3))
+    y = (np.sin(X[:, 0]) + np.cos(3 * X[:, 1]) * X[:, 2] + 0.1 * rng.standard_normal(16384))[:, None]
+    Xs = meshgrid_candidates(box, [64, 64, 64])[:32768]
+    m = HipGaussianProcess(X, y)
+    res = CausalExpectedImprovement(float(y.min()), "min", m).sweep(Xs, cost=3.0, want_acq=True, want_posterior=True)
+    assert int(np.argmax(res["acq"][:, 0])) == res["best_idx"]
+    post = O.fit(X, y)
+    assert m.jitter_tries == post.tries
+    sub = np.unique(np.concatenate([np.arange(0, 32768, 257), [res["best_idx"]]]))
+    mu, var = O.predict(post, Xs[sub])
+    # 16384 observations in this small box leave posterior variances of 1e-10..1e-7: var = kss - q with
+    # q = kss (1 - 1e-9) is a cancellation that no fp64 evaluation resolves to 1e-5 (both sides carry
+    # ~N eps kss = 1e-14 absolute); hence rtol 1e-5 plus that absolute floor
+    assert np.all(np.abs(res["var"][sub] - var) <= 1e-5 * var + 1e-13)
+    assert np.max(np.abs(res["mean"][sub] - mu)) < 1e-5 * np.max(np.abs(y))
