@@ -362,12 +362,10 @@ static void launch_syrk(hipStream_t s, double *A, int64_t lda, int r0, int n1, i
 void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &events, double *A, int64_t lda,
                      int64_t n_pad, double *invDt, int *info_dev)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag128_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DiagShared));
-        attr_set = true;
-    }
+    // > 64 KiB of dynamic LDS needs the opt-in on the current device (cheap; done per call so that several
+    // devices in one process are all covered)
+    hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)sizeof(DiagShared));
     hipMemsetAsync(info_dev, 0, sizeof(int), s);
     const int rcol = (int)n_pad;
 #ifdef CBO_DIAG_KNOBS
@@ -384,8 +382,11 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     // the side stream starts after everything queued on the main stream so far (K assembly, rhs)
     hipEventRecord(events[2 * np], s);
     hipStreamWaitEvent(side, events[2 * np], 0);
-    bool rest_pending = false;
-    for (int k = 0; k < np; ++k) {
+    // Panels are taken in pairs: the second panel of a pair only needs the first one's update of its own 128
+    // rows, so the trailing matrix below the pair is updated once with K = 256 (half the read-modify-write
+    // passes); the bulk of that update runs on the side stream under the next pair's diagonal/panel work.
+    int pending = -1;                      // event index of the bulk update still in flight
+    for (int k = 0; k < np; k += 2) {
         const int r0 = 128 * k;
         hipLaunchKernelGGL(potrf_diag128_kernel, dim3(1), dim3(256), sizeof(DiagShared), s, A, lda, r0, rcol, invDt,
                            info_dev, dbg);
@@ -393,17 +394,25 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         if (n2 <= 0) break;
         launch_trsm_strips(s, A + (int64_t)r0 * lda + r0, lda, invDt + (int64_t)(r0 / 16) * 256,
                            A + (int64_t)r0 * lda + r0 + 128, lda, 128, n2, nullptr, nullptr, nullptr);
-        // rows of the next panel: wait for the previous bulk update (it touches them too), then update
-        if (rest_pending) hipStreamWaitEvent(s, events[2 * (k - 1) + 1], 0);
+        // rows of the pair's second panel: K = 128 update with the first panel (after the previous bulk
+        // update, which touches the same rows)
+        if (pending >= 0) { hipStreamWaitEvent(s, events[pending], 0); pending = -1; }
         launch_syrk(s, A, lda, r0, 128, n2, rcol, 0, 2);
-        if (n2 > 128) {
-            hipEventRecord(events[2 * k], s);                 // panel k solved and next-panel rows updated
+        const int r1 = r0 + 128;
+        hipLaunchKernelGGL(potrf_diag128_kernel, dim3(1), dim3(256), sizeof(DiagShared), s, A, lda, r1, rcol, invDt,
+                           info_dev, dbg);
+        const int n3 = (int)n_pad - r1 - 128;
+        if (n3 <= 0) break;
+        launch_trsm_strips(s, A + (int64_t)r1 * lda + r1, lda, invDt + (int64_t)(r1 / 16) * 256,
+                           A + (int64_t)r1 * lda + r1 + 128, lda, 128, n3, nullptr, nullptr, nullptr);
+        // both panels against everything below them: next pair's first panel rows on this stream, ...
+        launch_syrk(s, A, lda, r0, 256, n3, rcol, 0, 2);
+        if (n3 > 128) {                                       // ... the rest on the side stream
+            hipEventRecord(events[2 * k], s);
             hipStreamWaitEvent(side, events[2 * k], 0);
-            launch_syrk(side, A, lda, r0, 128, n2, rcol, 2, n2 / 64);
+            launch_syrk(side, A, lda, r0, 256, n3, rcol, 2, n3 / 64);
             hipEventRecord(events[2 * k + 1], side);
-            rest_pending = true;
-        } else {
-            rest_pending = false;
+            pending = 2 * k + 1;
         }
     }
     // nothing is left on the side stream that the main stream has not waited for (the last bulk update is
