@@ -3,7 +3,8 @@
 
 One "step" = one pass of the whole hot path of BASELINE.json's north_star over one batch of synthetic
 input, exactly what CBO.intervene() triggers each trial (/root/reference/src/CBO.py:152-164):
-    fit   : K(X,X) assembly -> jittered Cholesky (+ z = L^-1 r) -> alpha
+    fit   : K(X,X) assembly -> jittered Cholesky with the forward solve z = L^-1 (y - m) carried along
+            (GPy's alpha = L^-T z is not needed by the sweep and is materialised on demand)
     sweep : K(X,X*) -> V = L^-1 K* (variance, mean) -> EI / cost -> arg-max over the rank's candidates
     pick  : arg-max exchange across ranks (RCCL all-gather of 16 B per rank when --gpus > 1)
 Inputs (X, y, candidate grid) are resident in HBM before the timed region starts; the only host
@@ -180,6 +181,17 @@ def main():
                          "avg_launch_ms": trsm_ms,
                          "algorithmic_flops_per_launch": timers["trsm_flops"] / launches},
         }
+        # secondary rooflines (HBM-bound kernels): K(X,X) assembly writes the upper 64x64 tiles of Ky once,
+        # the EI/arg-max epilogue streams q, mu in and nothing out (outputs stay on the device)
+        n_pad = -(-N_OBS // 128) * 128
+        nt = n_pad // 64
+        kxx_bytes = nt * (nt + 1) // 2 * 64 * 64 * 8
+        kxx_ms = timers["ms_kxx"] / max(1, timers["n_fit"])
+        out["roofline_kxx"] = {"kernel": "kmat_tile_kernel<3> (K(X,X) + diag, upper tiles) + rhs", "bound": "hbm",
+                               "achieved": kxx_bytes / (kxx_ms * 1e-3) / 1e9 if kxx_ms > 0 else 0.0, "peak": 8000.0,
+                               "unit": "GB/s", "frac": (kxx_bytes / (kxx_ms * 1e-3) / 1e9 / 8000.0) if kxx_ms > 0 else 0.0,
+                               "avg_launch_ms": kxx_ms, "algorithmic_bytes_per_launch": kxx_bytes,
+                               "note": "fp64 exp per element: ALU-bound below the HBM roof (DESIGN.md 4)"}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(X, y, Xs, y_best, cost, min(args.cpu_sample, Xs.shape[0]))
         else:

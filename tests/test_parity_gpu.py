@@ -507,3 +507,22 @@ def test_c4_size_chunked_workspace(hip):
     # ~N eps kss = 1e-14 absolute); hence rtol 1e-5 plus that absolute floor
     assert np.all(np.abs(res["var"][sub] - var) <= 1e-5 * var + 1e-13)
     assert np.max(np.abs(res["mean"][sub] - mu)) < 1e-5 * np.max(np.abs(y))
+
+
+def test_bitwise_reproducibility(hip):
+    """Two fits and two sweeps of the same inputs give bit-identical factors and scores (fixed reduction orders,
+    no atomics; a race in the LDS-DMA pipeline or the look-ahead streams would show up here)."""
+    from cbo_with_oop_amd import CausalExpectedImprovement
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    X, y, Xs = c2_problem(n=1536, grid=(16, 16, 8), seed=11)
+    a, b = HipGaussianProcess(X, y), HipGaussianProcess(X, y)
+    La, _ = a.posterior_state()
+    Lb, _ = b.posterior_state()
+    assert np.array_equal(La, Lb)
+    ei = CausalExpectedImprovement(float(y.min()), "min", a)
+    r1 = ei.sweep(Xs, cost=3.0, want_acq=True, want_posterior=True)
+    for _ in range(3):
+        a.set_data(X, y)                                      # refit in place, then sweep again
+        r2 = ei.sweep(Xs, cost=3.0, want_acq=True, want_posterior=True)
+        assert np.array_equal(r1["acq"], r2["acq"]) and np.array_equal(r1["var"], r2["var"])
+        assert np.array_equal(r1["mean"], r2["mean"]) and r1["best_idx"] == r2["best_idx"]
