@@ -87,6 +87,34 @@ class CausalExpectedImprovement:
         """(M,1) improvement, as the reference's ``evaluate`` (:27-43)."""
         return self.sweep(x, cost=1.0, want_acq=True)["acq"]
 
+    def __truediv__(self, cost):
+        """``CausalExpectedImprovement(...) / Cost(...)`` as in src/utils_functions/utils.py:34 (emukit's
+        ``Acquisition.__truediv__`` builds a Quotient there)."""
+        return AcquisitionQuotient(self, cost)
+
+    @property
+    def has_gradients(self):
+        return False
+
+
+class AcquisitionQuotient:
+    """emukit ``Quotient`` of the improvement and a ``Cost``: ``evaluate(x) = EI(x) / Cost(x)`` where the cost of
+    a batch is one scalar (cost_functions.py module docstring); the division happens inside the HIP sweep."""
+
+    def __init__(self, numerator, denominator):
+        self.numerator, self.denominator = numerator, denominator
+        self.model = numerator.model
+
+    def _points(self, candidates):
+        return candidates.points if isinstance(candidates, CandidateGrid) else np.asarray(candidates)
+
+    def sweep(self, candidates, **kwargs):
+        return self.numerator.sweep(candidates, cost=float(self.denominator.evaluate(self._points(candidates))),
+                                    **kwargs)
+
+    def evaluate(self, x):
+        return self.sweep(x, want_acq=True)["acq"]
+
     @property
     def has_gradients(self):
         return False

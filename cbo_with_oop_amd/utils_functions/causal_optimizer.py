@@ -1,0 +1,42 @@
+"""Acquisition optimiser of the MI355X path, mirroring the class name and ``optimize`` contract of
+/root/reference/src/utils_functions/causal_optimizer.py:15-71.
+
+The reference samples ``num_anchor_points`` uniform random anchors, scores them with one batched
+``acquisition.evaluate`` (:52-55), keeps the best and refines it with L-BFGS (:59-65).  Here the batched
+scoring IS the optimiser: a deterministic regular grid over the space (BASELINE.json's "N-candidate sweep",
+SURVEY.md §0.7), scored on the GPU, arg-max taken on the GPU.  Gradient refinement is SURVEY.md §8 f3.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ..graphs import meshgrid_candidates
+from .causal_acquisition_functions import CandidateGrid
+
+
+class CausalGradientAcquisitionOptimizer:
+    def __init__(self, space, num_anchor_points=None, grid_shape=None):
+        """``space``: emukit ParameterSpace / object with ``parameters`` / list of (lo, hi).  ``grid_shape``
+        (points per dimension) defaults to ``default_grid_shape``; ``num_anchor_points``, if given, is used as
+        the candidate budget instead of 16384."""
+        from .utils import default_grid_shape, space_bounds
+        self.space = space
+        self.bounds = space_bounds(space)
+        self.grid_shape = list(grid_shape) if grid_shape is not None else default_grid_shape(
+            len(self.bounds), budget=num_anchor_points)
+
+    def candidates(self):
+        return meshgrid_candidates(self.bounds, self.grid_shape)
+
+    def optimize(self, acquisition, context=None):
+        """(x_max (1,d), acquisition value at x_max (1,1)) -- emukit ``AcquisitionOptimizerBase.optimize``.
+        ``acquisition`` is ``CausalExpectedImprovement(...) / Cost(...)`` (an ``AcquisitionQuotient``) or a bare
+        ``CausalExpectedImprovement``."""
+        pts = self.candidates()
+        grid = CandidateGrid(pts, acquisition.model)
+        try:
+            res = acquisition.sweep(grid)
+        finally:
+            grid.close()
+        x = pts[res["best_idx"]][None, :].copy()
+        return x, np.array([[res["best_val"]]])

@@ -526,3 +526,23 @@ def test_bitwise_reproducibility(hip):
         r2 = ei.sweep(Xs, cost=3.0, want_acq=True, want_posterior=True)
         assert np.array_equal(r1["acq"], r2["acq"]) and np.array_equal(r1["var"], r2["var"])
         assert np.array_equal(r1["mean"], r2["mean"]) and r1["best_idx"] == r2["best_idx"]
+
+
+def test_optimizer_class_and_quotient_mirror_the_reference_call_sequence(hip):
+    """src/utils_functions/utils.py:29-37 written out with the mirrored classes gives find_next_y_point's answer."""
+    from cbo_with_oop_amd.graphs import ToyGraph
+    from cbo_with_oop_amd.utils_functions import (CausalExpectedImprovement, CausalGradientAcquisitionOptimizer, Cost,
+                                                  find_next_y_point)
+    from cbo_with_oop_amd.GaussianProcessFactory import GaussianProcessFactory, GaussianProcessType
+    f = load_fixture("toy_init_Z")
+    model = GaussianProcessFactory.create(GaussianProcessType.NON_CAUSAL_GP, f["X"], f["y"], None, emukit_wrapper=True)
+    costs = ToyGraph.get_cost_structure(1)
+    space = ToyGraph.bounds(["Z"])
+    cost_acquisition = Cost(costs, ["Z"])
+    optimizer = CausalGradientAcquisitionOptimizer(space, grid_shape=[200])
+    acquisition = CausalExpectedImprovement(float(f["y_best"]), "min", model) / cost_acquisition
+    x_new, _ = optimizer.optimize(acquisition)
+    y_acquisition = acquisition.evaluate(x_new)
+    y2, x2 = find_next_y_point(space, model, float(f["y_best"]), ["Z"], costs, grid_shape=[200])
+    assert np.array_equal(x_new, x2) and np.array_equal(x_new[0], f["Xs"][int(f["best_idx"])])
+    assert np.allclose(y_acquisition, y2, rtol=1e-14) and np.isclose(y2[0, 0], float(f["best_val"]), rtol=1e-5)
