@@ -136,37 +136,50 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
 
     for (int i0 = 0; i0 < n; i0 += kRB) {
         const int nst = i0 / kKB;
+        // Regular stages, software-pipelined ACROSS the stage barrier: the MFMAs of a stage's last k-step are
+        // issued after the next stage's barrier and first LDS reads, so barrier skew and the first read latency
+        // hide under 8 MFMAs (512 cycles) instead of draining the matrix pipe.
+        double af[2][kT], bf[2];
+        bool deferred = false;                // af[1]/bf[1] hold the previous stage's k-step 7, MFMAs not yet issued
         for (int j = 0; j < nst; ++j) {
+            // every LDS read this wave issued for the previous stage has returned: after the barrier other
+            // waves' DMA may overwrite that buffer
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             STAGE_TOP();
+            __builtin_amdgcn_sched_barrier(0);
             const int bnext = (buf >= 1) ? buf - 1 : 2;       // (buf + 2) % 3
             extra_prev = 0;
-            {
-                const double *abase = lds + buf * kABuf + kq * kLdsLd + lc;
-                const double *bbase = ldsB + buf * kBBuf + wave * (kKB * 16) + kq * 16 + lc;
-                double af[2][kT], bf[2];
+            const double *abase = lds + buf * kABuf + kq * kLdsLd + lc;
+            const double *bbase = ldsB + buf * kBBuf + wave * (kKB * 16) + kq * 16 + lc;
 #pragma unroll
-                for (int t = 0; t < kT; ++t) af[0][t] = abase[16 * t];
-                bf[0] = bbase[0];
-                SCHED_DS(kT + 1);
+            for (int t = 0; t < kT; ++t) af[0][t] = abase[16 * t];
+            bf[0] = bbase[0];
+            if (deferred) {
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    if (jj < 7) {
-#pragma unroll
-                        for (int t = 0; t < kT; ++t) af[(jj + 1) & 1][t] = abase[4 * (jj + 1) * kLdsLd + 16 * t];
-                        bf[(jj + 1) & 1] = bbase[4 * (jj + 1) * 16];
-                    }
-                    if (jj < 4) issue_part(ahead, bnext, jj);             // stage g+2's DMA rides under the MFMAs
-#pragma unroll
-                    for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[jj & 1][t], bf[jj & 1], acc[t]);
-                    // pin "LDS reads of step jj+1, DMA, then the MFMAs of step jj": reads and DMA issue complete
-                    // under the MFMAs
-                    if (jj < 7) { SCHED_DS(kT + 1); }
-                    if (jj < 4) { SCHED_VMEM(3); }
-                    SCHED_MFMA(kT);
-                }
+                for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jj = 0; jj < 7; ++jj) {
+#pragma unroll
+                for (int t = 0; t < kT; ++t) af[(jj + 1) & 1][t] = abase[4 * (jj + 1) * kLdsLd + 16 * t];
+                bf[(jj + 1) & 1] = bbase[4 * (jj + 1) * 16];
+                if (jj < 4) issue_part(ahead, bnext, jj);                 // stage g+2's DMA rides under the MFMAs
+#pragma unroll
+                for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[jj & 1][t], bf[jj & 1], acc[t]);
+                // pin "LDS reads of step jj+1, DMA, then the MFMAs of step jj": reads and DMA issue complete
+                // under the MFMAs
+                SCHED_DS(kT + 1);
+                if (jj < 4) { SCHED_VMEM(3); }
+                SCHED_MFMA(kT);
+            }
+            deferred = true;                                              // k-step 7 sits in af[1], bf[1]
             advance(ahead);
             buf = (buf == 2) ? 0 : buf + 1;
+        }
+        if (deferred) {
+#pragma unroll
+            for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
         }
 
         // ---- four diagonal stages: X_s = inv(L_ss) R_s, then R_t -= L_ts X_s for the tiles below
