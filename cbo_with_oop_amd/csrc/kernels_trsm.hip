@@ -36,6 +36,26 @@ constexpr int kNBuf = 3;                  // pipeline depth: DMA of stage s+2 is
 constexpr int kABuf = kKB * kLdsLd;       // doubles per U stage buffer
 constexpr int kBBuf = 4 * kKB * 16;       // doubles per V stage buffer (4 waves x [32 k][16 cols])
 constexpr int kDmaPerStage = 8 + 4;       // LDS-DMA instructions a wave issues per stage (8 U rows + 4 V pieces)
+#ifdef CBO_DIAG_KNOBS
+// Timing-only build: workgroup 0 / wave 0 stamps s_memtime around the barrier and at the end of every stage
+// (3 stamps per stage) into a debug buffer read back by cbo_diag_trsm_stamps (scripts/trsm_timeline.py).
+__device__ unsigned long long g_trsm_stamps[8 * 4096];
+#define STAMP(slot)                                                                          \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        if (stamp_on && stamp_i < 4096) g_trsm_stamps[8 * stamp_i + (slot)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    } while (0)
+#define STAMP_NEXT() do { if (stamp_on) ++stamp_i; } while (0)
+extern "C" int cbo_diag_trsm_stamps(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trsm_stamps), sizeof(unsigned long long) * (size_t)n);   // 8 per stage
+}
+#else
+#define STAMP(slot)
+#define STAMP_NEXT()
+#endif
+
 // One continuous software pipeline over "stages" of 32 U-rows.  Row block b (rows i0 = 128 b) consists
 // of nst = i0/32 regular stages (k rows [32 j, 32 j + 32) against the block's 128 columns) followed by four
 // diagonal stages (k rows i0 + 32 m: the block's own upper-triangular part).  Every stage's U tile
@@ -72,22 +92,29 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
 
     // Sources of the stage the cursor points at (scalar bookkeeping, done off the MFMA path).  A cursor past
     // the end is clamped to the last stage, whose buffer is free by then, so in-flight counts stay uniform.
+    // Branch-free on purpose (selects and masked arithmetic only): the cursor update sits in the middle of a
+    // regular stage's MFMA block, where the scheduler can only hide it if it stays in that basic block.
+    const double *inv_lane = invDt + lane * 2;
     auto locate = [&](StageCursor &c) __attribute__((always_inline)) {
         const bool past = c.i0 >= n;
         const int ai0 = past ? n - kRB : c.i0;
         const int aj = past ? (n - kRB) / kKB + 3 : c.j;
         const int nreg = ai0 / kKB;
         c.a_src = ug + (int64_t)(kKB * aj) * ldu + ai0;
-        if (aj >= nreg) {               // diagonal stage: the two 16x16 diagonal inverses go to the B region
-            c.b_src = invDt + ((int64_t)(ai0 / 16) + 2 * (aj - nreg)) * 256 + lane * 2;
-            c.b_stride = 128;
-        } else {                        // regular stage: V rows [32 aj, 32 aj + 32) of this wave's 16 columns
-            c.b_src = vg + (int64_t)(kKB * aj) * ldv;
-            c.b_stride = 8 * ldv;
-        }
+        // diagonal stage: the two 16x16 diagonal inverses go to the B region; regular stage: V rows
+        // [32 aj, 32 aj + 32) of this wave's 16 columns
+        const int64_t diag = (aj >= nreg) ? 1 : 0;
+        const int64_t off_diag = ((int64_t)(ai0 / 16) + 2 * (aj - nreg)) * 256;
+        const int64_t off_reg = (int64_t)(kKB * aj) * ldv;
+        const uintptr_t base = (uintptr_t)vg + ((uintptr_t)inv_lane - (uintptr_t)vg) * (uintptr_t)diag;
+        c.b_src = reinterpret_cast<const double *>(base) + (off_reg + (off_diag - off_reg) * diag);
+        c.b_stride = 8 * ldv + (128 - 8 * ldv) * diag;
     };
     auto advance = [&](StageCursor &c) __attribute__((always_inline)) {
-        if (++c.j == c.lim) { c.i0 += kRB; c.j = 0; c.lim = c.i0 / kKB + 4; }
+        const int wrap = (c.j + 1 == c.lim) ? 1 : 0;
+        c.i0 += kRB * wrap;
+        c.j = (c.j + 1) * (1 - wrap);
+        c.lim = c.lim + (c.i0 / kKB + 4 - c.lim) * wrap;
         locate(c);
     };
     // the 12 LDS-DMA instructions of a stage, split so they can sit between MFMAs: pieces 0..3 -> 3 each
@@ -120,6 +147,10 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
     advance(ahead);
     issue_stage(ahead, 1);
     advance(ahead);
+#ifdef CBO_DIAG_KNOBS
+    const bool stamp_on = SWEEP && blockIdx.x == 0 && tid == 0;
+    int stamp_i = 0;
+#endif
     int buf = 0;                 // buffer of the current stage; stage g+2 goes to (buf + 2) % 3
     int extra_prev = 0;          // VMEM operations the previous stage issued after its DMA (its V stores)
     double qacc = 0.0, macc = 0.0;
@@ -144,8 +175,11 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
         for (int j = 0; j < nst; ++j) {
             // every LDS read this wave issued for the previous stage has returned: after the barrier other
             // waves' DMA may overwrite that buffer
+            STAMP(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            STAMP(3);
             STAGE_TOP();
+            STAMP(1);
             __builtin_amdgcn_sched_barrier(0);
             const int bnext = (buf >= 1) ? buf - 1 : 2;       // (buf + 2) % 3
             extra_prev = 0;
@@ -159,12 +193,14 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
                 for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
             }
             __builtin_amdgcn_sched_barrier(0);
+            STAMP(4);
 #pragma unroll
             for (int jj = 0; jj < 7; ++jj) {
 #pragma unroll
                 for (int t = 0; t < kT; ++t) af[(jj + 1) & 1][t] = abase[4 * (jj + 1) * kLdsLd + 16 * t];
                 bf[(jj + 1) & 1] = bbase[4 * (jj + 1) * 16];
                 if (jj < 4) issue_part(ahead, bnext, jj);                 // stage g+2's DMA rides under the MFMAs
+                if (jj == 4) advance(ahead);                              // cursor bookkeeping under the MFMAs too
 #pragma unroll
                 for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[jj & 1][t], bf[jj & 1], acc[t]);
                 // pin "LDS reads of step jj+1, DMA, then the MFMAs of step jj": reads and DMA issue complete
@@ -174,7 +210,8 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
                 SCHED_MFMA(kT);
             }
             deferred = true;                                              // k-step 7 sits in af[1], bf[1]
-            advance(ahead);
+            STAMP(2);
+            STAMP_NEXT();
             buf = (buf == 2) ? 0 : buf + 1;
         }
         if (deferred) {
@@ -185,7 +222,9 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
         // ---- four diagonal stages: X_s = inv(L_ss) R_s, then R_t -= L_ts X_s for the tiles below
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
+            STAMP(0);
             STAGE_TOP();
+            STAMP(1);
             if (m == 0 && i0 + kRB < n) {
                 // next block's right-hand sides (K* rows) -- issued before this stage's DMA so that the
                 // DMA waits further down never have to cover them early
@@ -231,6 +270,8 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
                 }
             }
             extra_prev = 1;
+            STAMP(2);
+            STAMP_NEXT();
             buf = (buf == 2) ? 0 : buf + 1;
         }
 #pragma unroll
