@@ -205,7 +205,20 @@ class HipGaussianProcess:
         return res
 
     def get_prediction_gradients(self, x):
-        raise NotImplementedError("prediction gradients (SURVEY.md §8 f3) are not part of the grid-sweep path")
+        """emukit ``GPyModelWrapper.get_prediction_gradients`` -> GPy ``predictive_gradients``:
+        (d mean / d x (M,d), d var / d x (M,d)).  As in GPy, the mean function's and the causal rank-1 term's own
+        gradients are not included.  One backward triangular solve per point: meant for the few
+        points of a local refinement, not for grids."""
+        x = _lib.as_f64(x)
+        if x.ndim != 2 or x.shape[1] != self.input_dim:
+            raise ValueError(f"x must be (M, {self.input_dim})")
+        m = x.shape[0]
+        pv = _column(self.variance_adjustment(x), m, "variance_adjustment") if self.causal else None
+        dmean = np.empty((m, self.input_dim))
+        dvar = np.empty((m, self.input_dim))
+        _lib.check(self._lib.cbo_gp_predict_gradients(self._handle, m, _lib.dptr(x), _lib.dptr(pv), _lib.dptr(dmean),
+                                                      _lib.dptr(dvar)))
+        return dmean, dvar
 
     # -- posterior state (GPy: model.posterior.woodbury_chol / woodbury_vector) -------------------
     def posterior_state(self):

@@ -724,6 +724,55 @@ extern "C" int cbo_gp_log_marginal(cbo_gp *g, double *lml_out)
     return CBO_OK;
 }
 
+extern "C" int cbo_gp_predict_gradients(cbo_gp *g, int64_t m, const double *Xs, const double *pv_s, double *dmean_out,
+                                        double *dvar_out)
+{
+    if (!g || !Xs || !dmean_out || !dvar_out) return fail(CBO_ERR_INVALID, "NULL argument");
+    if (m <= 0 || m > 4096) return fail(CBO_ERR_INVALID, "m must be in [1, 4096] (one backward solve per point)");
+    if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
+    cbo_ctx *c = g->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const bool causal = g->X.sv != nullptr;
+    if (causal && !pv_s) return fail(CBO_ERR_INVALID, "causal gp needs the prior variance at the prediction points");
+    // the prior mean does not enter the gradients (GPy ignores the mean function there); zeros stand in
+    std::vector<double> zeros;
+    if (causal) zeros.assign((size_t)m, 0.0);
+    cbo_cands *k = nullptr;
+    int rc = cbo_cands_create(c, m, g->d, Xs, causal ? zeros.data() : nullptr, causal ? pv_s : nullptr, 0, &k);
+    if (rc != CBO_OK) return rc;
+    double *W = nullptr, *work = nullptr, *grads = nullptr, *inv_ls = nullptr;
+    auto cleanup = [&]() { hipFree(W); hipFree(work); hipFree(grads); hipFree(inv_ls); cbo_cands_destroy(k); };
+    rc = ensure_alpha(g);
+    if (rc == CBO_OK) rc = enqueue_posterior(g, k);            // V = L^-1 K*
+    int64_t chunk = 0, ldv = 0;
+    if (rc == CBO_OK) rc = ensure_workspaces(c, g->n_pad, k->m_pad, &chunk, &ldv);
+    if (rc == CBO_OK && chunk < k->m_pad) rc = fail(CBO_ERR_INVALID, "too many points for one workspace chunk");
+    if (rc != CBO_OK) { cleanup(); return rc; }
+    hipError_t e = hipMalloc(&W, sizeof(double) * (size_t)m * g->n_pad);
+    if (e == hipSuccess) e = hipMalloc(&work, sizeof(double) * g->n_pad);
+    if (e == hipSuccess) e = hipMalloc(&grads, sizeof(double) * 2 * (size_t)m * g->d);
+    if (e == hipSuccess && g->h.ard) {
+        std::vector<double> il(g->d);
+        for (int i = 0; i < g->d; ++i) il[i] = 1.0 / g->ls[i];
+        e = hipMalloc(&inv_ls, sizeof(double) * g->d);
+        if (e == hipSuccess) e = hipMemcpyAsync(inv_ls, il.data(), sizeof(double) * g->d, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess) {
+        // w_c = L^-T (L^-1 k*_c) = Ky^-1 k*_c, one backward solve per point
+        for (int64_t col = 0; col < m; ++col)
+            launch_backsolve_vec(c->stream, g->A, g->lda, g->n_pad, g->invDt, c->V + col, ldv, work, W + col * g->n_pad);
+        launch_pred_gradients(c->stream, g->X, k->P, m, g->h, inv_ls, g->alpha, W, g->n_pad, grads, grads + m * g->d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(dmean_out, grads, sizeof(double) * m * g->d, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dvar_out, grads + m * g->d, sizeof(double) * m * g->d, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(CBO_ERR_HIP, std::string("cbo_gp_predict_gradients: ") + hipGetErrorString(e));
+    return CBO_OK;
+}
+
 extern "C" int cbo_gp_predict_grouped(cbo_gp *g, int64_t m_groups, int64_t group, const double *Xs, const double *pm,
                                       const double *pv, int include_noise, double *mean_out, double *var_out)
 {

@@ -88,6 +88,13 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
                      int64_t n_pad, double *invDt, int *info_dev);
 // alpha = U^-1 z  (z = first rhs column of A).
 void launch_backsolve(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt, double *alpha);
+void launch_backsolve_vec(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt,
+                          const double *src, int64_t src_stride, double *work, double *out);
+// Gradients of the posterior mean and variance w.r.t. the prediction inputs (GPy predictive_gradients):
+// dmean[c][k] = sum_i alpha_i dk(x_i, x*_c)/dx*_k, dvar[c][k] = -2 sum_i W[c][i] dk(x_i, x*_c)/dx*_k (RBF part only).
+void launch_pred_gradients(hipStream_t s, const PointSet &X, const PointSet &C, int64_t m, const KernelHyper &h,
+                           const double *inv_ls_dev /* d values: 1/l per dim */, const double *alpha, const double *W,
+                           int64_t ldw, double *dmean, double *dvar);
 
 // V <- L^-1 V on m_pad columns (64-column strips); optional q[c] = sum_i V[i][c]^2, mu[c] = sum_i V[i][c] z[i].
 void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const double *invDt, double *V, int64_t ldv,

@@ -139,6 +139,78 @@ void launch_group_mean(hipStream_t s, const double *in, int64_t n_groups, int64_
     hipLaunchKernelGGL(group_mean_kernel, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, s, in, n_groups, group, out);
 }
 
+// Prediction gradients (GPy GP.predictive_gradients as reached through emukit's
+// get_prediction_gradients, /root/reference/src/utils_functions/causal_acquisition_functions.py:54):
+//   dk(x_i, x*)/dx*_k = k(x_i, x*) (x_ik - x*_k) / l_k^2      (stationary RBF part; GPy's Stationary.gradients_X,
+//   which CausalRBF inherits, ignores the rank-1 causal term -- SURVEY.md §A.2)
+// One workgroup per prediction point, threads stride over the observations, block reduction per dimension.
+// Coordinates are the (ARD-)scaled SoA copies: u = x / l, so dk/dx*_k = k (u_ik - u*_k) * inv_l_k.
+__global__ __launch_bounds__(256) void pred_gradients_kernel(const double *__restrict__ xs, int64_t ldx, int64_t n,
+                                                             const double *__restrict__ cs, int64_t ldc, int d,
+                                                             double variance, double iso_inv_l,
+                                                             const double *__restrict__ inv_ls,
+                                                             const double *__restrict__ alpha,
+                                                             const double *__restrict__ W, int64_t ldw,
+                                                             double *__restrict__ dmean, double *__restrict__ dvar)
+{
+    __shared__ double red[2 * CBO_MAX_DIM][256];
+    const int64_t c = blockIdx.x;
+    const int tid = threadIdx.x;
+    double xc[CBO_MAX_DIM], gm[CBO_MAX_DIM], gv[CBO_MAX_DIM];
+#pragma unroll
+    for (int k = 0; k < CBO_MAX_DIM; ++k) {
+        xc[k] = (k < d) ? cs[(int64_t)k * ldc + c] : 0.0;
+        gm[k] = 0.0;
+        gv[k] = 0.0;
+    }
+    const double *w = W + c * ldw;
+    for (int64_t i = tid; i < n; i += 256) {
+        double diff[CBO_MAX_DIM];
+        double r2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < CBO_MAX_DIM; ++k) {
+            diff[k] = (k < d) ? (xs[(int64_t)k * ldx + i] - xc[k]) * iso_inv_l : 0.0;   // scaled difference
+            r2 += diff[k] * diff[k];
+        }
+        const double kv = variance * exp(-0.5 * r2);
+        const double a = alpha[i] * kv, b = w[i] * kv;
+#pragma unroll
+        for (int k = 0; k < CBO_MAX_DIM; ++k) {
+            const double g = diff[k] * (inv_ls ? inv_ls[k] : iso_inv_l);
+            gm[k] += a * g;
+            gv[k] += b * g;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CBO_MAX_DIM; ++k) {
+        red[k][tid] = gm[k];
+        red[CBO_MAX_DIM + k][tid] = gv[k];
+    }
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) {
+#pragma unroll
+            for (int k = 0; k < 2 * CBO_MAX_DIM; ++k) red[k][tid] += red[k][tid + st];
+        }
+        __syncthreads();
+    }
+    if (tid < d) {
+        dmean[c * d + tid] = red[tid][0];
+        dvar[c * d + tid] = -2.0 * red[CBO_MAX_DIM + tid][0];
+    }
+}
+
+void launch_pred_gradients(hipStream_t s, const PointSet &X, const PointSet &C, int64_t m, const KernelHyper &h,
+                           const double *inv_ls_dev, const double *alpha, const double *W, int64_t ldw, double *dmean,
+                           double *dvar)
+{
+    // ARD: coordinates are already divided by l_k (iso factor 1, per-dimension 1/l_k for the chain rule);
+    // isotropic: raw coordinates, one 1/l for both
+    const double iso = h.ard ? 1.0 : 1.0 / h.lengthscale;
+    hipLaunchKernelGGL(pred_gradients_kernel, dim3((unsigned)m), dim3(256), 0, s, X.xs, X.ld, X.n, C.xs, C.ld, X.d,
+                       h.variance, iso, h.ard ? inv_ls_dev : nullptr, alpha, W, ldw, dmean, dvar);
+}
+
 int acq_blocks_for(int64_t m)
 {
     int64_t b = (m + 255) / 256;

@@ -485,12 +485,18 @@ __global__ void copy_strided_kernel(const double *__restrict__ src, int64_t stri
 // The caller provides alpha with 2*n_pad doubles: [0, n_pad) result, [n_pad, 2 n_pad) working copy of z.
 void launch_backsolve(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt, double *alpha)
 {
-    double *zt = alpha + n_pad;
-    hipLaunchKernelGGL(copy_strided_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, A + n_pad, lda,
-                       n_pad, zt);
+    launch_backsolve_vec(s, A, lda, n_pad, invDt, A + n_pad, lda, alpha + n_pad, alpha);
+}
+
+// out = U^-1 src for one strided vector (src is left untouched; work is an n_pad scratch vector).
+void launch_backsolve_vec(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt,
+                          const double *src, int64_t src_stride, double *work, double *out)
+{
+    hipLaunchKernelGGL(copy_strided_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, src, src_stride,
+                       n_pad, work);
     const int nb = (int)(n_pad / 128);
     for (int blk = nb - 1; blk >= 0; --blk)
-        hipLaunchKernelGGL(backsolve_step_kernel, dim3(blk + 1), dim3(256), 0, s, A, lda, invDt, blk, zt, alpha);
+        hipLaunchKernelGGL(backsolve_step_kernel, dim3(blk + 1), dim3(256), 0, s, A, lda, invDt, blk, work, out);
 }
 
 }  // namespace cbo

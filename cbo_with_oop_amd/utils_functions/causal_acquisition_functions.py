@@ -87,14 +87,33 @@ class CausalExpectedImprovement:
         """(M,1) improvement, as the reference's ``evaluate`` (:27-43)."""
         return self.sweep(x, cost=1.0, want_acq=True)["acq"]
 
+    @property
+    def has_gradients(self):
+        return True
+
+    def evaluate_with_gradients(self, x):
+        """(improvement (M,1), d improvement / d x (M,d)) as the reference's ``evaluate_with_gradients``
+        (:45-67).  Posterior and its gradients come from the device; the closing arithmetic on M (a few) points is
+        host numpy, scipy's normal pdf/cdf as in the reference (:77-88)."""
+        import scipy.stats
+        x = _lib.as_f64(x)
+        mean, variance = self.model.predict(x)
+        standard_deviation = np.sqrt(variance)
+        dmean_dx, dvariance_dx = self.model.get_prediction_gradients(x)
+        dstandard_deviation_dx = dvariance_dx / (2 * standard_deviation)
+        mean = mean + self.jitter
+        u = (np.asarray(self.current_global_min, dtype=np.float64).reshape(-1)[0] - mean) / standard_deviation
+        pdf, cdf = scipy.stats.norm.pdf(u), scipy.stats.norm.cdf(u)
+        improvement = standard_deviation * (u * cdf + pdf)
+        dimprovement_dx = dstandard_deviation_dx * pdf - cdf * dmean_dx
+        if self.task == 'min':
+            return improvement, dimprovement_dx
+        return -improvement, -dimprovement_dx
+
     def __truediv__(self, cost):
         """``CausalExpectedImprovement(...) / Cost(...)`` as in src/utils_functions/utils.py:34 (emukit's
         ``Acquisition.__truediv__`` builds a Quotient there)."""
         return AcquisitionQuotient(self, cost)
-
-    @property
-    def has_gradients(self):
-        return False
 
 
 class AcquisitionQuotient:
@@ -115,6 +134,13 @@ class AcquisitionQuotient:
     def evaluate(self, x):
         return self.sweep(x, want_acq=True)["acq"]
 
+    def evaluate_with_gradients(self, x):
+        """Quotient rule with the reference's zero cost gradient (cost_functions.py:23-24)."""
+        x = _lib.as_f64(x)
+        f, df = self.numerator.evaluate_with_gradients(x)
+        c = float(self.denominator.evaluate(x))
+        return f / c, df / c
+
     @property
     def has_gradients(self):
-        return False
+        return True

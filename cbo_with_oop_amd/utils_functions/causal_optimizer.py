@@ -28,7 +28,19 @@ class CausalGradientAcquisitionOptimizer:
     def candidates(self):
         return meshgrid_candidates(self.bounds, self.grid_shape)
 
-    def optimize(self, acquisition, context=None):
+    def refine(self, acquisition, x0):
+        """The reference's second stage (causal_optimizer.py:59-65; emukit OptLbfgs = scipy fmin_l_bfgs_b with
+        bounds and maxfun=1000, minimising -acquisition with its gradient) started from ``x0`` ((1,d))."""
+        from scipy.optimize import fmin_l_bfgs_b
+
+        def f_df(v):
+            f, df = acquisition.evaluate_with_gradients(v[None, :])
+            return -float(f[0, 0]), -df[0]
+
+        x, fx, _ = fmin_l_bfgs_b(f_df, np.asarray(x0, dtype=np.float64).reshape(-1), bounds=self.bounds, maxfun=1000)
+        return x[None, :], np.array([[-fx]])
+
+    def optimize(self, acquisition, context=None, refine=False):
         """(x_max (1,d), acquisition value at x_max (1,1)) -- emukit ``AcquisitionOptimizerBase.optimize``.
         ``acquisition`` is ``CausalExpectedImprovement(...) / Cost(...)`` (an ``AcquisitionQuotient``) or a bare
         ``CausalExpectedImprovement``."""
@@ -39,4 +51,9 @@ class CausalGradientAcquisitionOptimizer:
         finally:
             grid.close()
         x = pts[res["best_idx"]][None, :].copy()
-        return x, np.array([[res["best_val"]]])
+        fx = np.array([[res["best_val"]]])
+        if refine:
+            xr, fr = self.refine(acquisition, x)
+            if fr[0, 0] >= fx[0, 0]:
+                x, fx = xr, fr
+        return x, fx

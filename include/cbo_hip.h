@@ -110,6 +110,17 @@ int cbo_gp_predict(cbo_gp *gp, int64_t m, const double *Xs, const double *prior_
 int cbo_gp_set_hyper(cbo_gp *gp, double variance, const double *lengthscale, double noise_var);
 int cbo_gp_log_marginal(cbo_gp *gp, double *lml_out);
 
+/* Prediction gradients: emukit GPyModelWrapper.get_prediction_gradients -> GPy
+ * predictive_gradients, called from CausalExpectedImprovement.evaluate_with_gradients
+ * (src/utils_functions/causal_acquisition_functions.py:54) inside the L-BFGS refinement of
+ * src/utils_functions/causal_optimizer.py:59-65.  dmean_out / dvar_out: m*d row-major,
+ * d mean / d x and d var / d x.  For the causal kernel GPy differentiates the stationary part only, but the
+ * solve Ky^-1 k*(x) behind the variance gradient uses the full kernel, hence prior_var_s = variance_adjustment(Xs)
+ * (NULL for the non-causal kernel).  Meant for a handful of points (the refinement of the best grid candidates): the variance gradient needs
+ * one backward triangular solve per point. */
+int cbo_gp_predict_gradients(cbo_gp *gp, int64_t m, const double *Xs, const double *prior_var_s,
+                             double *dmean_out, double *dvar_out);
+
 /* Do-calculus prior (src/DoCalculus.py:34-89): predict at m_groups * group points and
  * average the predictive mean and variance over each consecutive run of `group` rows -- one run per
  * candidate intervention, its rows being the observed inputs with the intervened columns overwritten

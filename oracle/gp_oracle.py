@@ -233,6 +233,37 @@ def optimize_hyperparameters(X, y, mX=None, vX=None, variance=REF_VARIANCE, leng
     return float(v), np.atleast_1d(l), float(nz), -f(best)
 
 
+def predict_gradients(post, Xs, vXs=None):
+    """GPy ``GP.predictive_gradients`` as reached through emukit's ``get_prediction_gradients``
+    (src/utils_functions/causal_acquisition_functions.py:54): dmu/dx = gradients_X(alpha^T, Xnew, X) and
+    dvar/dx = gradients_X(-2 (Ky^-1 Kx)^T, Xnew, X), with Stationary.gradients_X using only the stationary
+    part dK/dx* = K_rbf (x_i - x*) / l^2 (the causal rank-1 term and the mean function are not differentiated,
+    SURVEY.md §A.2).  Returns (dmean (M,d), dvar (M,d))."""
+    Xs = np.ascontiguousarray(Xs, dtype=np.float64)
+    ls = np.atleast_1d(np.asarray(post.lengthscale, dtype=np.float64))
+    Krbf = rbf_K(post.X, Xs, post.variance, post.lengthscale)                      # (N, M)
+    Kx = causal_K(post.X, Xs, post.vX, vXs if post.vX is not None else None, post.variance, post.lengthscale)
+    W, info = lapack.dpotrs(post.L, Kx, lower=1)                                    # Ky^-1 Kx
+    diff = (post.X[:, None, :] - Xs[None, :, :]) / (ls ** 2)                        # (N, M, d)
+    dmean = np.einsum("n,nm,nmd->md", post.alpha[:, 0], Krbf, diff)
+    dvar = -2.0 * np.einsum("nm,nm,nmd->md", W, Krbf, diff)
+    return dmean, dvar
+
+
+def expected_improvement_with_gradients(post, Xs, y_best, mXs=None, vXs=None, task="min", jitter=0.0):
+    """CausalExpectedImprovement.evaluate_with_gradients
+    (src/utils_functions/causal_acquisition_functions.py:45-67)."""
+    mean, variance = predict(post, Xs, mXs, vXs)
+    s = np.sqrt(variance)
+    dmean_dx, dvariance_dx = predict_gradients(post, Xs, vXs)
+    ds_dx = dvariance_dx / (2 * s)
+    mean = mean + jitter
+    u, pdf, cdf = standard_normal_pdf_cdf(y_best, mean, s)
+    imp = s * (u * cdf + pdf)
+    dimp = ds_dx * pdf - cdf * dmean_dx
+    return (imp, dimp) if task == "min" else (-imp, -dimp)
+
+
 # --------------------------------------------------------------------------- acquisition
 def standard_normal_pdf_cdf(x, mean, standard_deviation):
     """src/utils_functions/causal_acquisition_functions.py:77-88."""

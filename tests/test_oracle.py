@@ -140,3 +140,23 @@ def test_fixture_generator_is_committed_and_reference_free_at_runtime():
                 if fn.endswith((".py", ".hip", ".h", ".c")):
                     text = open(os.path.join(dirpath, fn)).read()
                     assert "open('/root/reference" not in text and 'np.load("/root/reference' not in text
+
+
+def test_prediction_and_ei_gradients_against_finite_differences():
+    rng = np.random.default_rng(3)
+    X = rng.uniform(-2, 2, (25, 2))
+    y = np.sin(X[:, :1]) + 0.3 * X[:, 1:] + 0.05 * rng.standard_normal((25, 1))
+    post = O.fit(X, y, variance=1.3, lengthscale=np.array([0.8, 1.4]), noise_var=1e-3)
+    xs = rng.uniform(-2, 2, (4, 2))
+    dm, dv = O.predict_gradients(post, xs)
+    ei, dei = O.expected_improvement_with_gradients(post, xs, float(y.min()))
+    h = 1e-6
+    for k in range(2):
+        e = np.zeros(2); e[k] = h
+        mp, vp = O.predict(post, xs + e)
+        mm, vm = O.predict(post, xs - e)
+        assert np.allclose((mp - mm)[:, 0] / (2 * h), dm[:, k], rtol=1e-5, atol=1e-7)
+        assert np.allclose((vp - vm)[:, 0] / (2 * h), dv[:, k], rtol=1e-4, atol=1e-7)
+        ep, _ = O.expected_improvement_with_gradients(post, xs + e, float(y.min()))
+        em, _ = O.expected_improvement_with_gradients(post, xs - e, float(y.min()))
+        assert np.allclose((ep - em)[:, 0] / (2 * h), dei[:, k], rtol=1e-4, atol=1e-8)

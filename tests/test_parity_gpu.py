@@ -546,3 +546,47 @@ def test_optimizer_class_and_quotient_mirror_the_reference_call_sequence(hip):
     y2, x2 = find_next_y_point(space, model, float(f["y_best"]), ["Z"], costs, grid_shape=[200])
     assert np.array_equal(x_new, x2) and np.array_equal(x_new[0], f["Xs"][int(f["best_idx"])])
     assert np.allclose(y_acquisition, y2, rtol=1e-14) and np.isclose(y2[0, 0], float(f["best_val"]), rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------- gradients + refinement (f3)
+def test_prediction_gradients_and_refinement(hip):
+    """get_prediction_gradients / evaluate_with_gradients against the oracle, then the reference's second
+    optimiser stage (L-BFGS from the best grid point) with the same scipy call on both sides."""
+    from scipy.optimize import fmin_l_bfgs_b
+    from cbo_with_oop_amd.utils_functions import CausalExpectedImprovement, CausalGradientAcquisitionOptimizer, Cost
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    from cbo_with_oop_amd.graphs import CompleteGraph
+    rng = np.random.default_rng(21)
+    X = rng.uniform([-5, -5], [4, 5], (150, 2))
+    y = np.sin(X[:, :1]) + 0.1 * X[:, 1:] ** 2 + 0.05 * rng.standard_normal((150, 1))
+    m = HipGaussianProcess(X, y, variance=1.2, lengthscale=1.1, noise_var=1e-3)
+    post = O.fit(X, y, variance=1.2, lengthscale=1.1, noise_var=1e-3)
+    xs = rng.uniform([-5, -5], [4, 5], (9, 2))
+    dm, dv = m.get_prediction_gradients(xs)
+    dmo, dvo = O.predict_gradients(post, xs)
+    assert np.allclose(dm, dmo, rtol=1e-7, atol=1e-9) and np.allclose(dv, dvo, rtol=1e-6, atol=1e-9)
+    ei = CausalExpectedImprovement(float(y.min()), "min", m)
+    f, df = ei.evaluate_with_gradients(xs)
+    fo, dfo = O.expected_improvement_with_gradients(post, xs, float(y.min()))
+    assert np.allclose(f, fo, rtol=1e-6, atol=1e-12) and np.allclose(df, dfo, rtol=1e-5, atol=1e-10)
+    # ARD + causal kernel: gradients use the stationary part only, the solve uses the full kernel
+    c = load_fixture("causal_d2")
+    g = make_model(hip, c)
+    pts = c["Xs"][:5]
+    dm, dv = g.get_prediction_gradients(pts)
+    cpost = O.fit(c["X"], c["y"], c["mX"], c["vX"])
+    dmo, dvo = O.predict_gradients(cpost, pts, c["vXs"][:5])
+    assert np.allclose(dm, dmo, rtol=1e-6, atol=1e-9) and np.allclose(dv, dvo, rtol=1e-5, atol=1e-9)
+    # refinement: grid arg-max, then L-BFGS-B within the bounds
+    bounds = CompleteGraph.bounds(["B", "D"])
+    opt = CausalGradientAcquisitionOptimizer(bounds, grid_shape=[24, 24])
+    acq = ei / Cost(CompleteGraph.get_cost_structure(1), ["B", "D"])
+    x0, f0 = opt.optimize(acq)
+    x1, f1 = opt.optimize(acq, refine=True)
+    assert f1[0, 0] >= f0[0, 0] and all(lo <= v <= hi for v, (lo, hi) in zip(x1[0], bounds))
+
+    def f_df(v):
+        fv, dfv = O.expected_improvement_with_gradients(post, v[None, :], float(y.min()))
+        return -float(fv[0, 0]) / 2.0, -dfv[0] / 2.0
+    xo, fxo, _ = fmin_l_bfgs_b(f_df, x0[0], bounds=bounds, maxfun=1000)
+    assert np.isclose(f1[0, 0], -fxo, rtol=1e-5) and np.allclose(x1[0], xo, atol=1e-4)
