@@ -97,7 +97,7 @@ static hipEvent_t get_event(cbo_ctx *c)
         return e;
     }
     hipEvent_t e;
-    hipEventCreate(&e);
+    hipEventCreateWithFlags(&e, hipEventDisableSystemFence);   // device-scope ordering is all the stream needs
     return e;
 }
 

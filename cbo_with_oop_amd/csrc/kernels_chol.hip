@@ -376,7 +376,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     const int np = (int)(n_pad / 128);
     while ((int)events.size() < 2 * np + 2) {
         hipEvent_t e;
-        hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence);
         events.push_back(e);
     }
     // the side stream starts after everything queued on the main stream so far (K assembly, rhs)
