@@ -247,12 +247,29 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
             advance(ahead);
             const double *abase = lds + buf * kABuf + kq * kLdsLd + lc;
             const double *ibase = ldsB + buf * kBBuf + wave * (kKB * 16) + kq * 16 + lc;
+            // every LDS operand of the stage is fetched up front: the X_s / update chain below is a string of
+            // dependent MFMAs and must not wait for an LDS read in between
+            double iv[2][4], uf[2][kT][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) iv[h][kk] = ibase[h * 256 + 64 * kk];
+#pragma unroll
+                for (int t = 2 * m + h + 1; t < kT; ++t)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) uf[h][t][kk] = abase[(16 * h + 4 * kk) * kLdsLd + 16 * t];
+            }
+            asm volatile("" ::: "memory");                    // keep the reads ahead of the chain
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int s = 2 * m + h;
-                d4 x = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) x = MFMA_F64(ibase[h * 256 + 64 * kk], -acc[s][kk], x);
+                // two independent half-sums: a chain of dependent f64 MFMAs runs at about half the issue rate
+                d4 x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
+                x = MFMA_F64(iv[h][0], -acc[s][0], x);
+                x2 = MFMA_F64(iv[h][1], -acc[s][1], x2);
+                x = MFMA_F64(iv[h][2], -acc[s][2], x);
+                x2 = MFMA_F64(iv[h][3], -acc[s][3], x2);
+                x += x2;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = i0 + 16 * s + kq + 4 * r;
@@ -262,11 +279,11 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
                         macc = fma(x[r], zr[h][r], macc);
                     }
                 }
+                // k-major order: consecutive MFMAs go to different accumulators (no dependent back-to-back issue)
 #pragma unroll
-                for (int t = s + 1; t < kT; ++t) {
+                for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-                        acc[t] = MFMA_F64(abase[(16 * h + 4 * kk) * kLdsLd + 16 * t], x[kk], acc[t]);
+                    for (int t = s + 1; t < kT; ++t) acc[t] = MFMA_F64(uf[h][t][kk], x[kk], acc[t]);
                 }
             }
             extra_prev = 1;
