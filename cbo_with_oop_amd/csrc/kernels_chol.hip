@@ -214,17 +214,29 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t l
                 for (int k = 0; k < 16; ++k) s = fma(-sh.S[o + k][r], sh.rz[o + k], s);
                 sh.rz[r] = s;
             }
+            // rows o .. o+15 of the factor are final: write them out now, off the critical path of wave 0
+            for (int idx = t; idx < 16 * 64; idx += 192) {
+                const int i = o + (idx >> 6), j2 = (idx & 63) * 2;
+                if (j2 + 1 >= i) {
+                    d2 v;
+                    v[0] = (j2 >= i) ? sh.S[i][j2] : 0.0;
+                    v[1] = sh.S[i][j2 + 1];
+                    *reinterpret_cast<d2 *>(&A[(int64_t)(r0 + i) * lda + r0 + j2]) = v;
+                }
+            }
         }
         __syncthreads();
     }
 
-    // ---- outputs: factor (upper, zero below), z, and inv(U_bb) for the eight 16x16 diagonal tiles
-    for (int idx = tid; idx < 128 * 64 && !DBG_SKIP(16); idx += 256) {
-        const int i = idx >> 6, j2 = (idx & 63) * 2;
-        d2 v;
-        v[0] = (j2 >= i) ? sh.S[i][j2] : 0.0;
-        v[1] = (j2 + 1 >= i) ? sh.S[i][j2 + 1] : 0.0;
-        *reinterpret_cast<d2 *>(&A[(int64_t)(r0 + i) * lda + r0 + j2]) = v;
+    // ---- outputs: the last 16 rows of the factor (the others left during the loop) and z
+    for (int idx = tid; idx < 16 * 64 && !DBG_SKIP(16); idx += 256) {
+        const int i = 112 + (idx >> 6), j2 = (idx & 63) * 2;
+        if (j2 + 1 >= i) {
+            d2 v;
+            v[0] = (j2 >= i) ? sh.S[i][j2] : 0.0;
+            v[1] = sh.S[i][j2 + 1];
+            *reinterpret_cast<d2 *>(&A[(int64_t)(r0 + i) * lda + r0 + j2]) = v;
+        }
     }
     if (tid < 128) A[(int64_t)(r0 + tid) * lda + rcol] = sh.rz[tid];
 }
