@@ -39,6 +39,19 @@ class CboTimers(ctypes.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+SEM_MAX_NODES = 16
+SEM_MAX_TERMS = 64
+SEM_FN_CODE = {"id": 0, "square": 1, "exp": 2, "cos": 3, "sin": 4}
+
+
+class CboSemSpec(ctypes.Structure):
+    """struct cbo_sem_spec of include/cbo_hip.h."""
+    _fields_ = [("n_nodes", ctypes.c_int), ("eps_index", ctypes.c_int * SEM_MAX_NODES),
+                ("term_begin", ctypes.c_int * (SEM_MAX_NODES + 1)), ("term_parent", ctypes.c_int * SEM_MAX_TERMS),
+                ("term_fn", ctypes.c_int * SEM_MAX_TERMS), ("term_a", ctypes.c_double * SEM_MAX_TERMS),
+                ("term_c", ctypes.c_double * SEM_MAX_TERMS)]
+
+
 class CboHipError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"libcbo_hip error {code}: {message}")
@@ -87,6 +100,11 @@ SIGNATURES = {
                                           c_double_p, c_double_p, c_int64_p]),
     "cbo_argmax_sets": (ctypes.c_int, [c_double_p, ctypes.c_int, c_int_p]),
     "cbo_argmax_pairs": (ctypes.c_int, [c_double_p, c_int64_p, ctypes.c_int, c_double_p, c_int64_p]),
+    "cbo_sem_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(CboSemSpec), ctypes.c_int64, ctypes.c_int,
+                                      c_double_p, c_void_pp]),
+    "cbo_sem_destroy": (None, [ctypes.c_void_p]),
+    "cbo_sem_target": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_int_p,
+                                      c_double_p, c_double_p]),
     "cbo_selftest_mfma": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
 }
 

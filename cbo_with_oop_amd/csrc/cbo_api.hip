@@ -838,6 +838,110 @@ extern "C" int cbo_argmax_pairs(const double *vals, const int64_t *idxs, int n, 
     return CBO_OK;
 }
 
+// ---- Monte-Carlo interventional target (f4) ----------------------------------------------------------
+struct cbo_sem {
+    cbo_ctx *ctx = nullptr;
+    cbo_sem_spec spec{};
+    int64_t n_draws = 0;
+    int n_eps = 0;
+    double *eps_cm = nullptr;        // n_eps x n_draws (column of the caller's matrix = contiguous run here)
+    // per-call workspaces, grown on demand
+    double *values = nullptr, *partial = nullptr, *mean = nullptr;
+    int *iv_nodes = nullptr;
+    int64_t cap_m = 0;
+    int cap_iv = 0;
+};
+
+static int check_sem_spec(const cbo_sem_spec *sp, int n_eps)
+{
+    if (sp->n_nodes < 1 || sp->n_nodes > CBO_SEM_MAX_NODES) return fail(CBO_ERR_INVALID, "sem: n_nodes out of range");
+    if (sp->term_begin[0] != 0) return fail(CBO_ERR_INVALID, "sem: term_begin[0] must be 0");
+    for (int k = 0; k < sp->n_nodes; ++k) {
+        if (sp->term_begin[k + 1] < sp->term_begin[k] || sp->term_begin[k + 1] > CBO_SEM_MAX_TERMS)
+            return fail(CBO_ERR_INVALID, "sem: term_begin must be non-decreasing and <= CBO_SEM_MAX_TERMS");
+        if (sp->eps_index[k] < -1 || sp->eps_index[k] >= n_eps)
+            return fail(CBO_ERR_INVALID, "sem: eps_index out of range");
+        for (int t = sp->term_begin[k]; t < sp->term_begin[k + 1]; ++t) {
+            if (sp->term_parent[t] < 0 || sp->term_parent[t] >= k)
+                return fail(CBO_ERR_INVALID, "sem: a term must read an earlier node (evaluation order)");
+            if (sp->term_fn[t] < CBO_FN_ID || sp->term_fn[t] > CBO_FN_SIN)
+                return fail(CBO_ERR_INVALID, "sem: unknown term function");
+        }
+    }
+    return CBO_OK;
+}
+
+extern "C" int cbo_sem_create(cbo_ctx *c, const cbo_sem_spec *spec, int64_t n_samples, int n_eps, const double *eps,
+                              cbo_sem **out)
+{
+    if (!c || !spec || !eps || !out) return fail(CBO_ERR_INVALID, "NULL argument");
+    if (n_samples <= 0 || n_eps < 1 || n_eps > CBO_SEM_MAX_NODES)
+        return fail(CBO_ERR_INVALID, "sem: n_samples must be positive and n_eps in [1, CBO_SEM_MAX_NODES]");
+    int rc = check_sem_spec(spec, n_eps);
+    if (rc != CBO_OK) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    cbo_sem *m = new cbo_sem();
+    m->ctx = c; m->spec = *spec; m->n_draws = n_samples; m->n_eps = n_eps;
+    std::vector<double> cm((size_t)n_samples * n_eps);
+    for (int64_t s = 0; s < n_samples; ++s)
+        for (int k = 0; k < n_eps; ++k) cm[(size_t)k * n_samples + s] = eps[s * n_eps + k];
+    hipError_t e = hipMalloc(&m->eps_cm, sizeof(double) * cm.size());
+    if (e == hipSuccess) e = hipMemcpy(m->eps_cm, cm.data(), sizeof(double) * cm.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        cbo_sem_destroy(m);
+        return fail(CBO_ERR_HIP, std::string("cbo_sem_create: ") + hipGetErrorString(e));
+    }
+    *out = m;
+    return CBO_OK;
+}
+
+extern "C" void cbo_sem_destroy(cbo_sem *m)
+{
+    if (!m) return;
+    hipSetDevice(m->ctx->device);
+    hipStreamSynchronize(m->ctx->stream);
+    hipFree(m->eps_cm); hipFree(m->values); hipFree(m->partial); hipFree(m->mean); hipFree(m->iv_nodes);
+    delete m;
+}
+
+extern "C" int cbo_sem_target(cbo_sem *m, int target, int64_t n_iv_sets, int n_iv, const int *iv_nodes,
+                              const double *values, double *mean_out)
+{
+    if (!m || !mean_out) return fail(CBO_ERR_INVALID, "NULL argument");
+    if (n_iv_sets <= 0) return fail(CBO_ERR_INVALID, "sem: m must be positive");
+    if (target < 0 || target >= m->spec.n_nodes) return fail(CBO_ERR_INVALID, "sem: target node out of range");
+    if (n_iv < 0 || n_iv > CBO_SEM_MAX_NODES) return fail(CBO_ERR_INVALID, "sem: n_iv out of range");
+    if (n_iv > 0 && (!iv_nodes || !values)) return fail(CBO_ERR_INVALID, "sem: intervention nodes/values missing");
+    for (int j = 0; j < n_iv; ++j)
+        if (iv_nodes[j] < 0 || iv_nodes[j] >= m->spec.n_nodes)
+            return fail(CBO_ERR_INVALID, "sem: intervened node out of range");
+    cbo_ctx *c = m->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const int nb = sem_partial_blocks(m->n_draws);
+    const int iv_cols = n_iv > 0 ? n_iv : 1;
+    if (n_iv_sets > m->cap_m || iv_cols > m->cap_iv) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(m->values); hipFree(m->partial); hipFree(m->mean); hipFree(m->iv_nodes);
+        m->values = m->partial = m->mean = nullptr; m->iv_nodes = nullptr; m->cap_m = 0; m->cap_iv = 0;
+        const int64_t cap = n_iv_sets > m->cap_m ? n_iv_sets : m->cap_m;
+        HIP_TRY(hipMalloc(&m->values, sizeof(double) * cap * CBO_SEM_MAX_NODES));
+        HIP_TRY(hipMalloc(&m->partial, sizeof(double) * cap * nb));
+        HIP_TRY(hipMalloc(&m->mean, sizeof(double) * cap));
+        HIP_TRY(hipMalloc(&m->iv_nodes, sizeof(int) * CBO_SEM_MAX_NODES));
+        m->cap_m = cap; m->cap_iv = CBO_SEM_MAX_NODES;
+    }
+    if (n_iv > 0) {
+        HIP_TRY(hipMemcpyAsync(m->values, values, sizeof(double) * n_iv_sets * n_iv, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(m->iv_nodes, iv_nodes, sizeof(int) * n_iv, hipMemcpyHostToDevice, c->stream));
+    }
+    launch_sem_target(c->stream, m->spec, m->eps_cm, m->n_draws, target, n_iv_sets, n_iv, iv_nodes, m->iv_nodes, m->values,
+                      m->partial, m->mean);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(mean_out, m->mean, sizeof(double) * n_iv_sets, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CBO_OK;
+}
+
 extern "C" int cbo_selftest_mfma(cbo_ctx *c, double *max_abs_err_out)
 {
     if (!c) return fail(CBO_ERR_INVALID, "ctx is NULL");

@@ -122,4 +122,11 @@ void launch_export_sym(hipStream_t s, const double *A, int64_t lda, int64_t n, d
 
 int run_mfma_selftest(hipStream_t s, double *max_err);
 
+// Monte-Carlo target of an additive SEM: mean_out[i] = mean over draws of node `target` under intervention i.
+// partial: m * sem_partial_blocks(n_draws) doubles of workspace.
+int sem_partial_blocks(int64_t n_draws);
+void launch_sem_target(hipStream_t s, const cbo_sem_spec &spec, const double *eps_cm, int64_t n_draws, int target,
+                       int64_t m, int n_iv, const int *iv_nodes_host, const int *iv_nodes, const double *iv_values,
+                       double *partial, double *mean_out);
+
 }  // namespace cbo

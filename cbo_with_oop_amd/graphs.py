@@ -1,6 +1,8 @@
 """Problem tables the hot path needs from the reference's graph classes: exploration sets,
-interventional ranges and cost constants.  Only configuration data is restated here -- the SEMs,
-graph-level GP fits and Monte-Carlo targets of ``src/graphs/**`` are out of scope.
+interventional ranges and cost constants, plus the closed-form structural equation models in the
+additive form the device Monte-Carlo target takes.  The graph-level GP fits and the
+data-fitted SEMs of the coral graphs (sklearn regressors and mixtures fitted to SEM_data.mat,
+src/graphs/impl/CoralGraph.py:103-159) are out of scope.
 
 Citations are relative to /root/reference/.
 """
@@ -71,6 +73,23 @@ class CompleteGraph(_Graph):
     _mis = (("B",), ("D",), ("E",), ("B", "D"), ("B", "E"), ("D", "E"))
     _pomis = (("B",), ("D",), ("E",), ("B", "D"), ("D", "E"))
 
+    @staticmethod
+    def define_sem():
+        """src/graphs/impl/CompleteGraph.py:57-97 as an AdditiveSEM (same node order, same noise components).
+        ``/10.`` and ``/5.`` are written as multiplications by 0.1 and 0.2: at most one ulp per draw away from
+        the reference's divisions, far below the Monte-Carlo error of the mean."""
+        from .utils_functions.graph_functions import AdditiveSEM, Term as T
+        sem = AdditiveSEM()
+        sem.add("U1", eps=0).add("U2", eps=1).add("F", eps=8)
+        sem.add("A", [T("F", "square"), T("U1")], eps=2)
+        sem.add("B", [T("U2")], eps=3)
+        sem.add("C", [T("B", "exp", a=-1.0)], eps=4)
+        sem.add("D", [T("C", "exp", a=-1.0, c=0.1)], eps=5)
+        sem.add("E", [T("A", "cos"), T("C", c=0.1)], eps=6)
+        sem.add("Y", [T("D", "cos"), T("D", c=-0.2), T("E", "sin"), T("E", c=-0.25), T("U1"),
+                      T("U2", "exp", a=-1.0)], eps=7)
+        return sem
+
 
 class CoralGraph(_Graph):
     """src/graphs/impl/CoralGraph.py:162-184, 211-252."""
@@ -108,6 +127,17 @@ class ToyGraph(_Graph):
     _ranges = OrderedDict([("X", (-5, 5)), ("Z", (-5, 20))])
     _mis = (("X",), ("Z",))
     _pomis = (("Z",),)
+
+    @staticmethod
+    def define_sem():
+        """X = e0, Z = exp(-X) + e1, Y = cos(Z) - exp(-Z/20) + e2: the noisy form of the relations above
+        (upstream CBO's toy graph; not in the reference, see the class docstring)."""
+        from .utils_functions.graph_functions import AdditiveSEM, Term as T
+        sem = AdditiveSEM()
+        sem.add("X", eps=0)
+        sem.add("Z", [T("X", "exp", a=-1.0)], eps=1)
+        sem.add("Y", [T("Z", "cos"), T("Z", "exp", a=-0.05, c=-1.0)], eps=2)
+        return sem
 
     @staticmethod
     def target_do_z(z):

@@ -176,6 +176,40 @@ int cbo_argmax_sets(const double *ys, int s, int *idx_out);
 int cbo_argmax_pairs(const double *vals, const int64_t *idxs, int n, double *best_val,
                      int64_t *best_idx);
 
+/* ---- Monte-Carlo interventional target -----------------------------------------
+ * Replaces compute_interventions (src/utils_functions/graph_functions.py:48-77): the mean of the target node
+ * over num_samples draws of sample_from_model (:8-27) on the mutilated model of intervene_dict (:30-45).
+ *
+ * The model is an additive structural equation model listed in evaluation order (the reference's
+ * OrderedDict order): node k takes
+ *     value_k = sum_t  c_t * g_t(a_t * value[parent_t])   [ + eps[eps_index_k] ]
+ * terms added left to right and the noise last, g in {x, x^2, exp, cos, sin}.  The closed-form SEM the
+ * reference ships has this shape (src/graphs/impl/CompleteGraph.py:57-97).  An intervened node takes its
+ * intervention value instead.  The noise matrix eps (n_samples x n_eps, row-major: one row per draw, exactly
+ * the `randn(len(model))` vectors the reference draws after np.random.seed(seed)) is generated by the caller
+ * with numpy's legacy stream and stays resident on the device, so every call sees the reference's draws. */
+#define CBO_SEM_MAX_NODES 16
+#define CBO_SEM_MAX_TERMS 64
+enum cbo_sem_fn { CBO_FN_ID = 0, CBO_FN_SQUARE = 1, CBO_FN_EXP = 2, CBO_FN_COS = 3, CBO_FN_SIN = 4 };
+typedef struct cbo_sem_spec {
+    int n_nodes;
+    int eps_index[CBO_SEM_MAX_NODES];       /* column of eps added to node k, or -1 */
+    int term_begin[CBO_SEM_MAX_NODES + 1];  /* terms of node k are [term_begin[k], term_begin[k+1]) */
+    int term_parent[CBO_SEM_MAX_TERMS];     /* index of an EARLIER node */
+    int term_fn[CBO_SEM_MAX_TERMS];         /* enum cbo_sem_fn */
+    double term_a[CBO_SEM_MAX_TERMS];
+    double term_c[CBO_SEM_MAX_TERMS];
+} cbo_sem_spec;
+typedef struct cbo_sem cbo_sem;
+
+int cbo_sem_create(cbo_ctx *ctx, const cbo_sem_spec *spec, int64_t n_samples, int n_eps,
+                   const double *eps /* n_samples * n_eps, row-major */, cbo_sem **out);
+void cbo_sem_destroy(cbo_sem *sem);
+/* mean_out[i] = mean over the draws of node `target` under do(iv_nodes[j] = values[i*n_iv + j], j < n_iv).
+ * n_iv may be 0 (observational mean); m interventions are evaluated in one launch. */
+int cbo_sem_target(cbo_sem *sem, int target, int64_t m, int n_iv, const int *iv_nodes,
+                   const double *values /* m * n_iv */, double *mean_out /* m */);
+
 /* ---- hardware self-test ------------------------------------------------------------------------
  * Runs the fp64 MFMA lane-layout check (asymmetric operands) used by tests; returns CBO_OK when the
  * v_mfma_f64_16x16x4_f64 A/B/C maps this library assumes hold on the device. */

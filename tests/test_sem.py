@@ -1,0 +1,151 @@
+"""Monte-Carlo interventional target: the CPU restatement against closed forms and the
+reference's own data, the host mirror of graph_functions.py, and (gpu) the device kernel against the
+restatement on the reference's draws (seed 1, 100 000 samples, len(model) normals per sample).
+
+Tolerance of the device mean: rtol 1e-12.  The draws are the same numbers on both sides; what differs is
+exp/cos/sin of the device maths library against libm (a few ulp per draw), `x * 0.1` for the reference's
+`x / 10.` (one ulp) and the order the 100 000 terms are added in.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_fixture
+from oracle import sem_oracle as S
+from cbo_with_oop_amd.graphs import CompleteGraph, CoralGraph, ToyGraph
+from cbo_with_oop_amd.utils_functions import graph_functions as G
+
+
+def test_reference_noise_is_the_per_sample_stream():
+    """randn(len(model)) per sample after np.random.seed(seed) == one (num_samples, len(model)) matrix."""
+    np.random.seed(1)
+    rows = np.array([np.random.randn(9) for _ in range(257)])
+    assert np.array_equal(rows, G.reference_noise(257, 9, 1))
+
+
+def test_loop_and_stacked_restatement_agree_exactly():
+    sem = S.complete_graph_sem()
+    for fixed in ({}, {"B": 0.3}, {"D": -2.0, "E": 1.5}):
+        assert S.compute_interventions_loop(sem, fixed, num_samples=1500) == S.compute_interventions(sem, fixed, num_samples=1500)
+
+
+def test_closed_form_expectation_when_noisy_ancestors_are_cut():
+    """do(D=d, E=e): Y = cos d - d/5 + sin e - e/4 + U1 + exp(-U2) + e7, so E[Y] = ... + exp(1/2); the sample
+    standard deviation of U1 + exp(-U2) + e7 is sqrt(2 + e^2 - e) = 2.58."""
+    sem = S.complete_graph_sem()
+    for d, e in ((1.0, 0.5), (-3.0, 2.0)):
+        exact = np.cos(d) - d / 5 + np.sin(e) - e / 4 + np.exp(0.5)
+        got = S.compute_interventions(sem, {"D": d, "E": e})
+        assert abs(got - exact) < 4 * 2.58 / np.sqrt(100000)
+
+
+def test_restatement_reproduces_the_reference_data_file():
+    """data/complete_graph/interventional_data_{x,y}_BO.npy (committed as a fixture: columns B, E, D and the
+    authors' Monte-Carlo mean of Y) -- produced with fewer draws / another seed than compute_interventions'
+    defaults, so agreement is statistical: 0.041 worst case over the 20 rows."""
+    f = load_fixture("complete_bo_d3")
+    sem = S.complete_graph_sem()
+    got = np.array([S.compute_interventions(sem, {"B": b, "E": e, "D": d}, num_samples=20000) for b, e, d in f["X"]])
+    assert np.max(np.abs(got - f["y"][:, 0])) < 0.08
+
+
+def test_host_sample_matches_restatement_draw_for_draw():
+    rng = np.random.RandomState(5)
+    for graph, sem in ((CompleteGraph, S.complete_graph_sem()), (ToyGraph, S.toy_graph_sem())):
+        model = graph.define_sem()
+        assert list(model) == list(sem)
+        for fixed in ({}, {list(sem)[1]: 0.7}):
+            e = rng.randn(len(sem))
+            mine = G.sample_from_model(G.intervene_dict(model, **fixed), e)
+            ref = S.sample_from_model(sem, fixed, e)
+            for k in ref:
+                assert mine[k] == pytest.approx(ref[k], rel=4e-16, abs=1e-300), k
+
+
+def test_spec_packing_and_validation():
+    sp = CompleteGraph.define_sem().spec()
+    assert sp.n_nodes == 9
+    assert list(sp.eps_index[:9]) == [0, 1, 8, 2, 3, 4, 5, 6, 7]
+    assert list(sp.term_begin[:10]) == [0, 0, 0, 0, 2, 3, 4, 5, 7, 13]
+    assert list(sp.term_parent[:4]) == [2, 0, 1, 4]            # A reads F, U1; B reads U2; C reads B
+    with pytest.raises(ValueError):
+        G.AdditiveSEM().add("A", [G.Term("B")])                # reads a node that is not earlier
+    with pytest.raises(ValueError):
+        G.Term("A", "tanh")
+    assert not hasattr(CoralGraph, "define_sem")               # data-fitted SEM: out of scope, not faked
+    assert G.get_parameter_space({"B": "", "D": ""}, [-5, -5], [4, 5]) == [(-5.0, 4.0), (-5.0, 5.0)]
+
+
+# ---- device -----------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_device_target_matches_restatement_on_the_reference_draws():
+    model, sem = CompleteGraph.define_sem(), S.complete_graph_sem()
+    rng = np.random.default_rng(0)
+    for es in CompleteGraph.get_exploration_set("MIS"):
+        bounds = CompleteGraph.bounds(es)
+        x = np.array([[rng.uniform(lo, hi) for lo, hi in bounds]])
+        interventions = {n: "" for n in es}
+        got = G.compute_interventions(model, interventions, x)
+        assert got.shape == (1, 1)
+        assert interventions == {n: x[0, i] for i, n in enumerate(es)}      # the reference's side effect
+        want = S.compute_interventions(sem, dict(zip(es, x[0])))
+        assert got[0, 0] == pytest.approx(want, rel=1e-12), es
+
+
+@pytest.mark.gpu
+def test_device_target_batched_observational_and_other_nodes():
+    model, sem = CompleteGraph.define_sem(), S.complete_graph_sem()
+    dev = model.device()
+    assert model.device() is dev                                           # noise matrix uploaded once
+    # observational mean (no intervention) and a non-default target node
+    assert dev.target_means([], None)[0, 0] == pytest.approx(S.compute_interventions(sem, {}), rel=1e-12)
+    assert dev.target_means(["B"], [[0.4]], "E")[0, 0] == pytest.approx(
+        S.compute_interventions(sem, {"B": 0.4}, target="E"), rel=1e-12)
+    # a 4096-point grid in one launch; spot-check rows against the restatement, all rows against the closed form
+    d, e = np.meshgrid(np.linspace(-5, 5, 64), np.linspace(-6, 3, 64), indexing="ij")
+    vals = np.stack([d.ravel(), e.ravel()], axis=1)
+    got = dev.target_means(["D", "E"], vals)[:, 0]
+    for i in (0, 1234, 4095):
+        assert got[i] == pytest.approx(S.compute_interventions(sem, {"D": vals[i, 0], "E": vals[i, 1]}), rel=1e-12)
+    base = S.compute_interventions(sem, {"D": 0.0, "E": 0.0}) - 1.0        # mean of U1 + exp(-U2) + e7 on these draws
+    exact = np.cos(vals[:, 0]) - vals[:, 0] / 5 + np.sin(vals[:, 1]) - vals[:, 1] / 4 + base
+    assert np.allclose(got, exact, rtol=0, atol=1e-12)
+    # repeated launches give the same bits (fixed reduction order)
+    assert np.array_equal(got, dev.target_means(["D", "E"], vals)[:, 0])
+
+
+@pytest.mark.gpu
+def test_device_target_other_sizes_seeds_and_toy_graph():
+    toy, sem = ToyGraph.define_sem(), S.toy_graph_sem()
+    for n, seed in ((1, 1), (1023, 7), (1025, 2), (5000, 3)):
+        got = G.compute_interventions(toy, {"Z": ""}, np.array([[2.5]]), num_samples=n, seed=seed)[0, 0]
+        assert got == pytest.approx(S.compute_interventions(sem, {"Z": 2.5}, num_samples=n, seed=seed), rel=1e-12)
+    # do(X): the mean of Y over Z's noise approaches the noise-free curve only roughly (Jensen), but do(Z)
+    # differs from the shipped noise-free curve by the mean of e2 alone
+    z = np.linspace(-5, 20, 9)[:, None]
+    got = toy.device().target_means(["Z"], z)[:, 0]
+    e2_mean = G.reference_noise(100000, 3, 1)[:, 2].mean()
+    assert np.allclose(got, ToyGraph.target_do_z(z)[:, 0] + e2_mean, rtol=0, atol=1e-12)
+    # a model that went through intervene_dict keeps its clamps
+    clamped = G.intervene_dict(CompleteGraph.define_sem(), B=1.0)
+    got = G.compute_interventions(clamped, {"D": ""}, np.array([[0.5]]))[0, 0]
+    assert got == pytest.approx(S.compute_interventions(S.complete_graph_sem(), {"B": 1.0, "D": 0.5}), rel=1e-12)
+
+
+@pytest.mark.gpu
+def test_device_rejects_malformed_models():
+    import ctypes
+    from cbo_with_oop_amd import _lib
+    lib, ctx = _lib.load(), _lib.Context.get()
+    sp = CompleteGraph.define_sem().spec()
+    eps = np.zeros((10, 9))
+    h = ctypes.c_void_p()
+    sp.term_parent[0] = 5                                      # A would read a later node
+    assert lib.cbo_sem_create(ctx.handle, ctypes.byref(sp), 10, 9, _lib.dptr(eps), ctypes.byref(h)) == _lib.CBO_ERR_INVALID
+    sp = CompleteGraph.define_sem().spec()
+    assert lib.cbo_sem_create(ctx.handle, ctypes.byref(sp), 10, 8, _lib.dptr(eps), ctypes.byref(h)) == _lib.CBO_ERR_INVALID
+    assert lib.cbo_sem_create(ctx.handle, ctypes.byref(sp), 10, 9, _lib.dptr(eps), ctypes.byref(h)) == 0
+    out = np.zeros(1)
+    bad = np.array([11], dtype=np.int32)
+    assert lib.cbo_sem_target(h, 8, 1, 1, bad.ctypes.data_as(_lib.c_int_p), _lib.dptr(out), _lib.dptr(out)) == _lib.CBO_ERR_INVALID
+    assert lib.cbo_sem_target(h, 9, 1, 0, None, None, _lib.dptr(out)) == _lib.CBO_ERR_INVALID
+    lib.cbo_sem_destroy(h)
