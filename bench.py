@@ -99,7 +99,10 @@ def main():
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
     torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
-    if world > 1:
+    # under torch.distributed.run the process group is always formed (also for one rank, so that the RCCL
+    # exchange can be exercised on a one-GPU box); a plain `python bench.py` stays free of torch.distributed
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -129,7 +132,7 @@ def main():
         return exchange_argmax(bv.value, bi.value)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         ctx.synchronize()
         torch.cuda.synchronize()
@@ -146,7 +149,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timers = ctx.timers()
     ctx.set_profiling(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -197,7 +200,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -45,11 +45,12 @@ NO_CANDIDATE = np.iinfo(np.int64).max     # index sent by a rank whose shard is 
 
 def exchange_argmax(best_val, best_idx, group=None, device=None):
     """All-gather this rank's (best_val, best_global_idx) and reduce.  Returns (val, idx) identical on
-    every rank.  Without an initialised process group (single GPU) it is the identity."""
+    every rank.  Without an initialised process group (plain single-GPU run) it is the identity; a group of
+    one rank still goes through the collective."""
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(best_val), int(best_idx)
     world = dist.get_world_size(group)
     if device is None:

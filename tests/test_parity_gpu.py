@@ -590,3 +590,28 @@ def test_prediction_gradients_and_refinement(hip):
         return -float(fv[0, 0]) / 2.0, -dfv[0] / 2.0
     xo, fxo, _ = fmin_l_bfgs_b(f_df, x0[0], bounds=bounds, maxfun=1000)
     assert np.isclose(f1[0, 0], -fxo, rtol=1e-5) and np.allclose(x1[0], xo, atol=1e-4)
+
+
+def test_bench_exchange_over_rccl_single_rank(hip):
+    """bench.py under torch.distributed.run with one rank: the process group is RCCL (backend nccl) and the
+    winner goes through all_gather_into_tensor on the GPU; it must equal the winner of the plain run."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-sample", "0"]
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, env=env, capture_output=True,
+                           text=True, timeout=300, cwd=ROOT)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                               "--master-addr", "127.0.0.1", "--master-port", "29541",
+                               os.path.join(ROOT, "bench.py")] + common, env=env, capture_output=True, text=True,
+                              timeout=300, cwd=ROOT)
+    assert launched.returncode == 0, launched.stderr[-2000:]
+    a = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in launched.stdout.splitlines() if l.startswith("{")][-1])
+    assert a["winner"] == b["winner"]
+    assert b["n_gpus"] == 1 and b["roofline"]["frac"] > 0.3
