@@ -176,15 +176,19 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
     cbo_ctx *c = new cbo_ctx();
     c->device = device_id;
     std::snprintf(c->name, sizeof(c->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc(&c->part_val, 2048 * sizeof(double)));
-    HIP_TRY(hipMalloc(&c->part_idx, 2048 * sizeof(int64_t)));
-    HIP_TRY(hipMalloc(&c->best_val, sizeof(double)));
-    HIP_TRY(hipMalloc(&c->best_idx, sizeof(int64_t)));
-    HIP_TRY(hipHostMalloc(&c->h_best_val, sizeof(double)));
-    HIP_TRY(hipHostMalloc(&c->h_best_idx, sizeof(int64_t)));
-    HIP_TRY(hipHostMalloc(&c->h_info, sizeof(int)));
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&c->part_val, 2048 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&c->part_idx, 2048 * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(&c->best_val, sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&c->best_idx, sizeof(int64_t));
+    if (e == hipSuccess) e = hipHostMalloc(&c->h_best_val, sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc(&c->h_best_idx, sizeof(int64_t));
+    if (e == hipSuccess) e = hipHostMalloc(&c->h_info, sizeof(int));
+    if (e != hipSuccess) {
+        cbo_shutdown(c);
+        return fail(CBO_ERR_HIP, std::string("cbo_init: ") + hipGetErrorString(e));
+    }
     const char *ws = std::getenv("CBO_HIP_WORKSPACE_MB");
     if (ws) c->max_ws_bytes = (size_t)std::atoll(ws) << 20;
     *out = c;
@@ -195,15 +199,15 @@ extern "C" void cbo_shutdown(cbo_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->pool) hipEventDestroy(e);
     hipFree(c->V); hipFree(c->q); hipFree(c->mu); hipFree(c->mean); hipFree(c->var); hipFree(c->acq);
     hipFree(c->part_val); hipFree(c->part_idx); hipFree(c->best_val); hipFree(c->best_idx);
     hipHostFree(c->h_best_val); hipHostFree(c->h_best_idx); hipHostFree(c->h_info);
     for (auto e : c->chol_events) hipEventDestroy(e);
-    hipStreamDestroy(c->side_stream);
-    hipStreamDestroy(c->stream);
+    if (c->side_stream) hipStreamDestroy(c->side_stream);
+    if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -252,6 +256,8 @@ static void free_gp_data(cbo_gp *g)
     hipFree(g->raw); hipFree(g->y); hipFree(g->A); hipFree(g->invDt); hipFree(g->alpha); hipFree(g->z);
     g->X = PointSet{};
     g->raw = g->y = g->A = g->invDt = g->alpha = g->z = nullptr;
+    g->n = g->n_pad = 0;             // no storage: every entry point that needs data checks g->n
+    g->fitted = false;
 }
 
 static int upload_gp_data(cbo_gp *g, int64_t n, const double *X, const double *y, const double *pm, const double *pv)
@@ -264,7 +270,6 @@ static int upload_gp_data(cbo_gp *g, int64_t n, const double *X, const double *y
     const int64_t n_pad = round_up(n, kPadN);
     if (n_pad != g->n_pad || (pv != nullptr) != (g->X.sv != nullptr)) {
         free_gp_data(g);
-        g->n_pad = n_pad;
         g->lda = n_pad + kRhsCols + kLdExtra;
         HIP_TRY(hipMalloc(&g->X.xs, sizeof(double) * g->d * n_pad));
         HIP_TRY(hipMalloc(&g->X.sq, sizeof(double) * n_pad));
@@ -279,6 +284,7 @@ static int upload_gp_data(cbo_gp *g, int64_t n, const double *X, const double *y
         HIP_TRY(hipMalloc(&g->invDt, sizeof(double) * (n_pad / 16) * 256));
         HIP_TRY(hipMalloc(&g->alpha, sizeof(double) * 2 * n_pad));
         HIP_TRY(hipMalloc(&g->z, sizeof(double) * n_pad));
+        g->n_pad = n_pad;            // only now: a failed allocation above leaves the handle empty (n_pad == 0)
     }
     g->n = n;
     g->X.n = n; g->X.ld = n_pad; g->X.d = g->d;
@@ -369,6 +375,7 @@ static void enqueue_factor(cbo_gp *g, double jitter)
 extern "C" int cbo_gp_fit(cbo_gp *g, int *tries_out, double *jitter_out)
 {
     if (!g) return fail(CBO_ERR_INVALID, "gp is NULL");
+    if (g->n <= 0 || g->n_pad <= 0) return fail(CBO_ERR_INVALID, "gp holds no data (a previous upload failed)");
     cbo_ctx *c = g->ctx;
     HIP_TRY(hipSetDevice(c->device));
     g->fitted = false;
@@ -469,6 +476,7 @@ extern "C" int cbo_gp_get_posterior(cbo_gp *g, double *L_out, double *alpha_out)
 extern "C" int cbo_gp_assemble_kxx(cbo_gp *g, double *K_out)
 {
     if (!g || !K_out) return fail(CBO_ERR_INVALID, "NULL argument");
+    if (g->n <= 0 || g->n_pad <= 0) return fail(CBO_ERR_INVALID, "gp holds no data (a previous upload failed)");
     cbo_ctx *c = g->ctx;
     HIP_TRY(hipSetDevice(c->device));
     double *Atmp = nullptr, *tmp = nullptr;
