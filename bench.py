@@ -2,13 +2,20 @@
 """bench.py -- candidate-intervention acquisitions/sec of the MI355X hot path.
 
 One "step" = one pass of the whole hot path of BASELINE.json's north_star over one batch of synthetic
-input, exactly what CBO.intervene() triggers each trial (/root/reference/src/CBO.py:152-164):
+input, exactly what CBO.intervene() triggers each trial for the set it intervened on
+(/root/reference/src/CBO.py:152-164):
     fit   : K(X,X) assembly -> jittered Cholesky with the forward solve z = L^-1 (y - m) carried along
             (GPy's alpha = L^-T z is not needed by the sweep and is materialised on demand)
     sweep : K(X,X*) -> V = L^-1 K* (variance, mean) -> EI / cost -> arg-max over the rank's candidates
     pick  : arg-max exchange across ranks (RCCL all-gather of 16 B per rank when --gpus > 1)
+The timed steps make ONE device call for fit + sweep (cbo_gp_fit_sweep): the sweep's substitution advances
+panel by panel on two extra streams underneath the factorisation's chain of short kernels.
+--sequential times the same work as two calls (cbo_gp_fit, then cbo_acq_sweep), nothing overlapped.
 Inputs (X, y, candidate grid) are resident in HBM before the timed region starts; the only host
 traffic inside it is the jitchol status word and the 16-byte winner.
+
+After the timed region a short instrumented pass (not part of `value`) runs the two-call sequence with
+per-phase hipEvent timers: it prices the phases and the dominant kernel on its own (`roofline.isolated`).
 
 Workload at N=1 = BASELINE.json configs[1]: toy_graph box, d=3, 4096 observations, 16384-candidate
 regular grid (32x32x16), fp64.  For --gpus G the grid grows to G x 16384 (32x32x16G) and is cut into
@@ -70,13 +77,14 @@ def cpu_baseline(X, y, Xs, y_best, cost, sample):
                       f"of the GPy/emukit path, not GPy itself"}
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/trsm_pmc.json, written by scripts/pmc_to_json.py from separate FETCH_SIZE / WRITE_SIZE runs of
-    this same command).  gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md HBM)."""
-    path = os.path.join(ROOT, "profiles", "trsm_pmc.json")
+def pmc_traffic_bytes(section):
+    """HBM bytes from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by
+    scripts/pmc_to_json.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command): "step" = all
+    kernels of one timed step, "strip_kernel" = one launch of the isolated sweep kernel.
+    gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md HBM)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        d = json.load(open(path))
+        d = json.load(open(path))[section]
         return d["fetch_size_kb"] * 1024 * 2 + d["write_size_kb"] * 1024
     except Exception:
         return None
@@ -88,6 +96,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-sample", type=int, default=4096, help="candidates in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--post-steps", type=int, default=3,
+                    help="instrumented two-call steps after the timed region (phase timers, isolated kernel; 0 = skip)")
+    ap.add_argument("--sequential", action="store_true",
+                    help="refit, then sweep (two calls) instead of the overlapped cbo_gp_fit_sweep")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     args = ap.parse_args()
 
@@ -120,15 +132,19 @@ def main():
     y_best, cost = float(y.min()), 3.0                     # incumbent = best observation; type_cost 1 -> |set| = 3
     begin, end = shard_bounds(Xs.shape[0], world, rank)
 
-    model = HipGaussianProcess(X, y, context=ctx)          # uploads X, y (and fits once: part of warm-up)
+    model = HipGaussianProcess(X, y, context=ctx, fit=False)   # uploads X, y; the first warm-up step fits
     cands = CandidateGrid(Xs[begin:end], model, index_offset=begin, context=ctx)
     ei = CausalExpectedImprovement(y_best, "min", model)
     bv, bi = ctypes.c_double(), ctypes.c_int64()
 
     def step():
-        _lib.check(lib.cbo_gp_fit(model._handle, None, None))
-        _lib.check(lib.cbo_acq_sweep(model._handle, cands._handle, y_best, 0, 0.0, cost, None, None, None,
-                                     ctypes.byref(bv), ctypes.byref(bi)))
+        if args.sequential:
+            _lib.check(lib.cbo_gp_fit(model._handle, None, None))
+            _lib.check(lib.cbo_acq_sweep(model._handle, cands._handle, y_best, 0, 0.0, cost, None, None, None,
+                                         ctypes.byref(bv), ctypes.byref(bi)))
+        else:
+            _lib.check(lib.cbo_gp_fit_sweep(model._handle, cands._handle, y_best, 0, 0.0, cost, None, None, None,
+                                            ctypes.byref(bv), ctypes.byref(bi), None, None))
         return exchange_argmax(bv.value, bi.value)
 
     def fence():
@@ -137,29 +153,48 @@ def main():
         ctx.synchronize()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def step_two_calls():
+        _lib.check(lib.cbo_gp_fit(model._handle, None, None))
+        _lib.check(lib.cbo_acq_sweep(model._handle, cands._handle, y_best, 0, 0.0, cost, None, None, None,
+                                     ctypes.byref(bv), ctypes.byref(bi)))
+        return bv.value, bi.value
+
+    for _ in range(max(1, args.warmup)):       # at least one: the model is created unfitted
         winner = step()
-    ctx.set_profiling(True)
-    ctx.reset_timers()
     fence()
+    ctx.region_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         winner = step()
+    region_ms = ctx.region_end()               # hipEvents on the ctx stream around the K steps
     fence()
     elapsed = time.perf_counter() - t0
-    timers = ctx.timers()
-    ctx.set_profiling(False)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # instrumented pass, outside the timed region: the same work as two calls, per-phase event timers on
+    timers, post_winner = None, None
+    if args.post_steps > 0:
+        post_winner = step_two_calls()
+        ctx.set_profiling(True)
+        ctx.reset_timers()
+        for _ in range(args.post_steps):
+            post_winner = step_two_calls()
+        timers = ctx.timers()
+        ctx.set_profiling(False)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         total_cands = Xs.shape[0]
-        launches = max(1, timers["n_trsm_launches"])
-        trsm_ms = timers["ms_trsm"] / launches
-        achieved = timers["trsm_flops"] / launches / (trsm_ms * 1e-3) / 1e12 if trsm_ms > 0 else 0.0
+        n_pad = -(-N_OBS // 128) * 128
+        m_rank = -(-(end - begin) // 64) * 64
+        # MFMA work of one step on one rank: substitution n^2 flops per candidate column + Cholesky n^3/3
+        step_flops = float(n_pad) ** 2 * m_rank + float(n_pad) ** 3 / 3.0
+        step_tflops = step_flops / (region_ms / args.steps * 1e-3) / 1e12
+        mode = "two calls, nothing overlapped" if args.sequential else \
+            "cbo_gp_fit_sweep: sweep pipelined under the factorisation (5 streams)"
         out = {
             "metric": "candidate-intervention acquisitions/sec (16k grid, d=3)",
             "value": total_cands / (elapsed / args.steps),
@@ -171,30 +206,43 @@ def main():
             "config": {"workload": "toy_graph box d=3, 4096 obs, 16384-candidate regular grid per GPU "
                                    "(BASELINE.json configs[1]); step = GP refit + EI/cost sweep + argmax",
                        "n_obs": N_OBS, "candidates_total": int(total_cands), "grid": list(grid),
-                       "candidates_per_gpu": int(total_cands // world), "parallelism": f"candidate shards x{world}, "
-                       "replicated posterior, RCCL all-gather of (val, idx)"},
+                       "candidates_per_gpu": int(total_cands // world), "step_mode": mode,
+                       "parallelism": f"candidate shards x{world}, replicated posterior, RCCL all-gather of (val, idx)"},
             "winner": {"index": int(winner[1]), "acq": float(winner[0])},
-            "phases_ms_per_step": {k[3:]: timers[k] / args.steps for k in
-                                   ("ms_kxx", "ms_chol", "ms_alpha", "ms_kstar", "ms_trsm", "ms_acq")},
-            "sweep_only_acq_per_s": (total_cands // world) / ((timers["ms_kstar"] + timers["ms_trsm"] + timers["ms_acq"])
-                                                              / args.steps * 1e-3) * world,
-            "roofline": {"kernel": "trsm_strip_kernel<128> (V = L^-1 K*, fused sum V^2 and V^T z)",
-                         "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic_bytes(),
-                         "avg_launch_ms": trsm_ms,
-                         "algorithmic_flops_per_launch": timers["trsm_flops"] / launches},
+            # With the factorisation and the sweep co-scheduled a kernel's own launch duration measures its share
+            # of the machine, not its efficiency: the roofline of the timed region is taken over the whole step
+            # (all fp64-MFMA flops of a step / device time of a step, hipEvents around the K steps).
+            "roofline": {"kernel": "whole step: trsm_update_kernel<16> (dominant) + trsm_strip_kernel<*,16> + "
+                                   "syrk_kernel<64> + potrf_diag128_kernel, co-scheduled" if not args.sequential else
+                                   "whole step: trsm_strip_kernel<true,32> (dominant), then the factorisation's kernels",
+                         "bound": "mfma", "achieved": step_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": step_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic_bytes("step"),
+                         "per": "step", "avg_step_ms_events": region_ms / args.steps,
+                         "algorithmic_flops_per_step": step_flops},
         }
-        # secondary rooflines (HBM-bound kernels): K(X,X) assembly writes the upper 64x64 tiles of Ky once,
-        # the EI/arg-max epilogue streams q, mu in and nothing out (outputs stay on the device)
-        n_pad = -(-N_OBS // 128) * 128
-        nt = n_pad // 64
-        kxx_bytes = nt * (nt + 1) // 2 * 64 * 64 * 8
-        kxx_ms = timers["ms_kxx"] / max(1, timers["n_fit"])
-        out["roofline_kxx"] = {"kernel": "kmat_tile_kernel<3> (K(X,X) + diag, upper tiles) + rhs", "bound": "hbm",
-                               "achieved": kxx_bytes / (kxx_ms * 1e-3) / 1e9 if kxx_ms > 0 else 0.0, "peak": 8000.0,
-                               "unit": "GB/s", "frac": (kxx_bytes / (kxx_ms * 1e-3) / 1e9 / 8000.0) if kxx_ms > 0 else 0.0,
-                               "avg_launch_ms": kxx_ms, "algorithmic_bytes_per_launch": kxx_bytes,
-                               "note": "fp64 exp per element: ALU-bound below the HBM roof (DESIGN.md 4)"}
+        if timers is not None:
+            launches = max(1, timers["n_trsm_launches"])
+            trsm_ms = timers["ms_trsm"] / launches
+            achieved = timers["trsm_flops"] / launches / (trsm_ms * 1e-3) / 1e12 if trsm_ms > 0 else 0.0
+            out["roofline"]["isolated"] = {
+                "kernel": "trsm_strip_kernel<true,32> (V = L^-1 K*, fused sum V^2 and V^T z): the sweep of every set "
+                          "that is not refitted, alone on the device (instrumented pass after the timed region)",
+                "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic_bytes("strip_kernel"),
+                "avg_launch_ms": trsm_ms, "algorithmic_flops_per_launch": timers["trsm_flops"] / launches}
+            out["phases_ms_per_step_two_calls"] = {k[3:]: timers[k] / args.post_steps for k in
+                                                   ("ms_kxx", "ms_chol", "ms_alpha", "ms_kstar", "ms_trsm", "ms_acq")}
+            # rank 0's own shard winner of the two-call pass; with one rank it is the winner of the timed steps
+            out["two_calls_winner_matches"] = (int(post_winner[1]) == int(winner[1])) if world == 1 else None
+            # secondary roofline (HBM-bound): K(X,X) assembly writes the upper 64x64 tiles of Ky once
+            nt = n_pad // 64
+            kxx_bytes = nt * (nt + 1) // 2 * 64 * 64 * 8
+            kxx_ms = timers["ms_kxx"] / max(1, timers["n_fit"])
+            out["roofline_kxx"] = {"kernel": "kmat_tile_kernel<3> (K(X,X) + diag, upper tiles) + rhs", "bound": "hbm",
+                                   "achieved": kxx_bytes / (kxx_ms * 1e-3) / 1e9 if kxx_ms > 0 else 0.0, "peak": 8000.0,
+                                   "unit": "GB/s", "frac": (kxx_bytes / (kxx_ms * 1e-3) / 1e9 / 8000.0) if kxx_ms > 0 else 0.0,
+                                   "avg_launch_ms": kxx_ms, "algorithmic_bytes_per_launch": kxx_bytes,
+                                   "note": "fp64 exp per element: ALU-bound below the HBM roof (DESIGN.md 4)"}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(X, y, Xs, y_best, cost, min(args.cpu_sample, Xs.shape[0]))
         else:

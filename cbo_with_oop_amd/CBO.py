@@ -39,11 +39,13 @@ class CBOAcquisitionPath:
             for s in range(self.es_size)
         ]
 
-    def update_gaussian_process_of_last_intervention(self):
-        """CBO.py:224-235."""
+    def update_gaussian_process_of_last_intervention(self, fit=False):
+        """CBO.py:224-235.  By default the rebuilt model is left unfitted: ``compute_best_acquisition_values``
+        comes next (CBO.py:152-164) and its sweep over this set refits and sweeps in one overlapped device call.
+        ``fit=True`` restores the reference's timing (a not-PD error then surfaces here)."""
         s = self.last_intervention
         self.models[s] = GPFactory.create(self.gp_type, self.data_x[s], self.data_y[s],
-                                          [self.mean_functions[s], self.var_functions[s]], emukit_wrapper=True)
+                                          [self.mean_functions[s], self.var_functions[s]], emukit_wrapper=True, fit=fit)
 
     def compute_best_acquisition_values(self, current_best):
         """CBO.py:237-260."""

@@ -44,7 +44,7 @@ class HipGaussianProcess:
     """
 
     def __init__(self, x, y, *, variance=1.0, lengthscale=1.0, ard=False, noise_var=1e-10, mean_function=None,
-                 variance_adjustment=None, zero_diag=None, context=None, fix_noise=False):
+                 variance_adjustment=None, zero_diag=None, context=None, fix_noise=False, fit=True):
         if (mean_function is None) != (variance_adjustment is None):
             raise ValueError("mean_function and variance_adjustment must be given together")
         self._lib = _lib.load()
@@ -74,7 +74,10 @@ class HipGaussianProcess:
             self._ctx.handle, 0, self.X.shape[0], self.input_dim, _lib.dptr(self.X), _lib.dptr(self._y_flat),
             _lib.dptr(pm), _lib.dptr(pv), self.variance, _lib.dptr(self.lengthscale), int(self.ard), self.noise_var,
             int(self.zero_diag), ctypes.byref(self._handle)))
-        self._fit()
+        if fit:
+            self._fit()
+        else:
+            self.stale = True      # the first acquisition sweep refits, overlapped (see set_data(fit=False))
 
     # -- construction helpers ------------------------------------------------------------------
     def _set_arrays(self, x, y):
@@ -100,10 +103,16 @@ class HipGaussianProcess:
         tries = ctypes.c_int(0)
         jitter = ctypes.c_double(0.0)
         _lib.check(self._lib.cbo_gp_fit(self._handle, ctypes.byref(tries), ctypes.byref(jitter)))
-        self.jitter_tries, self.jitter = tries.value, jitter.value
-        if tries.value:
+        self._note_jitter(tries.value, jitter.value)
+
+    stale = False      # data uploaded, posterior not yet refitted (set_data(..., fit=False))
+
+    def _note_jitter(self, tries, jitter):
+        self.stale = False
+        self.jitter_tries, self.jitter = tries, jitter
+        if tries:
             # GPy logs a warning when jitchol needed jitter
-            warnings.warn(f"Added jitter of {jitter.value:.10e}", RuntimeWarning, stacklevel=3)
+            warnings.warn(f"Added jitter of {jitter:.10e}", RuntimeWarning, stacklevel=4)
 
     # -- reference-facing API -------------------------------------------------------------------
     @property
@@ -120,6 +129,7 @@ class HipGaussianProcess:
         pm, pv = self._prior(x)
         mean = np.empty(m)
         var = np.empty(m)
+        self.ensure_fitted()
         _lib.check(self._lib.cbo_gp_predict(self._handle, m, _lib.dptr(x), _lib.dptr(pm), _lib.dptr(pv),
                                             int(include_likelihood), _lib.dptr(mean), _lib.dptr(var)))
         return mean[:, None], var[:, None]
@@ -135,6 +145,7 @@ class HipGaussianProcess:
         pm, pv = self._prior(x)
         mean = np.empty(m)
         var = np.empty(m)
+        self.ensure_fitted()
         _lib.check(self._lib.cbo_gp_predict_grouped(self._handle, m, group, _lib.dptr(x), _lib.dptr(pm), _lib.dptr(pv),
                                                     int(include_likelihood), _lib.dptr(mean), _lib.dptr(var)))
         return mean[:, None], var[:, None]
@@ -142,16 +153,31 @@ class HipGaussianProcess:
     def predict_noiseless(self, x):
         return self.predict(x, include_likelihood=False)
 
-    def set_data(self, X, Y):
-        """GPyModelWrapper.set_data -> GP.set_XY: replace the data and refit (src/Monitor.py:160)."""
+    def set_data(self, X, Y, fit=True):
+        """GPyModelWrapper.set_data -> GP.set_XY: replace the data and refit (src/Monitor.py:160).
+
+        ``fit=False`` uploads only and leaves the refit to the next use: an acquisition sweep then runs the
+        refit and the sweep overlapped (``cbo_gp_fit_sweep``); any other consumer (predict, log_likelihood, ...)
+        fits first.  A not-positive-definite error then surfaces at that use instead of here."""
         self._set_arrays(X, Y)
         pm, pv = self._prior(self.X)
+        if not fit:
+            _lib.check(self._lib.cbo_gp_upload_data(self._handle, self.X.shape[0], _lib.dptr(self.X),
+                                                    _lib.dptr(self._y_flat), _lib.dptr(pm), _lib.dptr(pv)))
+            self.stale = True
+            return
         _lib.check(self._lib.cbo_gp_set_data(self._handle, self.X.shape[0], _lib.dptr(self.X),
                                              _lib.dptr(self._y_flat), _lib.dptr(pm), _lib.dptr(pv)))
+        self.stale = False
         tries = ctypes.c_int(0)
         jitter = ctypes.c_double(0.0)
         _lib.check(self._lib.cbo_gp_jitter(self._handle, ctypes.byref(tries), ctypes.byref(jitter)))
         self.jitter_tries, self.jitter = tries.value, jitter.value
+
+    def ensure_fitted(self):
+        """Fit now if the data were replaced with ``set_data(..., fit=False)`` and nothing has refitted since."""
+        if self.stale:
+            self._fit()
 
     set_XY = set_data
 
@@ -159,6 +185,7 @@ class HipGaussianProcess:
         """GPy ``model.log_likelihood()``: log marginal likelihood of the fitted model (device reduction over
         the factor's diagonal and z = L^-1 (y - m))."""
         out = ctypes.c_double(0.0)
+        self.ensure_fitted()
         _lib.check(self._lib.cbo_gp_log_marginal(self._handle, ctypes.byref(out)))
         return out.value
 
@@ -216,6 +243,7 @@ class HipGaussianProcess:
         pv = _column(self.variance_adjustment(x), m, "variance_adjustment") if self.causal else None
         dmean = np.empty((m, self.input_dim))
         dvar = np.empty((m, self.input_dim))
+        self.ensure_fitted()
         _lib.check(self._lib.cbo_gp_predict_gradients(self._handle, m, _lib.dptr(x), _lib.dptr(pv), _lib.dptr(dmean),
                                                       _lib.dptr(dvar)))
         return dmean, dvar
@@ -225,6 +253,7 @@ class HipGaussianProcess:
         n = self.X.shape[0]
         L = np.empty((n, n))
         alpha = np.empty(n)
+        self.ensure_fitted()
         _lib.check(self._lib.cbo_gp_get_posterior(self._handle, _lib.dptr(L), _lib.dptr(alpha)))
         return L, alpha[:, None]
 
@@ -251,7 +280,9 @@ class GaussianProcessFactory:
     """src/GaussianProcessFactory.py:18-73, same static methods."""
 
     @staticmethod
-    def create(gp_type, x, y, parameters=None, emukit_wrapper=False):
+    def create(gp_type, x, y, parameters=None, emukit_wrapper=False, fit=True):
+        """``fit=False`` (not in the reference) builds the model without fitting it; the first acquisition sweep
+        then refits and sweeps in one overlapped call."""
         gp_functions = {
             GaussianProcessType.GRAPH_GP: GaussianProcessFactory.create_graph_gp,
             GaussianProcessType.CAUSAL_GP: GaussianProcessFactory.create_causal_gp,
@@ -259,22 +290,22 @@ class GaussianProcessFactory:
         }
         # emukit_wrapper only selected the wrapper class in the reference; HipGaussianProcess answers
         # both interfaces, so the flag changes nothing here.
-        return gp_functions[gp_type](x, y, parameters)
+        return gp_functions[gp_type](x, y, parameters, fit=fit)
 
     @staticmethod
-    def create_graph_gp(x, y, parameters):
+    def create_graph_gp(x, y, parameters, fit=True):
         """:49-54  RBF(lengthscale=p[0], variance=p[1], ARD=p[3]), noise fixed to 1e-2 after construction."""
         return HipGaussianProcess(x, y, variance=parameters[1], lengthscale=parameters[0], ard=parameters[3],
-                                  noise_var=1e-2, fix_noise=True)
+                                  noise_var=1e-2, fix_noise=True, fit=fit)
 
     @staticmethod
-    def create_non_causal_gp(x, y, _):
+    def create_non_causal_gp(x, y, _, fit=True):
         """:57-60  RBF(lengthscale=1, variance=1), noise 1e-10."""
-        return HipGaussianProcess(x, y, variance=1.0, lengthscale=1.0, noise_var=1e-10)
+        return HipGaussianProcess(x, y, variance=1.0, lengthscale=1.0, noise_var=1e-10, fit=fit)
 
     @staticmethod
-    def create_causal_gp(x, y, parameters):
+    def create_causal_gp(x, y, parameters, fit=True):
         """:63-73  CausalRBF(variance_adjustment=var_function) + mean function, noise 1e-10."""
         mean_function, var_function = parameters
         return HipGaussianProcess(x, y, variance=1.0, lengthscale=1.0, noise_var=1e-10,
-                                  mean_function=mean_function, variance_adjustment=var_function)
+                                  mean_function=mean_function, variance_adjustment=var_function, fit=fit)

@@ -69,6 +69,8 @@ SIGNATURES = {
     "cbo_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "cbo_reset_timers": (ctypes.c_int, [ctypes.c_void_p]),
     "cbo_get_timers": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(CboTimers)]),
+    "cbo_region_begin": (ctypes.c_int, [ctypes.c_void_p]),
+    "cbo_region_end": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
     "cbo_device_name": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]),
     "cbo_gp_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_double_p,
                                      c_double_p, c_double_p, c_double_p, ctypes.c_double, c_double_p, ctypes.c_int,
@@ -77,6 +79,8 @@ SIGNATURES = {
     "cbo_gp_fit": (ctypes.c_int, [ctypes.c_void_p, c_int_p, c_double_p]),
     "cbo_gp_set_data": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_double_p, c_double_p, c_double_p,
                                        c_double_p]),
+    "cbo_gp_upload_data": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_double_p, c_double_p, c_double_p,
+                                          c_double_p]),
     "cbo_gp_predict": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_double_p, c_double_p, c_double_p,
                                       ctypes.c_int, c_double_p, c_double_p]),
     "cbo_gp_set_hyper": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, c_double_p, ctypes.c_double]),
@@ -95,6 +99,9 @@ SIGNATURES = {
     "cbo_acq_sweep": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_int,
                                      ctypes.c_double, ctypes.c_double, c_double_p, c_double_p, c_double_p,
                                      c_double_p, c_int64_p]),
+    "cbo_gp_fit_sweep": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_int,
+                                        ctypes.c_double, ctypes.c_double, c_double_p, c_double_p, c_double_p,
+                                        c_double_p, c_int64_p, c_int_p, c_double_p]),
     "cbo_acq_sweep_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_double_p, c_double_p, c_double_p,
                                           ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                           c_double_p, c_double_p, c_int64_p]),
@@ -197,6 +204,14 @@ class Context:
         t = CboTimers()
         check(load().cbo_get_timers(self.handle, ctypes.byref(t)))
         return t.as_dict()
+
+    def region_begin(self):
+        check(load().cbo_region_begin(self.handle))
+
+    def region_end(self):
+        ms = ctypes.c_double(0.0)
+        check(load().cbo_region_end(self.handle, ctypes.byref(ms)))
+        return ms.value
 
     def name(self):
         buf = ctypes.create_string_buffer(256)

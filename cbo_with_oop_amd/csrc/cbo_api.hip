@@ -37,7 +37,14 @@ struct cbo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;        // look-ahead stream of the Cholesky
+    hipStream_t sweep_stream = nullptr;       // the sweep when it is pipelined with the factorisation (lower priority)
+    hipStream_t bulk_stream = nullptr;        // its bulk updates (lowest priority)
     std::vector<hipEvent_t> chol_events;
+    std::vector<hipEvent_t> pipe_events;      // factorisation -> sweep dependencies
+    hipEvent_t ev_join = nullptr, ev_join2 = nullptr, ev_fork = nullptr;
+    hipEvent_t region_a = nullptr, region_b = nullptr;
+    int pipe_chunk_blocks = 2;
+    bool pipe_half_lds = true;
     bool profiling = false;
     std::vector<EventPair> pending;
     std::vector<hipEvent_t> pool;
@@ -105,19 +112,21 @@ struct PhaseScope {
     cbo_ctx *c;
     EventPair p{};
     bool on;
-    PhaseScope(cbo_ctx *ctx, int phase) : c(ctx), on(ctx->profiling)
+    hipStream_t st;
+    PhaseScope(cbo_ctx *ctx, int phase, hipStream_t stream = nullptr)
+        : c(ctx), on(ctx->profiling), st(stream ? stream : ctx->stream)
     {
         if (on) {
             p.a = get_event(c);
             p.b = get_event(c);
             p.phase = phase;
-            hipEventRecord(p.a, c->stream);
+            hipEventRecord(p.a, st);
         }
     }
     ~PhaseScope()
     {
         if (on) {
-            hipEventRecord(p.b, c->stream);
+            hipEventRecord(p.b, st);
             c->pending.push_back(p);
         }
     }
@@ -127,6 +136,8 @@ static void resolve_events(cbo_ctx *c)
 {
     if (c->pending.empty()) return;
     hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->sweep_stream);
+    hipStreamSynchronize(c->bulk_stream);
     for (auto &p : c->pending) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, p.a, p.b);
@@ -176,8 +187,33 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
     cbo_ctx *c = new cbo_ctx();
     c->device = device_id;
     std::snprintf(c->name, sizeof(c->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
+    // the factorisation's streams outrank the sweep stream: its kernels are short, few and on the critical path
+    int prio_low = 0, prio_high = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_high);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, prio_high);
+    // The sweep streams leave a few CUs per XCD to the factorisation: its diagonal-block kernel needs a whole
+    // CU's LDS and would otherwise wait behind a queue of half-LDS sweep workgroups that keep every CU partly
+    // occupied.  CU-mask bit b is CU b/8 of XCD b%8 on this device (scripts/probes/cumask_probe.hip).
+    if (e == hipSuccess) {
+        int reserve = 1;
+        const char *rv = std::getenv("CBO_HIP_PIPE_RESERVE");
+        if (rv) reserve = std::atoi(rv);
+        const int n_cu = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
+        for (int b = 0; b < n_cu; ++b)
+            if (b / 8 >= reserve) mask[(size_t)b / 32] |= 1u << (b % 32);
+        if (reserve > 0 && reserve * 8 < n_cu) {
+            e = hipExtStreamCreateWithCUMask(&c->sweep_stream, (uint32_t)mask.size(), mask.data());
+            if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->bulk_stream, (uint32_t)mask.size(), mask.data());
+        } else {
+            e = hipStreamCreateWithPriority(&c->sweep_stream, hipStreamNonBlocking, (prio_low + prio_high) / 2);
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->bulk_stream, hipStreamNonBlocking, prio_low);
+        }
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming | hipEventDisableSystemFence);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming | hipEventDisableSystemFence);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence);
     if (e == hipSuccess) e = hipMalloc(&c->part_val, 2048 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&c->part_idx, 2048 * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc(&c->best_val, sizeof(double));
@@ -191,6 +227,10 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
     }
     const char *ws = std::getenv("CBO_HIP_WORKSPACE_MB");
     if (ws) c->max_ws_bytes = (size_t)std::atoll(ws) << 20;
+    const char *cb = std::getenv("CBO_HIP_PIPE_CHUNK");
+    if (cb && std::atoi(cb) >= 1) c->pipe_chunk_blocks = std::atoi(cb);
+    const char *kb = std::getenv("CBO_HIP_PIPE_KB");
+    if (kb && std::atoi(kb) == 32) c->pipe_half_lds = false;
     *out = c;
     return CBO_OK;
 }
@@ -206,6 +246,14 @@ extern "C" void cbo_shutdown(cbo_ctx *c)
     hipFree(c->part_val); hipFree(c->part_idx); hipFree(c->best_val); hipFree(c->best_idx);
     hipHostFree(c->h_best_val); hipHostFree(c->h_best_idx); hipHostFree(c->h_info);
     for (auto e : c->chol_events) hipEventDestroy(e);
+    for (auto e : c->pipe_events) hipEventDestroy(e);
+    if (c->region_a) hipEventDestroy(c->region_a);
+    if (c->region_b) hipEventDestroy(c->region_b);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->ev_join2) hipEventDestroy(c->ev_join2);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->sweep_stream) hipStreamDestroy(c->sweep_stream);
+    if (c->bulk_stream) hipStreamDestroy(c->bulk_stream);
     if (c->side_stream) hipStreamDestroy(c->side_stream);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -239,6 +287,33 @@ extern "C" int cbo_get_timers(cbo_ctx *c, cbo_timers *out)
     if (!c || !out) return fail(CBO_ERR_INVALID, "NULL argument");
     resolve_events(c);
     *out = c->timers;
+    return CBO_OK;
+}
+
+// One event pair on the main stream around a region of calls: device time of the region whatever runs inside
+// (several streams join the main stream before every call returns).
+extern "C" int cbo_region_begin(cbo_ctx *c)
+{
+    if (!c) return fail(CBO_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->region_a) {
+        HIP_TRY(hipEventCreate(&c->region_a));
+        HIP_TRY(hipEventCreate(&c->region_b));
+    }
+    HIP_TRY(hipEventRecord(c->region_a, c->stream));
+    return CBO_OK;
+}
+
+extern "C" int cbo_region_end(cbo_ctx *c, double *ms_out)
+{
+    if (!c || !ms_out) return fail(CBO_ERR_INVALID, "NULL argument");
+    if (!c->region_a) return fail(CBO_ERR_INVALID, "cbo_region_end without cbo_region_begin");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->region_b, c->stream));
+    HIP_TRY(hipEventSynchronize(c->region_b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->region_a, c->region_b));
+    *ms_out = ms;
     return CBO_OK;
 }
 
@@ -372,6 +447,31 @@ static void enqueue_factor(cbo_gp *g, double jitter)
     }
 }
 
+// GPy util.linalg.jitchol after a failed attempt: first mean(diag) * 1e-6, then x10 per retry, at most 5 retries.
+static int next_jitter(cbo_gp *g, int *tries, double *jitter)
+{
+    if (*tries == 0) {
+        // diag of Ky as assembled (jitter-free): variance + v_i + (noise + 1e-8); the kernel's own
+        // diagonal differs from this only when zero_diag is off and |x|^2 rounds differently from
+        // x.x, i.e. by O(1e-16) relative -- irrelevant for a 1e-6 * mean(diag) jitter.
+        double sum = 0.0;
+        bool nonpos = false;
+        for (int64_t i = 0; i < g->n; ++i) {
+            const double dv = g->h.variance + (g->h_pv.empty() ? 0.0 : g->h_pv[i]) + (g->noise_var + kGpyDiagJitter);
+            if (!(dv > 0.0)) nonpos = true;
+            sum += dv;
+        }
+        if (nonpos) return fail(CBO_ERR_NONPOS_DIAG, "not pd: non-positive diagonal elements");
+        *jitter = sum / (double)g->n * 1e-6;
+    } else {
+        *jitter *= 10.0;
+    }
+    ++*tries;
+    if (*tries > 5 || !std::isfinite(*jitter))
+        return fail(CBO_ERR_NOT_PD, "not positive definite, even with jitter.");
+    return CBO_OK;
+}
+
 extern "C" int cbo_gp_fit(cbo_gp *g, int *tries_out, double *jitter_out)
 {
     if (!g) return fail(CBO_ERR_INVALID, "gp is NULL");
@@ -388,25 +488,8 @@ extern "C" int cbo_gp_fit(cbo_gp *g, int *tries_out, double *jitter_out)
         HIP_TRY(hipMemcpyAsync(c->h_info, g->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (*c->h_info == 0) break;
-        if (tries == 0) {
-            // diag of Ky as assembled (jitter-free): variance + v_i + (noise + 1e-8); the kernel's own
-            // diagonal differs from this only when zero_diag is off and |x|^2 rounds differently from
-            // x.x, i.e. by O(1e-16) relative -- irrelevant for a 1e-6 * mean(diag) jitter.
-            double sum = 0.0;
-            bool nonpos = false;
-            for (int64_t i = 0; i < g->n; ++i) {
-                const double dv = g->h.variance + (g->h_pv.empty() ? 0.0 : g->h_pv[i]) + (g->noise_var + kGpyDiagJitter);
-                if (!(dv > 0.0)) nonpos = true;
-                sum += dv;
-            }
-            if (nonpos) return fail(CBO_ERR_NONPOS_DIAG, "not pd: non-positive diagonal elements");
-            jitter = sum / (double)g->n * 1e-6;
-        } else {
-            jitter *= 10.0;
-        }
-        ++tries;
-        if (tries > 5 || !std::isfinite(jitter))
-            return fail(CBO_ERR_NOT_PD, "not positive definite, even with jitter.");
+        const int rc = next_jitter(g, &tries, &jitter);
+        if (rc != CBO_OK) return rc;
     }
     // contiguous z = L^-1 (y - m) for the sweep: the posterior mean is (L^-1 k*)^T z, so the backward
     // solve for alpha = L^-T z is not on the sweep's path and is materialised on first use (ensure_alpha)
@@ -447,6 +530,15 @@ extern "C" int cbo_gp_set_data(cbo_gp *g, int64_t n, const double *X, const doub
     const int rc = upload_gp_data(g, n, X, y, pm, pv);
     if (rc != CBO_OK) return rc;
     return cbo_gp_fit(g, nullptr, nullptr);
+}
+
+extern "C" int cbo_gp_upload_data(cbo_gp *g, int64_t n, const double *X, const double *y, const double *pm,
+                                  const double *pv)
+{
+    if (!g) return fail(CBO_ERR_INVALID, "gp is NULL");
+    HIP_TRY(hipSetDevice(g->ctx->device));
+    HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    return upload_gp_data(g, n, X, y, pm, pv);      // leaves the model unfitted
 }
 
 extern "C" int cbo_gp_get_posterior(cbo_gp *g, double *L_out, double *alpha_out)
@@ -607,20 +699,22 @@ static int enqueue_posterior(cbo_gp *g, cbo_cands *k)
     return CBO_OK;
 }
 
-extern "C" int cbo_acq_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task, double ei_jitter, double cost,
-                             double *acq_out, double *mean_out, double *var_out, double *best_val, int64_t *best_idx)
+static int check_sweep_args(const cbo_gp *g, const cbo_cands *k, int task)
 {
     if (!g || !k) return fail(CBO_ERR_INVALID, "NULL argument");
-    if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
     if (g->ctx != k->ctx) return fail(CBO_ERR_INVALID, "gp and candidates live on different contexts");
     if (g->d != k->d) return fail(CBO_ERR_INVALID, "gp and candidates have different dimensions");
     if ((g->X.sv != nullptr) && (k->pv == nullptr))
         return fail(CBO_ERR_INVALID, "causal gp needs candidate prior mean/variance");
     if (task != CBO_TASK_MIN && task != CBO_TASK_MAX) return fail(CBO_ERR_INVALID, "task must be 0 (min) or 1 (max)");
+    return CBO_OK;
+}
+
+// EI / cost and arg-max from q, mu (already on the device), results to the host
+static int finish_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task, double ei_jitter, double cost,
+                        double *acq_out, double *mean_out, double *var_out, double *best_val, int64_t *best_idx)
+{
     cbo_ctx *c = g->ctx;
-    HIP_TRY(hipSetDevice(c->device));
-    int rc = enqueue_posterior(g, k);
-    if (rc != CBO_OK) return rc;
     const bool causal = g->X.sv != nullptr;
     AcqParams p;
     p.variance = g->h.variance; p.noise_var = g->noise_var; p.y_best = y_best; p.ei_jitter = ei_jitter; p.cost = cost;
@@ -644,6 +738,131 @@ extern "C" int cbo_acq_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task, d
     if (best_idx) *best_idx = *c->h_best_idx;
     if (c->profiling) c->timers.n_sweep += 1;
     return CBO_OK;
+}
+
+extern "C" int cbo_acq_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task, double ei_jitter, double cost,
+                             double *acq_out, double *mean_out, double *var_out, double *best_val, int64_t *best_idx)
+{
+    int rc = check_sweep_args(g, k, task);
+    if (rc != CBO_OK) return rc;
+    if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
+    cbo_ctx *c = g->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    rc = enqueue_posterior(g, k);
+    if (rc != CBO_OK) return rc;
+    return finish_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
+}
+
+// timers of the pipelined sweep: one event pair per launch on the sweep stream
+static void pipe_mark(void *user, hipStream_t st, int begin, double flops)
+{
+    cbo_ctx *c = static_cast<cbo_ctx *>(user);
+    if (!c->profiling) return;
+    static thread_local EventPair cur;
+    if (begin) {
+        cur.a = get_event(c);
+        cur.b = get_event(c);
+        cur.phase = PH_TRSM;
+        hipEventRecord(cur.a, st);
+        c->timers.n_trsm_launches += 1;
+        c->timers.trsm_flops += flops;
+    } else {
+        hipEventRecord(cur.b, st);
+        c->pending.push_back(cur);
+    }
+}
+
+// Refit and sweep in one call, the two overlapped: what CBO.intervene() does for the set it has just
+// intervened on (set_data -> refit, then find_next_y_point -> acquisition over the candidates,
+// /root/reference/src/Monitor.py:160, src/CBO.py:250-257).  The factorisation is a chain of short kernels
+// that leaves most CUs idle; the sweep's rows become solvable panel by panel as the chain advances, so it
+// runs right-looking on a second stream underneath (SweepPipe).  Same results as cbo_gp_fit followed by
+// cbo_acq_sweep (the per-element operation order is the same; only q and mu are summed panel-wise).
+extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task, double ei_jitter, double cost,
+                                double *acq_out, double *mean_out, double *var_out, double *best_val,
+                                int64_t *best_idx, int *tries_out, double *jitter_out)
+{
+    int rc = check_sweep_args(g, k, task);
+    if (rc != CBO_OK) return rc;
+    if (g->n <= 0 || g->n_pad <= 0) return fail(CBO_ERR_INVALID, "gp holds no data (a previous upload failed)");
+    cbo_ctx *c = g->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    rc = prepare_cands(g, k);
+    if (rc != CBO_OK) return rc;
+    int64_t chunk = 0, ldv = 0;
+    rc = ensure_workspaces(c, g->n_pad, k->m_pad, &chunk, &ldv);
+    if (rc != CBO_OK) return rc;
+    if (chunk < k->m_pad) {
+        // the candidates do not fit one V workspace: no overlap, the plain sequence
+        rc = cbo_gp_fit(g, tries_out, jitter_out);
+        if (rc != CBO_OK) return rc;
+        return cbo_acq_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
+    }
+    g->fitted = false;
+    SweepPipe pipe{};
+    pipe.stream = c->sweep_stream;
+    pipe.bulk = c->bulk_stream;
+    pipe.V = c->V; pipe.ldv = ldv; pipe.m_pad = k->m_pad;
+    pipe.zvec = g->z; pipe.q = c->q; pipe.mu = c->mu;
+    pipe.chunk_blocks = c->pipe_chunk_blocks;
+    pipe.half_lds = c->pipe_half_lds;
+    pipe.events = &c->pipe_events;
+    pipe.mark = pipe_mark; pipe.user = c;
+    double jitter = 0.0;
+    int tries = 0;
+    for (;;) {
+        // fork: the sweep stream starts after what is queued on the main stream (candidate preparation)
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->sweep_stream, c->ev_fork, 0));
+        {
+            PhaseScope ps(c, PH_KSTAR, c->sweep_stream);
+            launch_kstar(c->sweep_stream, g->X, k->P, 0, k->m_pad, g->h, c->V, ldv, g->n_pad);
+        }
+        HIP_TRY(hipMemsetAsync(c->q, 0, sizeof(double) * k->m_pad, c->sweep_stream));
+        HIP_TRY(hipMemsetAsync(c->mu, 0, sizeof(double) * k->m_pad, c->sweep_stream));
+        {
+            PhaseScope ps(c, PH_KXX);
+            launch_kxx(c->stream, g->X, g->h, g->noise_var + kGpyDiagJitter, jitter, g->A, g->lda, g->n_pad);
+            launch_rhs(c->stream, g->y, g->X.pm, g->n, g->A, g->lda, g->n_pad);
+        }
+        {
+            PhaseScope ps(c, PH_CHOL);
+#ifdef CBO_DIAG_KNOBS
+            // timing-only: factor first, then the same right-looking sweep launches with nothing beside them
+            if (std::getenv("CBO_DBG_PIPE_SERIAL")) {
+                launch_cholesky(c->stream, c->side_stream, c->chol_events, g->A, g->lda, g->n_pad, g->invDt, g->info);
+                hipMemcpy2DAsync(g->z, sizeof(double), g->A + g->n_pad, sizeof(double) * g->lda, sizeof(double),
+                                 (size_t)g->n_pad, hipMemcpyDeviceToDevice, c->stream);
+                int pr = 0;
+                for (int r0 = 0; r0 < (int)g->n_pad; r0 += 256, ++pr)
+                    sweep_pipe_pair(pipe, c->stream, g->A, g->lda, g->invDt, g->n_pad, pr, r0,
+                                    (r0 + 256 <= (int)g->n_pad) ? 256 : 128);
+            } else
+#endif
+            launch_cholesky(c->stream, c->side_stream, c->chol_events, g->A, g->lda, g->n_pad, g->invDt, g->info, &pipe);
+        }
+        // join: everything the sweep streams were given is done before the main stream goes on (the last
+        // pair has no rows below it, so the bulk stream's last launch precedes the sweep stream's in-panel solve
+        // of that pair only through the events: wait for both)
+        HIP_TRY(hipEventRecord(c->ev_join, c->sweep_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        HIP_TRY(hipEventRecord(c->ev_join2, c->bulk_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(c->h_info, g->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (*c->h_info == 0) break;
+        rc = next_jitter(g, &tries, &jitter);
+        if (rc != CBO_OK) return rc;
+    }
+    g->fitted = true;
+    g->alpha_ready = false;
+    g->tries = tries;
+    g->jitter = jitter;
+    if (c->profiling) c->timers.n_fit += 1;
+    if (tries_out) *tries_out = tries;
+    if (jitter_out) *jitter_out = jitter;
+    return finish_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
 }
 
 extern "C" int cbo_acq_sweep_host(cbo_gp *g, int64_t m, const double *Xs, const double *pm, const double *pv,

@@ -84,8 +84,27 @@ void launch_kstar(hipStream_t s, const PointSet &X, const PointSet &C, int64_t c
                   const KernelHyper &h, double *V, int64_t ldv, int64_t n_pad);
 
 // Recursive blocked Cholesky (upper) of A[0:n_pad, 0:n_pad] incl. forward solve of the rhs strip.
+// Sweep pipelined with the factorisation: as soon as a pair of 128-row panels of U is final, the strip kernel
+// solves those rows of V on `stream` (q, mu accumulate) and trsm_update_kernel folds them into the rows below,
+// while the factorisation continues on its own streams.  V holds K(X, X*) on entry (assembled on `stream`).
+struct SweepPipe {
+    hipStream_t stream;                  // in-panel solves + the update of the next panel pair's rows
+    hipStream_t bulk;                    // the updates of everything below that
+    double *V;
+    int64_t ldv, m_pad;
+    double *zvec;                        // contiguous copy of z, written panel by panel by the diagonal kernel
+    double *q, *mu;                      // zeroed on `stream` by the caller
+    int chunk_blocks;                    // row blocks per workgroup of the update kernel
+    bool half_lds;                       // 16-row stages (two workgroups per CU) for every kernel of the pipeline
+    std::vector<hipEvent_t> *events;     // factorisation -> sweep dependencies, grown on demand
+    void (*mark)(void *user, hipStream_t st, int begin, double flops);   // optional: around every sweep launch (timers)
+    void *user;
+};
 void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &events, double *A, int64_t lda,
-                     int64_t n_pad, double *invDt, int *info_dev);
+                     int64_t n_pad, double *invDt, int *info_dev, const SweepPipe *pipe = nullptr);
+// pair p of the pipelined sweep: rows [r0, r0 + klen) of the factor are final on stream `chain`
+void sweep_pipe_pair(const SweepPipe &pipe, hipStream_t chain, const double *A, int64_t lda, const double *invDt,
+                     int64_t n_pad, int p, int r0, int klen);
 // alpha = U^-1 z  (z = first rhs column of A).
 void launch_backsolve(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt, double *alpha);
 void launch_backsolve_vec(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt,
@@ -98,7 +117,11 @@ void launch_pred_gradients(hipStream_t s, const PointSet &X, const PointSet &C, 
 
 // V <- L^-1 V on m_pad columns (64-column strips); optional q[c] = sum_i V[i][c]^2, mu[c] = sum_i V[i][c] z[i].
 void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const double *invDt, double *V, int64_t ldv,
-                        int64_t n, int64_t m_pad, const double *z, double *q, double *mu);
+                        int64_t n, int64_t m_pad, const double *z, double *q, double *mu, bool accumulate = false,
+                        bool half_lds = false);
+// C[i0_begin:i0_end, :] -= U[k0:k0+klen, i0_begin:i0_end]^T V[k0:k0+klen, :]  (C and V share the workspace V)
+void launch_trsm_update(hipStream_t s, const double *U, int64_t ldu, double *V, int64_t ldv, int k0, int klen,
+                        int i0_begin, int i0_end, int64_t m_pad, int chunk_blocks, bool half_lds = true);
 
 struct AcqParams {
     double variance, noise_var, y_best, ei_jitter, cost;

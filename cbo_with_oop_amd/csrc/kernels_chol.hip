@@ -133,7 +133,8 @@ __device__ __forceinline__ void diag_tile_update(DiagShared &sh, int o, int r0, 
 }
 
 __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t lda, int r0, int rcol,
-                                                            double *__restrict__ invDt, int *info, int dbg)
+                                                            double *__restrict__ invDt, int *info, int dbg,
+                                                            double *__restrict__ zvec)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     DiagShared &sh = *reinterpret_cast<DiagShared *>(smem_raw);
@@ -238,7 +239,10 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t l
             *reinterpret_cast<d2 *>(&A[(int64_t)(r0 + i) * lda + r0 + j2]) = v;
         }
     }
-    if (tid < 128) A[(int64_t)(r0 + tid) * lda + rcol] = sh.rz[tid];
+    if (tid < 128) {
+        A[(int64_t)(r0 + tid) * lda + rcol] = sh.rz[tid];
+        if (zvec) zvec[r0 + tid] = sh.rz[tid];          // contiguous copy for a sweep that runs alongside
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -368,11 +372,57 @@ static void launch_syrk(hipStream_t s, double *A, int64_t lda, int r0, int n1, i
                        ti_begin, dbg);
 }
 
+// Rows [r0, r0 + klen) of U (all columns) and of z are final on stream `chain`: hand them to the sweep.
+// Two sweep streams with a look-ahead of one panel pair: `stream` solves the pair's rows of V (sd) and folds
+// them into the NEXT pair's rows only (first); `bulk` folds them into everything below that (rest).  The
+// bulk launches then follow each other without a gap while sd/first of the following pair run beside them:
+//   stream: wait chain[p]; sd(p); record sd[p]; wait rest[p-1]; first(p)      (first(p) rewrites rows that
+//   bulk  : wait sd[p]; rest(p); record rest[p]                                rest(p-1) also rewrites)
+void sweep_pipe_pair(const SweepPipe &pipe, hipStream_t chain, const double *A, int64_t lda, const double *invDt,
+                     int64_t n_pad, int p, int r0, int klen)
+{
+    auto pipe_event = [&](int kind, int pp) -> hipEvent_t {      // kind 0: chain, 1: sd done, 2: rest done
+        std::vector<hipEvent_t> &ev = *pipe.events;
+        const size_t slot = (size_t)(3 * pp + kind);
+        while (ev.size() <= slot) {
+            hipEvent_t e;
+            hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence);
+            ev.push_back(e);
+        }
+        return ev[slot];
+    };
+    const double m = (double)pipe.m_pad;
+    hipEventRecord(pipe_event(0, p), chain);
+    hipStreamWaitEvent(pipe.stream, pipe_event(0, p), 0);
+    if (pipe.mark) pipe.mark(pipe.user, pipe.stream, 1, (double)klen * (double)klen * m);
+    launch_trsm_strips(pipe.stream, A + (int64_t)r0 * lda + r0, lda, invDt + (int64_t)(r0 / 16) * 256,
+                       pipe.V + (int64_t)r0 * pipe.ldv, pipe.ldv, klen, pipe.m_pad, pipe.zvec + r0, pipe.q, pipe.mu, true,
+                       pipe.half_lds);
+    if (pipe.mark) pipe.mark(pipe.user, pipe.stream, 0, 0.0);
+    hipEventRecord(pipe_event(1, p), pipe.stream);
+    const int below = r0 + klen;
+    if (below >= (int)n_pad) return;
+    const int first_end = (below + 256 < (int)n_pad) ? below + 256 : (int)n_pad;
+    if (p > 0) hipStreamWaitEvent(pipe.stream, pipe_event(2, p - 1), 0);
+    if (pipe.mark) pipe.mark(pipe.user, pipe.stream, 1, 2.0 * (double)klen * (double)(first_end - below) * m);
+    launch_trsm_update(pipe.stream, A, lda, pipe.V, pipe.ldv, r0, klen, below, first_end, pipe.m_pad, pipe.chunk_blocks,
+                       pipe.half_lds);
+    if (pipe.mark) pipe.mark(pipe.user, pipe.stream, 0, 0.0);
+    hipStreamWaitEvent(pipe.bulk, pipe_event(1, p), 0);
+    if (first_end < (int)n_pad) {
+        if (pipe.mark) pipe.mark(pipe.user, pipe.bulk, 1, 2.0 * (double)klen * (double)((int)n_pad - first_end) * m);
+        launch_trsm_update(pipe.bulk, A, lda, pipe.V, pipe.ldv, r0, klen, first_end, (int)n_pad, pipe.m_pad,
+                           pipe.chunk_blocks, pipe.half_lds);
+        if (pipe.mark) pipe.mark(pipe.user, pipe.bulk, 0, 0.0);
+    }
+    hipEventRecord(pipe_event(2, p), pipe.bulk);
+}
+
 // Look-ahead: the bulk of panel k-1's trailing update (tile rows below the next panel) runs on the side
 // stream while the main stream factors the diagonal block of panel k and solves its row panel; the two
 // meet again before the next panel's own rows are updated.
 void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &events, double *A, int64_t lda,
-                     int64_t n_pad, double *invDt, int *info_dev)
+                     int64_t n_pad, double *invDt, int *info_dev, const SweepPipe *pipe)
 {
     // > 64 KiB of dynamic LDS needs the opt-in on the current device (cheap; done per call so that several
     // devices in one process are all covered)
@@ -397,26 +447,34 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     // Panels are taken in pairs: the second panel of a pair only needs the first one's update of its own 128
     // rows, so the trailing matrix below the pair is updated once with K = 256 (half the read-modify-write
     // passes); the bulk of that update runs on the side stream under the next pair's diagonal/panel work.
+    double *zvec = pipe ? pipe->zvec : nullptr;
+    // beside a pipelined sweep the panel solves use the half-LDS kernel, which fits next to a sweep workgroup
+    const bool half_lds = pipe && pipe->half_lds;
+    int pair = 0;
+    auto sweep_rows = [&](int r0, int klen) {
+        if (pipe) sweep_pipe_pair(*pipe, s, A, lda, invDt, n_pad, pair++, r0, klen);
+    };
     int pending = -1;                      // event index of the bulk update still in flight
     for (int k = 0; k < np; k += 2) {
         const int r0 = 128 * k;
         hipLaunchKernelGGL(potrf_diag128_kernel, dim3(1), dim3(256), sizeof(DiagShared), s, A, lda, r0, rcol, invDt,
-                           info_dev, dbg);
+                           info_dev, dbg, zvec);
         const int n2 = (int)n_pad - r0 - 128;
-        if (n2 <= 0) break;
+        if (n2 <= 0) { sweep_rows(r0, 128); break; }
         launch_trsm_strips(s, A + (int64_t)r0 * lda + r0, lda, invDt + (int64_t)(r0 / 16) * 256,
-                           A + (int64_t)r0 * lda + r0 + 128, lda, 128, n2, nullptr, nullptr, nullptr);
+                           A + (int64_t)r0 * lda + r0 + 128, lda, 128, n2, nullptr, nullptr, nullptr, false, half_lds);
         // rows of the pair's second panel: K = 128 update with the first panel (after the previous bulk
         // update, which touches the same rows)
         if (pending >= 0) { hipStreamWaitEvent(s, events[pending], 0); pending = -1; }
         launch_syrk(s, A, lda, r0, 128, n2, rcol, 0, 2);
         const int r1 = r0 + 128;
         hipLaunchKernelGGL(potrf_diag128_kernel, dim3(1), dim3(256), sizeof(DiagShared), s, A, lda, r1, rcol, invDt,
-                           info_dev, dbg);
+                           info_dev, dbg, zvec);
         const int n3 = (int)n_pad - r1 - 128;
-        if (n3 <= 0) break;
+        if (n3 <= 0) { sweep_rows(r0, 256); break; }
         launch_trsm_strips(s, A + (int64_t)r1 * lda + r1, lda, invDt + (int64_t)(r1 / 16) * 256,
-                           A + (int64_t)r1 * lda + r1 + 128, lda, 128, n3, nullptr, nullptr, nullptr);
+                           A + (int64_t)r1 * lda + r1 + 128, lda, 128, n3, nullptr, nullptr, nullptr, false, half_lds);
+        sweep_rows(r0, 256);
         // both panels against everything below them: next pair's first panel rows on this stream, ...
         launch_syrk(s, A, lda, r0, 256, n3, rcol, 0, 2);
         if (n3 > 128) {                                       // ... the rest on the side stream

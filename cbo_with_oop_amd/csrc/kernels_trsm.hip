@@ -18,6 +18,8 @@
 //
 // Roofline: fp64 MFMA bound.  Algorithmic work n^2 flops per column (n^2/2 FMAs); V re-read traffic is
 // n^2/(2*RB) * 8 B per column (left-looking), U traffic n^2/2*8 B per strip served from L2/MALL.
+#include <cstdlib>
+
 #include "cbo_internal.h"
 
 namespace cbo {
@@ -30,12 +32,25 @@ namespace cbo {
 
 constexpr int kRB = 128;                  // rows per block
 constexpr int kT = kRB / 16;              // 16-row tiles per block
-constexpr int kKB = 32;                   // rows of U / V per pipeline stage (8 MFMA k-steps)
 constexpr int kLdsLd = kRB + 16;          // U-tile row stride: rows kq and kq+1 land 32 banks apart (ds_read_b64)
 constexpr int kNBuf = 3;                  // pipeline depth: DMA of stage s+2 is in flight while stage s computes
-constexpr int kABuf = kKB * kLdsLd;       // doubles per U stage buffer
-constexpr int kBBuf = 4 * kKB * 16;       // doubles per V stage buffer (4 waves x [32 k][16 cols])
-constexpr int kDmaPerStage = 8 + 4;       // LDS-DMA instructions a wave issues per stage (8 U rows + 4 V pieces)
+// Per-stage geometry for KB rows of U / V per pipeline stage (KB/4 MFMA k-steps).  KB = 32: one workgroup fills a
+// CU's LDS (159,744 B) -- fewest barriers, the choice when there is one workgroup per CU anyway.  KB = 16: 79,872 B
+// and < 256 registers per lane, so two workgroups share a CU (two waves per SIMD) and hide each other's barrier
+// and LDS latencies; used when kernels of several streams are in flight at once (the pipelined refit + sweep).
+template <int KB>
+struct StageGeom {
+    static constexpr int kA = KB * kLdsLd;            // doubles per U stage buffer
+    static constexpr int kB = 4 * KB * 16;            // doubles per V stage buffer (4 waves x [KB k][16 cols])
+    static constexpr int kRA = KB / 4;                // U rows a wave fetches per stage
+    static constexpr int kParts = KB / 8;             // DMA groups per stage and wave: 2 U rows + one 1 KiB B piece
+    static constexpr int kDma = 3 * kParts;           // LDS-DMA instructions a wave issues per stage
+    static constexpr int kKS = KB / 4;                // MFMA k-steps per stage
+    static constexpr int kDiagStages = kRB / KB;      // diagonal stages per row block
+    static constexpr int kDiagTiles = KB / 16;        // 16x16 diagonal tiles solved per diagonal stage
+    static constexpr int kDiagStores = 4 * kDiagTiles;   // V stores a wave issues per diagonal stage
+    static_assert(kParts <= kKS - 2, "the DMA groups and the cursor update ride under the first k-steps");
+};
 #ifdef CBO_DIAG_KNOBS
 // Timing-only build: workgroup 0 / wave 0 stamps s_memtime around the barrier and at the end of every stage
 // (3 stamps per stage) into a debug buffer read back by cbo_diag_trsm_stamps (scripts/trsm_timeline.py).
@@ -56,10 +71,10 @@ extern "C" int cbo_diag_trsm_stamps(unsigned long long *out, int n)
 #define STAMP_NEXT()
 #endif
 
-// One continuous software pipeline over "stages" of 32 U-rows.  Row block b (rows i0 = 128 b) consists
-// of nst = i0/32 regular stages (k rows [32 j, 32 j + 32) against the block's 128 columns) followed by four
-// diagonal stages (k rows i0 + 32 m: the block's own upper-triangular part).  Every stage's U tile
-// [32][128] is fetched by the same LDS-DMA pattern; the per-wave B region receives V rows (regular
+// One continuous software pipeline over "stages" of KB U-rows (described for KB = 32).  Row block b (rows
+// i0 = 128 b) consists of nst = i0/32 regular stages (k rows [32 j, 32 j + 32) against the block's 128 columns)
+// followed by four diagonal stages (k rows i0 + 32 m: the block's own upper-triangular part).  Every stage's U
+// tile [32][128] is fetched by the same LDS-DMA pattern; the per-wave B region receives V rows (regular
 // stages) or the two 16x16 diagonal inverses (diagonal stages).  The DMA of stage g+2 is issued while
 // stage g computes, across block boundaries, so the pipeline never drains.
 struct StageCursor {
@@ -69,15 +84,17 @@ struct StageCursor {
     int64_t b_stride;                     // doubles between consecutive B pieces
 };
 
-constexpr int kStoresPerDiagStage = 8;    // V stores a wave issues per diagonal stage (2 tiles x 4 rows)
-
-template <bool SWEEP>
+template <bool SWEEP, int KB>
 __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restrict__ U, int64_t ldu,
                                                          const double *__restrict__ invDt, double *V, int64_t ldv,
                                                          int n, const double *__restrict__ z,
-                                                         double *__restrict__ q_out, double *__restrict__ mu_out)
+                                                         double *__restrict__ q_out, double *__restrict__ mu_out,
+                                                         int accumulate)
 {
-    __shared__ __align__(16) double lds[kNBuf * (kABuf + kBBuf)];      // 159,744 B of the CU's 160 KiB
+    using G = StageGeom<KB>;
+    constexpr int kKB = KB, kABuf = G::kA, kBBuf = G::kB, kDmaPerStage = G::kDma, kStoresPerDiagStage = G::kDiagStores;
+    constexpr int kDS = G::kDiagStages, kDT = G::kDiagTiles, kKS = G::kKS, kParts = G::kParts;
+    __shared__ __align__(16) double lds[kNBuf * (kABuf + kBBuf)];      // KB = 32: 159,744 B of the CU's 160 KiB
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -87,7 +104,7 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
     double *Vc = V + colw + lc;
     double *ldsB = lds + kNBuf * kABuf;
     const unsigned lds_byte0 = lds_byte_address(lds);      // LDS byte address of lds[0]
-    const double *ug = U + (int64_t)(wave * 8) * ldu + lane * 2;
+    const double *ug = U + (int64_t)(wave * G::kRA) * ldu + lane * 2;
     const double *vg = V + (int64_t)(lane >> 3) * ldv + colw + 2 * (lane & 7);
 
     // Sources of the stage the cursor points at (scalar bookkeeping, done off the MFMA path).  A cursor past
@@ -98,13 +115,13 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
     auto locate = [&](StageCursor &c) __attribute__((always_inline)) {
         const bool past = c.i0 >= n;
         const int ai0 = past ? n - kRB : c.i0;
-        const int aj = past ? (n - kRB) / kKB + 3 : c.j;
+        const int aj = past ? (n - kRB) / kKB + kDS - 1 : c.j;
         const int nreg = ai0 / kKB;
         c.a_src = ug + (int64_t)(kKB * aj) * ldu + ai0;
         // diagonal stage: the two 16x16 diagonal inverses go to the B region; regular stage: V rows
         // [32 aj, 32 aj + 32) of this wave's 16 columns
         const int64_t diag = (aj >= nreg) ? 1 : 0;
-        const int64_t off_diag = ((int64_t)(ai0 / 16) + 2 * (aj - nreg)) * 256;
+        const int64_t off_diag = ((int64_t)(ai0 / 16) + kDT * (aj - nreg)) * 256;
         const int64_t off_reg = (int64_t)(kKB * aj) * ldv;
         const uintptr_t base = (uintptr_t)vg + ((uintptr_t)inv_lane - (uintptr_t)vg) * (uintptr_t)diag;
         c.b_src = reinterpret_cast<const double *>(base) + (off_reg + (off_diag - off_reg) * diag);
@@ -114,12 +131,12 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
         const int wrap = (c.j + 1 == c.lim) ? 1 : 0;
         c.i0 += kRB * wrap;
         c.j = (c.j + 1) * (1 - wrap);
-        c.lim = c.lim + (c.i0 / kKB + 4 - c.lim) * wrap;
+        c.lim = c.lim + (c.i0 / kKB + kDS - c.lim) * wrap;
         locate(c);
     };
-    // the 12 LDS-DMA instructions of a stage, split so they can sit between MFMAs: pieces 0..3 -> 3 each
+    // the LDS-DMA instructions of a stage, split so they can sit between MFMAs: kParts groups of 3
     auto issue_part = [&](const StageCursor &c, int buf, int part) __attribute__((always_inline)) {
-        const unsigned la = __builtin_amdgcn_readfirstlane(lds_byte0 + 8u * (unsigned)(buf * kABuf + (wave * 8) * kLdsLd));
+        const unsigned la = __builtin_amdgcn_readfirstlane(lds_byte0 + 8u * (unsigned)(buf * kABuf + (wave * G::kRA) * kLdsLd));
         const unsigned lb = __builtin_amdgcn_readfirstlane(
             lds_byte0 + 8u * (unsigned)(kNBuf * kABuf + buf * kBBuf + wave * (kKB * 16)));
 #pragma unroll
@@ -131,7 +148,7 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
     };
     auto issue_stage = [&](const StageCursor &c, int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int part = 0; part < 4; ++part) issue_part(c, buf, part);
+        for (int part = 0; part < kParts; ++part) issue_part(c, buf, part);
     };
 
     // acc holds the NEGATED residual  L[blk, 0:k] V[0:k] - V[blk]  so the K-loop needs no operand negation
@@ -141,7 +158,7 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] = -Vc[(int64_t)(16 * t + kq + 4 * r) * ldv];
 
-    StageCursor ahead{0, 0, 4, nullptr, nullptr, 0};
+    StageCursor ahead{0, 0, kDS, nullptr, nullptr, 0};
     locate(ahead);
     issue_stage(ahead, 0);
     advance(ahead);
@@ -195,21 +212,21 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
             __builtin_amdgcn_sched_barrier(0);
             STAMP(4);
 #pragma unroll
-            for (int jj = 0; jj < 7; ++jj) {
+            for (int jj = 0; jj < kKS - 1; ++jj) {
 #pragma unroll
                 for (int t = 0; t < kT; ++t) af[(jj + 1) & 1][t] = abase[4 * (jj + 1) * kLdsLd + 16 * t];
                 bf[(jj + 1) & 1] = bbase[4 * (jj + 1) * 16];
-                if (jj < 4) issue_part(ahead, bnext, jj);                 // stage g+2's DMA rides under the MFMAs
-                if (jj == 4) advance(ahead);                              // cursor bookkeeping under the MFMAs too
+                if (jj < kParts) issue_part(ahead, bnext, jj);            // stage g+2's DMA rides under the MFMAs
+                if (jj == kParts) advance(ahead);                         // cursor bookkeeping under the MFMAs too
 #pragma unroll
                 for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[jj & 1][t], bf[jj & 1], acc[t]);
                 // pin "LDS reads of step jj+1, DMA, then the MFMAs of step jj": reads and DMA issue complete
                 // under the MFMAs
                 SCHED_DS(kT + 1);
-                if (jj < 4) { SCHED_VMEM(3); }
+                if (jj < kParts) { SCHED_VMEM(3); }
                 SCHED_MFMA(kT);
             }
-            deferred = true;                                              // k-step 7 sits in af[1], bf[1]
+            deferred = true;                                              // the last k-step sits in af[1], bf[1]
             STAMP(2);
             STAMP_NEXT();
             buf = (buf == 2) ? 0 : buf + 1;
@@ -219,9 +236,9 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
             for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
         }
 
-        // ---- four diagonal stages: X_s = inv(L_ss) R_s, then R_t -= L_ts X_s for the tiles below
+        // ---- diagonal stages (KB rows each): X_s = inv(L_ss) R_s, then R_t -= L_ts X_s for the tiles below
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < kDS; ++m) {
             STAMP(0);
             STAGE_TOP();
             STAMP(1);
@@ -234,12 +251,12 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
                     for (int r = 0; r < 4; ++r) accn[t][r] = -Vc[(int64_t)(i0 + kRB + 16 * t + kq + 4 * r) * ldv];
             }
             // z rows of this stage, fetched ahead of the DMA issue so they are older than it in vmcnt order
-            double zr[2][4];
+            double zr[kDT][4];
             if (SWEEP) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < kDT; ++h)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) zr[h][r] = z[i0 + 32 * m + 16 * h + kq + 4 * r];
+                    for (int r = 0; r < 4; ++r) zr[h][r] = z[i0 + kKB * m + 16 * h + kq + 4 * r];
                 asm volatile("" ::: "memory");
             }
             const int bnext = (buf >= 1) ? buf - 1 : 2;
@@ -249,20 +266,20 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
             const double *ibase = ldsB + buf * kBBuf + wave * (kKB * 16) + kq * 16 + lc;
             // every LDS operand of the stage is fetched up front: the X_s / update chain below is a string of
             // dependent MFMAs and must not wait for an LDS read in between
-            double iv[2][4], uf[2][kT][4];
+            double iv[kDT][4], uf[kDT][kT][4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < kDT; ++h) {
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) iv[h][kk] = ibase[h * 256 + 64 * kk];
 #pragma unroll
-                for (int t = 2 * m + h + 1; t < kT; ++t)
+                for (int t = kDT * m + h + 1; t < kT; ++t)
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) uf[h][t][kk] = abase[(16 * h + 4 * kk) * kLdsLd + 16 * t];
             }
             asm volatile("" ::: "memory");                    // keep the reads ahead of the chain
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int s = 2 * m + h;
+            for (int h = 0; h < kDT; ++h) {
+                const int s = kDT * m + h;
                 // two independent half-sums: a chain of dependent f64 MFMAs runs at about half the issue rate
                 d4 x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
                 x = MFMA_F64(iv[h][0], -acc[s][0], x);
@@ -304,22 +321,199 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
         macc += __shfl_xor(macc, 16);
         macc += __shfl_xor(macc, 32);
         if (kq == 0) {
-            q_out[colw + lc] = qacc;
-            mu_out[colw + lc] = macc;
+            // accumulate: the rows of this call are one panel of a sweep that is spread over several launches
+            q_out[colw + lc] = accumulate ? q_out[colw + lc] + qacc : qacc;
+            mu_out[colw + lc] = accumulate ? mu_out[colw + lc] + macc : macc;
         }
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Right-looking companion of the strip kernel, used when the sweep is pipelined with the factorisation
+// (launch_cholesky with a SweepPipe): once rows [k0, k0 + klen) of U and of V are final, every row block below
+// them receives its share of the substitution,
+//     C[i0 : i0+128, strip] -= U[k0 : k0+klen, i0 : i0+128]^T  V[k0 : k0+klen, strip],
+// so that by the time the factorisation reaches a block its right-hand sides only lack the in-block solve.
+// Same decomposition, LDS stages, DMA pipeline and MFMA order as the regular stages above (the k-loop of a block
+// is simply cut into the pieces [k0, k0+klen) and the partial sums rest in C between launches: fp64 either way,
+// the result is bit-identical to the left-looking kernel).  One workgroup = one strip x a chunk of row blocks;
+// chunks are short (tens of microseconds) so that the factorisation's own kernels, queued on a higher-priority
+// stream, find a free CU quickly.
+constexpr int kAccMoves = kT * 4;         // global loads (next block's C) or stores (this block's C) per lane and block
+
+// KB = rows of U / V per pipeline stage.  With KB = 16 a workgroup needs 79,872 B of LDS and 192 registers per
+// lane, so two workgroups share a CU (two waves per SIMD): while one waits at its stage barrier or for an LDS
+// read the other keeps the matrix pipe busy, and a workgroup's prologue/epilogue hides under its neighbour.
+template <int KB>
+__global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restrict__ U, int64_t ldu, double *V,
+                                                          int64_t ldv, int k0, int klen, int i0_begin, int i0_end,
+                                                          int chunk_rows)
+{
+    using G = StageGeom<KB>;
+    constexpr int kA = G::kA, kB = G::kB, kRA = G::kRA, kParts = G::kParts, kDma = G::kDma, kKS = G::kKS;
+    __shared__ __align__(16) double lds[kNBuf * (kA + kB)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, kq = lane >> 4;
+    const int64_t colw = (int64_t)blockIdx.x * kStrip + wave * 16;
+    const int ib = i0_begin + (int)blockIdx.y * chunk_rows;
+    const int ie = (ib + chunk_rows < i0_end) ? ib + chunk_rows : i0_end;
+    if (ib >= ie) return;                                              // uniform for the workgroup
+    const int nst = klen / KB;
+    double *Cc = V + colw + lc;
+    double *ldsB = lds + kNBuf * kA;
+    const unsigned lds_byte0 = lds_byte_address(lds);
+    const double *ug = U + (int64_t)(k0 + wave * kRA) * ldu + lane * 2;
+    const double *vg = V + (int64_t)(k0 + (lane >> 3)) * ldv + colw + 2 * (lane & 7);
+    const int64_t b_stride = 8 * ldv;
+
+    // stage cursor: (row block, KB-row slice of the panel); past the end it stays on the last stage
+    int ci0 = ib, cj = 0;
+    const double *a_src, *b_src;
+    auto locate = [&]() __attribute__((always_inline)) {
+        const bool past = ci0 >= ie;
+        const int ai0 = past ? ie - kRB : ci0;
+        const int aj = past ? nst - 1 : cj;
+        a_src = ug + (int64_t)(KB * aj) * ldu + ai0;
+        b_src = vg + (int64_t)(KB * aj) * ldv;
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        const int wrap = (cj + 1 == nst) ? 1 : 0;
+        ci0 += kRB * wrap;
+        cj = (cj + 1) * (1 - wrap);
+        locate();
+    };
+    auto issue_part = [&](int buf, int part) __attribute__((always_inline)) {
+        const unsigned la = __builtin_amdgcn_readfirstlane(lds_byte0 + 8u * (unsigned)(buf * kA + (wave * kRA) * kLdsLd));
+        const unsigned lb = __builtin_amdgcn_readfirstlane(
+            lds_byte0 + 8u * (unsigned)(kNBuf * kA + buf * kB + wave * (KB * 16)));
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = 2 * part + q;
+            glds16(a_src + (int64_t)p * ldu, la + 8u * (unsigned)(p * kLdsLd));
+        }
+        glds16(b_src + part * b_stride, lb + 8u * (unsigned)(part * 128));
+    };
+
+    // acc = -C (as in the strip kernel: the k-loop then needs no operand negation)
+    d4 acc[kT], accn[kT];
+#pragma unroll
+    for (int t = 0; t < kT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = -Cc[(int64_t)(ib + 16 * t + kq + 4 * r) * ldv];
+
+    locate();
+#pragma unroll
+    for (int part = 0; part < kParts; ++part) issue_part(0, part);
+    advance();
+#pragma unroll
+    for (int part = 0; part < kParts; ++part) issue_part(1, part);
+    advance();
+
+    int buf = 0;
+    // vmcnt bookkeeping (in-order retirement): at the top of a stage this wave's DMA of the stage must have
+    // landed; younger than it are the next stage's DMA instructions and, around a block boundary, the 32
+    // stores of the finished block and the 32 loads of the block after next -- never more than kDma + 32 that
+    // may still be in flight (see the order of issue below)
+    int boundary = 0;
+    for (int i0 = ib; i0 < ie; i0 += kRB) {
+        double af[2][kT], bf[2];
+        bool deferred = false;
+        for (int j = 0; j < nst; ++j) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (boundary) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma + kAccMoves) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma) : "memory");
+            __builtin_amdgcn_s_barrier();
+            boundary = (boundary > 0) ? boundary - 1 : 0;
+            if (j == 0 && i0 + kRB < ie) {
+                // next block's C, ahead of this stage's DMA in issue order
+#pragma unroll
+                for (int t = 0; t < kT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accn[t][r] = -Cc[(int64_t)(i0 + kRB + 16 * t + kq + 4 * r) * ldv];
+                asm volatile("" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int bnext = (buf >= 1) ? buf - 1 : 2;
+            const double *abase = lds + buf * kA + kq * kLdsLd + lc;
+            const double *bbase = ldsB + buf * kB + wave * (KB * 16) + kq * 16 + lc;
+#pragma unroll
+            for (int t = 0; t < kT; ++t) af[0][t] = abase[16 * t];
+            bf[0] = bbase[0];
+            if (deferred) {
+#pragma unroll
+                for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jj = 0; jj < kKS - 1; ++jj) {
+#pragma unroll
+                for (int t = 0; t < kT; ++t) af[(jj + 1) & 1][t] = abase[4 * (jj + 1) * kLdsLd + 16 * t];
+                bf[(jj + 1) & 1] = bbase[4 * (jj + 1) * 16];
+                if (jj < kParts) issue_part(bnext, jj);
+                if (jj == kParts) advance();
+#pragma unroll
+                for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[jj & 1][t], bf[jj & 1], acc[t]);
+                SCHED_DS(kT + 1);
+                if (jj < kParts) { SCHED_VMEM(3); }
+                SCHED_MFMA(kT);
+            }
+            deferred = true;                       // the last k-step sits in af[1], bf[1] (kKS is even)
+            buf = (buf == 2) ? 0 : buf + 1;
+        }
+#pragma unroll
+        for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
+#pragma unroll
+        for (int t = 0; t < kT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cc[(int64_t)(i0 + 16 * t + kq + 4 * r) * ldv] = -acc[t][r];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < kT; ++t) acc[t] = accn[t];
+        boundary = 2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const double *invDt, double *V, int64_t ldv,
-                        int64_t n, int64_t m_pad, const double *z, double *q, double *mu)
+                        int64_t n, int64_t m_pad, const double *z, double *q, double *mu, bool accumulate,
+                        bool half_lds)
 {
     if (n <= 0 || m_pad <= 0) return;
     // n is a multiple of 128 at every call site (n_pad of the sweep, the 128-row Cholesky panel)
     const dim3 grid((unsigned)(m_pad / kStrip));
-    if (q != nullptr)
-        hipLaunchKernelGGL(trsm_strip_kernel<true>, grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu);
+    const int acc = accumulate ? 1 : 0;
+    if (q != nullptr) {
+        if (half_lds)
+            hipLaunchKernelGGL((trsm_strip_kernel<true, 16>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, acc);
+        else
+            hipLaunchKernelGGL((trsm_strip_kernel<true, 32>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, acc);
+    } else {
+        if (half_lds)
+            hipLaunchKernelGGL((trsm_strip_kernel<false, 16>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, 0);
+        else
+            hipLaunchKernelGGL((trsm_strip_kernel<false, 32>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, 0);
+    }
+}
+
+void launch_trsm_update(hipStream_t s, const double *U, int64_t ldu, double *V, int64_t ldv, int k0, int klen,
+                        int i0_begin, int i0_end, int64_t m_pad, int chunk_blocks, bool half_lds)
+{
+    if (i0_begin >= i0_end || m_pad <= 0 || klen <= 0) return;
+    // klen is 128 or 256 (a multiple of the 32-row stage and at least two stages, which the vmcnt bookkeeping
+    // assumes), the row range a multiple of 128
+    const int chunk_rows = chunk_blocks * kRB;
+    const unsigned chunks = (unsigned)((i0_end - i0_begin + chunk_rows - 1) / chunk_rows);
+    const dim3 grid((unsigned)(m_pad / kStrip), chunks);
+    if (!half_lds)
+        hipLaunchKernelGGL(trsm_update_kernel<32>, grid, dim3(256), 0, s, U, ldu, V, ldv, k0, klen, i0_begin, i0_end,
+                           chunk_rows);
     else
-        hipLaunchKernelGGL(trsm_strip_kernel<false>, grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu);
+        hipLaunchKernelGGL(trsm_update_kernel<16>, grid, dim3(256), 0, s, U, ldu, V, ldv, k0, klen, i0_begin, i0_end,
+                           chunk_rows);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -60,9 +60,12 @@ class CausalExpectedImprovement:
         self.current_global_min = current_global_min
         self.task = task
 
-    def sweep(self, candidates, cost=1.0, want_acq=False, want_posterior=False):
+    def sweep(self, candidates, cost=1.0, want_acq=False, want_posterior=False, refit=False):
         """Score every candidate and pick the best: returns dict(best_val, best_idx, acq, mean, var).
-        ``candidates`` is a CandidateGrid (device resident) or an (M,d) array."""
+        ``candidates`` is a CandidateGrid (device resident) or an (M,d) array.  ``refit=True`` refits the model
+        from its resident data first, overlapped with the sweep (``cbo_gp_fit_sweep``): the pair of steps
+        ``CBO.intervene`` takes for the set it has just intervened on.  A model whose data were replaced with
+        ``set_data(..., fit=False)`` is refitted this way without being asked."""
         own = not isinstance(candidates, CandidateGrid)
         grid = CandidateGrid(candidates, self.model) if own else candidates
         m = len(grid)
@@ -71,11 +74,16 @@ class CausalExpectedImprovement:
         var = np.empty(m) if want_posterior else None
         best_val = ctypes.c_double(0.0)
         best_idx = ctypes.c_int64(-1)
-        try:
-            _lib.check(_lib.load().cbo_acq_sweep(
-                self.model._handle, grid._handle, float(np.asarray(self.current_global_min).reshape(-1)[0]),
+        args = (self.model._handle, grid._handle, float(np.asarray(self.current_global_min).reshape(-1)[0]),
                 _lib.TASK_CODE[self.task], float(self.jitter), float(cost), _lib.dptr(acq), _lib.dptr(mean),
-                _lib.dptr(var), ctypes.byref(best_val), ctypes.byref(best_idx)))
+                _lib.dptr(var), ctypes.byref(best_val), ctypes.byref(best_idx))
+        try:
+            if refit or self.model.stale:
+                tries, jitter = ctypes.c_int(0), ctypes.c_double(0.0)
+                _lib.check(_lib.load().cbo_gp_fit_sweep(*args, ctypes.byref(tries), ctypes.byref(jitter)))
+                self.model._note_jitter(tries.value, jitter.value)
+            else:
+                _lib.check(_lib.load().cbo_acq_sweep(*args))
         finally:
             if own:
                 grid.close()

@@ -70,6 +70,10 @@ int cbo_set_profiling(cbo_ctx *ctx, int enabled);
 int cbo_reset_timers(cbo_ctx *ctx);
 int cbo_get_timers(cbo_ctx *ctx, cbo_timers *out);
 int cbo_device_name(cbo_ctx *ctx, char *buf, int buflen);
+/* Device time (hipEvents on the ctx stream) of everything enqueued between the two calls; the work of the
+ * other streams a call uses joins the ctx stream before the call returns, so it is covered. */
+int cbo_region_begin(cbo_ctx *ctx);
+int cbo_region_end(cbo_ctx *ctx, double *ms_out);
 
 /* ---- GP model ----------------------------------------------------------------------------------
  * Replaces GaussianProcessFactory.create / create_non_causal_gp / create_causal_gp / create_graph_gp
@@ -95,6 +99,12 @@ int cbo_gp_fit(cbo_gp *gp, int *jitter_tries_out, double *jitter_out);
  * and refit. */
 int cbo_gp_set_data(cbo_gp *gp, int64_t n, const double *X, const double *y,
                     const double *prior_mean_X, const double *prior_var_X);
+
+/* The upload half of cbo_gp_set_data: replace the data and leave the model unfitted, for a caller that refits
+ * together with the next sweep (cbo_gp_fit_sweep).  Any call that needs the posterior returns
+ * CBO_ERR_NOT_FITTED until then. */
+int cbo_gp_upload_data(cbo_gp *gp, int64_t n, const double *X, const double *y,
+                       const double *prior_mean_X, const double *prior_var_X);
 
 /* GPyModelWrapper.predict -> GP.predict -> Posterior._raw_predict (called from
  * src/utils_functions/causal_acquisition_functions.py:33 and src/DoCalculus.py:77):
@@ -160,6 +170,15 @@ void cbo_cands_destroy(cbo_cands *c);
 int cbo_acq_sweep(cbo_gp *gp, cbo_cands *cands, double y_best, int task, double ei_jitter,
                   double cost, double *acq_out, double *mean_out, double *var_out, double *best_val,
                   int64_t *best_idx);
+
+/* Refit (as cbo_gp_fit, jitchol ladder included) and sweep (as cbo_acq_sweep) in one call, overlapped: the
+ * sweep's substitution advances panel by panel on a second stream while the factorisation's chain of short
+ * kernels runs.  This is the pair of calls CBO.intervene() makes for the set it has just intervened on
+ * (src/Monitor.py:160 set_data -> refit; src/CBO.py:250-257 find_next_y_point).  Same outputs as the two calls
+ * in sequence.  tries_out / jitter_out as in cbo_gp_fit (may be NULL). */
+int cbo_gp_fit_sweep(cbo_gp *gp, cbo_cands *cands, double y_best, int task, double ei_jitter, double cost,
+                     double *acq_out, double *mean_out, double *var_out, double *best_val,
+                     int64_t *best_idx, int *tries_out, double *jitter_out);
 
 /* Host-buffer convenience form of the same call (uploads Xs first). */
 int cbo_acq_sweep_host(cbo_gp *gp, int64_t m, const double *Xs, const double *prior_mean_s,

@@ -1,0 +1,21 @@
+"""Timeline of the last bench step from a rocprofv3 --kernel-trace csv: start/end/duration per kernel and queue."""
+import csv, sys, glob
+path = sys.argv[1] if len(sys.argv) > 1 else sorted(glob.glob("gpurun_out/ovtrace*/**/*_kernel_trace.csv", recursive=True))[-1]
+rows = list(csv.DictReader(open(path)))
+for r in rows:
+    r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+rows.sort(key=lambda r: r["s"])
+i0 = [i for i, r in enumerate(rows) if "rhs_kernel" in r["Kernel_Name"]][-1]
+t0 = rows[i0]["s"]
+def short(n):
+    for k in ("potrf_diag128", "syrk", "trsm_update", "trsm_strip_kernel<true>", "trsm_strip_kernel<false>", "kmat", "acq_kernel", "argmax", "rhs", "prep"):
+        if k in n:
+            return k
+    return n[:30]
+busy = {}
+for r in rows[i0 - 3:]:
+    k = short(r["Kernel_Name"])
+    busy[k] = busy.get(k, 0) + (r["e"] - r["s"]) / 1e3
+    if "-q" not in sys.argv:
+        print(f"{(r['s']-t0)/1e3:9.1f} {(r['e']-t0)/1e3:9.1f} {(r['e']-r['s'])/1e3:8.1f} q{r['Queue_Id']} {k} grid={r['Grid_Size_X']}x{r.get('Grid_Size_Y','')}")
+print({k: round(v, 1) for k, v in busy.items()})

@@ -1,16 +1,29 @@
-"""Extract FETCH_SIZE / WRITE_SIZE (KB, mean per dispatch) of the strip TRSM from the rocprofv3 --pmc passes
-(scripts/pmc_passes.sh output) into profiles/trsm_pmc.json, which bench.py reads for roofline.traffic."""
+"""HBM traffic from the rocprofv3 --pmc passes (scripts/pmc_passes.sh output) into profiles/pmc_traffic.json,
+which bench.py reads for roofline.traffic:
+  "step"         : FETCH_SIZE / WRITE_SIZE (KB) summed over every kernel dispatch of the run, divided by the
+                   number of steps (bench.py --steps 2 --warmup 1 --post-steps 0: three overlapped steps; the model is
+                   created unfitted, so nothing else launches kernels)
+  "strip_kernel" : mean per dispatch of trsm_strip_kernel<true, 32> from the --sequential passes
+Counter collection serialises the kernels; bytes per kernel do not depend on that."""
 import csv, glob, json, sys
-root = sys.argv[1]
-out = {}
-for name, key in (("fetch", "fetch_size_kb"), ("write", "write_size_kb")):
-    vals = []
-    for f in glob.glob(f"{root}/{name}/*/*counter_collection.csv"):
+root, dst = sys.argv[1], sys.argv[2]
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+def values(run, counter, pred):
+    out = []
+    for f in glob.glob(f"{root}/{run}/*/*counter_collection.csv"):
         for row in csv.DictReader(open(f)):
-            if "trsm_strip_kernel<true>" in row["Kernel_Name"] and row["Counter_Name"].startswith(name.upper()):
-                vals.append(float(row["Counter_Value"]))
-    out[key] = sum(vals) / len(vals)
-    out[key + "_dispatches"] = len(vals)
-out["note"] = "mean per dispatch of trsm_strip_kernel<true>, bench.py --steps 2 --warmup 1, N=4096 M=16384"
-json.dump(out, open(sys.argv[2], "w"), indent=1)
-print(out)
+            if row["Counter_Name"].startswith(counter) and pred(row["Kernel_Name"]):
+                out.append(float(row["Counter_Value"]))
+    return out
+res = {"step": {}, "strip_kernel": {}}
+for run, counter, key in (("fetch", "FETCH_SIZE", "fetch_size_kb"), ("write", "WRITE_SIZE", "write_size_kb")):
+    v = values(run, counter, lambda n: True)
+    res["step"][key] = sum(v) / steps
+    res["step"][key + "_dispatches_per_step"] = len(v) / steps
+    s = values(run + "_seq", counter, lambda n: "trsm_strip_kernel<true, 32>" in n or "trsm_strip_kernel<true,32>" in n)
+    if s:
+        res["strip_kernel"][key] = sum(s) / len(s)
+        res["strip_kernel"][key + "_dispatches"] = len(s)
+res["note"] = f"bench.py --steps 2 --warmup 1 --post-steps 0 ({steps} steps), N=4096 M=16384; KB as rocprofv3 reports"
+json.dump(res, open(dst, "w"), indent=1)
+print(json.dumps(res, indent=1))

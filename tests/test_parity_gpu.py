@@ -615,3 +615,113 @@ def test_bench_exchange_over_rccl_single_rank(hip):
     b = json.loads([l for l in launched.stdout.splitlines() if l.startswith("{")][-1])
     assert a["winner"] == b["winner"]
     assert b["n_gpus"] == 1 and b["roofline"]["frac"] > 0.3
+
+
+@pytest.mark.parametrize("n,m,d", [(100, 300, 2), (128, 64, 1), (129, 1000, 3), (257, 777, 3), (640, 2048, 3),
+                                   (1500, 4100, 4)])
+def test_overlapped_refit_sweep_equals_the_two_calls(hip, n, m, d):
+    """cbo_gp_fit_sweep (sweep pipelined under the factorisation, right-looking) against cbo_gp_fit followed by
+    cbo_acq_sweep (left-looking): the factor is the same code, V's per-element operation order is the same, q and
+    mu are summed panel-wise instead of in one chain -> values agree to rounding, same winner; both against the
+    oracle at the path's tolerance."""
+    from cbo_with_oop_amd import CandidateGrid, CausalExpectedImprovement
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    rng = np.random.default_rng(n + m)
+    X = rng.uniform(-3, 3, (n, d))
+    y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.standard_normal((n, 1))
+    Xs = rng.uniform(-3, 3, (m, d))
+    model = HipGaussianProcess(X, y, lengthscale=1.3, noise_var=1e-2)
+    ei = CausalExpectedImprovement(float(y.min()), "min", model)
+    grid = CandidateGrid(Xs, model)
+    a = ei.sweep(grid, cost=2.0, want_acq=True, want_posterior=True)
+    b = ei.sweep(grid, cost=2.0, want_acq=True, want_posterior=True, refit=True)
+    L_seq = model.posterior_state()[0]
+    assert b["best_idx"] == a["best_idx"]
+    np.testing.assert_allclose(b["mean"], a["mean"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(b["var"], a["var"], rtol=1e-11, atol=1e-15)
+    np.testing.assert_allclose(b["acq"], a["acq"], rtol=1e-9, atol=1e-300)
+    # the model left behind is a fitted one: a plain sweep after the overlapped call reproduces the first
+    c = ei.sweep(grid, cost=2.0, want_acq=True)
+    assert np.array_equal(c["acq"], a["acq"]) and c["best_idx"] == a["best_idx"]
+    assert np.array_equal(model.posterior_state()[0], L_seq)
+    post = O.fit(X, y, lengthscale=1.3, noise_var=1e-2)
+    mu, var = O.predict(post, Xs)
+    np.testing.assert_allclose(b["mean"], mu, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(b["var"], var, rtol=1e-5, atol=1e-10)
+
+
+def test_overlapped_refit_sweep_jitter_ladder_and_chunking(hip, monkeypatch):
+    """The overlapped call walks the same jitchol ladder (duplicate rows, no noise) and falls back to the plain
+    sequence when the candidates do not fit one workspace."""
+    import warnings
+    from cbo_with_oop_amd import CandidateGrid, CausalExpectedImprovement
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    f = load_fixture("jitter_ladder")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        model = make_model(hip, f)
+        tries_seq, jit_seq = model.jitter_tries, model.jitter
+        ei = CausalExpectedImprovement(float(f["y_best"]), "min", model)
+        a = ei.sweep(f["Xs"], want_acq=True)
+        b = ei.sweep(f["Xs"], want_acq=True, refit=True)
+    assert tries_seq >= 1 and (model.jitter_tries, model.jitter) == (tries_seq, jit_seq)
+    np.testing.assert_allclose(b["acq"], a["acq"], rtol=1e-8, atol=1e-300)
+    assert b["best_idx"] == a["best_idx"]
+
+
+def test_deferred_refit_is_transparent(hip):
+    """set_data(fit=False) / create(fit=False): the next sweep refits overlapped, any other consumer fits first;
+    results equal the eager path; a not-PD model raises at that use."""
+    from cbo_with_oop_amd import CausalExpectedImprovement, GaussianProcessFactory, GaussianProcessType
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    rng = np.random.default_rng(11)
+    X = rng.uniform(-2, 2, (300, 2)); y = np.cos(X[:, :1]) + 0.05 * rng.standard_normal((300, 1))
+    X2 = np.vstack([X, rng.uniform(-2, 2, (5, 2))]); y2 = np.vstack([y, rng.standard_normal((5, 1))])
+    Xs = rng.uniform(-2, 2, (500, 2))
+    eager = HipGaussianProcess(X, y, noise_var=1e-3)
+    eager.set_data(X2, y2)
+    lazy = HipGaussianProcess(X, y, noise_var=1e-3)
+    lazy.set_data(X2, y2, fit=False)
+    assert lazy.stale
+    a = CausalExpectedImprovement(0.0, "min", eager).sweep(Xs, want_acq=True)
+    b = CausalExpectedImprovement(0.0, "min", lazy).sweep(Xs, want_acq=True)
+    assert not lazy.stale and b["best_idx"] == a["best_idx"]
+    np.testing.assert_allclose(b["acq"], a["acq"], rtol=1e-9, atol=1e-300)
+    lazy.set_data(X, y, fit=False)
+    mu_l, var_l = lazy.predict(Xs)                      # a consumer other than the sweep fits first
+    mu_e, var_e = HipGaussianProcess(X, y, noise_var=1e-3).predict(Xs)
+    assert not lazy.stale and np.array_equal(mu_l, mu_e) and np.array_equal(var_l, var_e)
+    # construction without a fit, then the error of a hopeless matrix at first use
+    bad_x = np.zeros((8, 1)); bad_y = np.zeros((8, 1))
+    m = GaussianProcessFactory.create(GaussianProcessType.CAUSAL_GP, bad_x, bad_y,
+                                      [lambda a: np.zeros((len(a), 1)), lambda a: -2.0 * np.ones((len(a), 1))], fit=False)
+    with pytest.raises(np.linalg.LinAlgError):
+        CausalExpectedImprovement(0.0, "min", m).sweep(np.ones((4, 1)))
+
+
+def test_path_with_deferred_refit_takes_the_same_decisions(hip):
+    from cbo_with_oop_amd import CBOAcquisitionPath, GaussianProcessType
+    from cbo_with_oop_amd.graphs import ToyGraph
+    rng = np.random.default_rng(3)
+    es = ToyGraph.get_exploration_set("MIS")
+    picks = []
+    for lazy in (False, True):
+        xs = [rng.uniform(-5, 5, (40, 1)), rng.uniform(-5, 20, (40, 1))] if not picks else [x.copy() for x in xs0]
+        xs0 = [x.copy() for x in xs]
+        ys = [ToyGraph.target_do_x(xs[0]), ToyGraph.target_do_z(xs[1])]
+        path = CBOAcquisitionPath(GaussianProcessType.NON_CAUSAL_GP, es, ToyGraph.get_cost_structure(1), "min", xs, ys,
+                                  [ToyGraph.bounds(s) for s in es], grid_shapes=[[300], [300]])
+        path.update_all_gaussian_processes()
+        best = min(float(ys[0].min()), float(ys[1].min()))
+        trace = []
+        for _ in range(4):
+            xn, yn = path.compute_best_acquisition_values(best)
+            _, s = path.select_next_intervention(yn)
+            target = ToyGraph.target_do_x if s == 0 else ToyGraph.target_do_z
+            path.data_x[s] = np.vstack([path.data_x[s], xn[s]]); path.data_y[s] = np.vstack([path.data_y[s], target(xn[s])])
+            best = min(best, float(path.data_y[s][-1, 0]))
+            path.update_gaussian_process_of_last_intervention(fit=not lazy)
+            trace.append((s, float(xn[s][0, 0])))
+        picks.append(trace)
+    assert [t[0] for t in picks[0]] == [t[0] for t in picks[1]]
+    np.testing.assert_allclose([t[1] for t in picks[0]], [t[1] for t in picks[1]], rtol=0, atol=1e-12)
