@@ -266,7 +266,8 @@ class HipGaussianProcess:
     # -- lifetime ------------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:
-            self._lib.cbo_gp_destroy(self._handle)
+            if not self._ctx.closed:               # after cbo_shutdown the device memory is gone with the context
+                self._lib.cbo_gp_destroy(self._handle)
             self._handle = ctypes.c_void_p()
 
     def __del__(self):

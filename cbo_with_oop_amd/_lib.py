@@ -2,9 +2,11 @@
 library is missing, or no gfx950 GPU is visible when a context is requested, this raises."""
 from __future__ import annotations
 
+import atexit
 import ctypes
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -170,6 +172,7 @@ def as_f64(a, shape=None):
 class Context:
     """One HIP device + stream (cbo_ctx).  Contexts are cached per device id."""
     _cache = {}
+    _live = weakref.WeakSet()      # every context not yet shut down, cached or not
 
     def __init__(self, device_id=0):
         lib = load()
@@ -177,6 +180,16 @@ class Context:
         check(lib.cbo_init(int(device_id), ctypes.byref(h)))
         self.handle = h
         self.device_id = int(device_id)
+        self.closed = False
+        Context._live.add(self)
+
+    def close(self):
+        """cbo_shutdown.  Handles created on this context must not be used (or destroyed) afterwards; the
+        wrappers check ``closed`` before they free anything."""
+        if not self.closed:
+            self.closed = True
+            load().cbo_shutdown(self.handle)
+            self.handle = None
 
     @classmethod
     def get(cls, device_id=None):
@@ -222,6 +235,18 @@ class Context:
         err = ctypes.c_double(-1.0)
         check(load().cbo_selftest_mfma(self.handle, ctypes.byref(err)))
         return err.value
+
+
+@atexit.register
+def _close_contexts():
+    # Tear the device state down while the HIP runtime is still fully alive: streams created with a CU mask that
+    # survive into the runtime's own exit handlers crash profiling tools that hook finalisation (rocprofv3).
+    for ctx in list(Context._live):
+        try:
+            ctx.close()
+        except Exception:
+            pass
+    Context._cache.clear()
 
 
 def device_count():

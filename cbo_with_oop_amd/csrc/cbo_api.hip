@@ -203,10 +203,17 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
         std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
         for (int b = 0; b < n_cu; ++b)
             if (b / 8 >= reserve) mask[(size_t)b / 32] |= 1u << (b % 32);
+        bool masked = false;
         if (reserve > 0 && reserve * 8 < n_cu) {
-            e = hipExtStreamCreateWithCUMask(&c->sweep_stream, (uint32_t)mask.size(), mask.data());
-            if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->bulk_stream, (uint32_t)mask.size(), mask.data());
-        } else {
+            masked = hipExtStreamCreateWithCUMask(&c->sweep_stream, (uint32_t)mask.size(), mask.data()) == hipSuccess &&
+                     hipExtStreamCreateWithCUMask(&c->bulk_stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+            if (!masked) {                       // no CU masking on this stack: plain lower-priority streams instead
+                (void)hipGetLastError();
+                if (c->sweep_stream) { hipStreamDestroy(c->sweep_stream); c->sweep_stream = nullptr; }
+                if (c->bulk_stream) { hipStreamDestroy(c->bulk_stream); c->bulk_stream = nullptr; }
+            }
+        }
+        if (!masked) {
             e = hipStreamCreateWithPriority(&c->sweep_stream, hipStreamNonBlocking, (prio_low + prio_high) / 2);
             if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->bulk_stream, hipStreamNonBlocking, prio_low);
         }

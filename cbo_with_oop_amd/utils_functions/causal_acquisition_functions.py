@@ -42,7 +42,8 @@ class CandidateGrid:
 
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:
-            self._lib.cbo_cands_destroy(self._handle)
+            if not self._ctx.closed:
+                self._lib.cbo_cands_destroy(self._handle)
             self._handle = ctypes.c_void_p()
 
     def __del__(self):

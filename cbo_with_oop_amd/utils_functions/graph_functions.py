@@ -112,7 +112,7 @@ class DeviceSEM:
 
     def __del__(self):
         h, self._handle = getattr(self, "_handle", None), None
-        if h:
+        if h and not self.ctx.closed:
             try:
                 self._lib.cbo_sem_destroy(h)
             except Exception:

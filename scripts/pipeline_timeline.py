@@ -8,7 +8,7 @@ rows.sort(key=lambda r: r["s"])
 i0 = [i for i, r in enumerate(rows) if "rhs_kernel" in r["Kernel_Name"]][-1]
 t0 = rows[i0]["s"]
 def short(n):
-    for k in ("potrf_diag128", "syrk", "trsm_update", "trsm_strip_kernel<true>", "trsm_strip_kernel<false>", "kmat", "acq_kernel", "argmax", "rhs", "prep"):
+    for k in ("potrf_diag128", "syrk", "trsm_update", "trsm_strip_kernel<true", "trsm_strip_kernel<false", "kmat", "acq_kernel", "argmax", "rhs", "prep"):
         if k in n:
             return k
     return n[:30]
