@@ -273,6 +273,15 @@ def test_full_size_properties(hip):
     assert np.array_equal(va, vb) and np.array_equal(va, full["var"][::16])
     # (5) variances are within [noise, prior]
     assert full["var"].min() >= 1e-10 and full["var"].max() <= 1.0 + 1e-10 + 1e-12
+    # (6) refit + sweep as ONE overlapped call (what bench.py times) against the two calls above, full size:
+    #     same winner; q = sum V^2 and mu = V^T z are summed panel-wise there, so values agree to rounding
+    fused = ei.sweep(Xs, cost=3.0, want_acq=True, want_posterior=True, refit=True)
+    assert fused["best_idx"] == full["best_idx"]
+    # var = kss - q with q ~ 1 summed over 4096 rows: a different grouping of that sum moves var by ~1e-14 absolute
+    assert np.allclose(fused["var"], full["var"], rtol=1e-9, atol=2e-13)
+    assert np.allclose(fused["mean"], full["mean"], rtol=0, atol=1e-11 * np.max(np.abs(y)))
+    again = ei.sweep(Xs, cost=3.0, want_acq=True, want_posterior=True, refit=True)
+    assert np.array_equal(again["acq"], fused["acq"])         # the overlapped schedule does not leak into the bits
 
 
 # ---------------------------------------------------------------------------------- edge cases
