@@ -8,7 +8,9 @@ from __future__ import annotations
 import numpy as np
 
 from .GaussianProcessFactory import GaussianProcessFactory as GPFactory
-from .utils_functions.utils import find_current_global, find_next_y_point
+from .graphs import meshgrid_candidates
+from .utils_functions.causal_acquisition_functions import CandidateGrid
+from .utils_functions.utils import default_grid_shape, find_current_global, find_next_y_point, space_bounds
 
 
 class CBOAcquisitionPath:
@@ -30,9 +32,11 @@ class CBOAcquisitionPath:
         self.intervention_names = ["".join(v) for v in exploration_set]
         self.models = []
         self.last_intervention = None
+        self._grids = {}          # per set: (grid shape, prior closures, device-resident candidate grid)
 
     def update_all_gaussian_processes(self):
         """CBO.py:209-222."""
+        self._grids.clear()
         self.models = [
             GPFactory.create(self.gp_type, self.data_x[s], self.data_y[s],
                              [self.mean_functions[s], self.var_functions[s]], emukit_wrapper=True)
@@ -44,15 +48,36 @@ class CBOAcquisitionPath:
         comes next (CBO.py:152-164) and its sweep over this set refits and sweeps in one overlapped device call.
         ``fit=True`` restores the reference's timing (a not-PD error then surfaces here)."""
         s = self.last_intervention
+        model = self.models[s]
+        if model is not None and model.mean_function is self.mean_functions[s] \
+                and model.variance_adjustment is self.var_functions[s]:
+            model.rebuild(self.data_x[s], self.data_y[s], fit=fit)      # same handle: no allocation, no new grid
+            return
+        self._grids.pop(s, None)
         self.models[s] = GPFactory.create(self.gp_type, self.data_x[s], self.data_y[s],
                                           [self.mean_functions[s], self.var_functions[s]], emukit_wrapper=True, fit=fit)
+
+    def candidate_grid(self, s):
+        """The regular grid over the set's box, resident on the device across trials (the reference draws fresh
+        random anchors each trial; the grid of BASELINE.json's sweep is fixed).  Rebuilt when the grid shape, the
+        model object or the prior closures change."""
+        bounds = space_bounds(self.space_list[s])
+        shape = tuple(self.grid_shapes[s] or default_grid_shape(len(bounds)))
+        key = (shape, id(self.models[s]), id(self.mean_functions[s]), id(self.var_functions[s]))
+        cached = self._grids.get(s)
+        if cached is None or cached[0] != key:
+            if cached is not None:
+                cached[1].close()
+            cached = (key, CandidateGrid(meshgrid_candidates(bounds, shape), self.models[s]))
+            self._grids[s] = cached
+        return cached[1]
 
     def compute_best_acquisition_values(self, current_best):
         """CBO.py:237-260."""
         xs, ys = [], []
         for s in range(len(self.exploration_set)):
             y, x = find_next_y_point(self.space_list[s], self.models[s], current_best, self.exploration_set[s],
-                                     self.costs, task=self.task, grid_shape=self.grid_shapes[s])
+                                     self.costs, task=self.task, candidates=self.candidate_grid(s))
             ys.append(y)
             xs.append(x)
         return xs, ys

@@ -74,6 +74,7 @@ class HipGaussianProcess:
             self._ctx.handle, 0, self.X.shape[0], self.input_dim, _lib.dptr(self.X), _lib.dptr(self._y_flat),
             _lib.dptr(pm), _lib.dptr(pv), self.variance, _lib.dptr(self.lengthscale), int(self.ard), self.noise_var,
             int(self.zero_diag), ctypes.byref(self._handle)))
+        self._initial_hyper = (self.variance, self.lengthscale.copy(), self.noise_var)
         if fit:
             self._fit()
         else:
@@ -189,15 +190,28 @@ class HipGaussianProcess:
         _lib.check(self._lib.cbo_gp_log_marginal(self._handle, ctypes.byref(out)))
         return out.value
 
-    def set_hyperparameters(self, variance, lengthscale, noise_var):
-        """Replace kernel variance, lengthscale(s) and Gaussian noise variance and refit."""
+    def set_hyperparameters(self, variance, lengthscale, noise_var, fit=True):
+        """Replace kernel variance, lengthscale(s) and Gaussian noise variance and refit (``fit=False``: the next
+        use refits, as with ``set_data``)."""
         ls = np.atleast_1d(np.asarray(lengthscale, dtype=np.float64))
         if self.ard and ls.size == 1:
             ls = np.full(self.input_dim, ls[0])
         ls = np.ascontiguousarray(ls)
         _lib.check(self._lib.cbo_gp_set_hyper(self._handle, float(variance), _lib.dptr(ls), float(noise_var)))
         self.variance, self.lengthscale, self.noise_var = float(variance), ls, float(noise_var)
-        self._fit()
+        if fit:
+            self._fit()
+        else:
+            self.stale = True
+
+    def rebuild(self, X, Y, fit=True):
+        """What the reference obtains by constructing a NEW model on new data (src/CBO.py:224-235 builds one each
+        trial): the hyper-parameters the constructor was given, the new data.  Same device handle and buffers, so
+        nothing is allocated when the padded size does not change."""
+        v0, ls0, nv0 = self._initial_hyper
+        if (self.variance, self.noise_var) != (v0, nv0) or not np.array_equal(self.lengthscale, ls0):
+            self.set_hyperparameters(v0, ls0, nv0, fit=False)
+        self.set_data(X, Y, fit=fit)
 
     def _objective(self, log_theta):
         """Negative log marginal likelihood at exp(log_theta) = [variance, lengthscale(s), (noise)]."""

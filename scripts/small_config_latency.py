@@ -33,3 +33,9 @@ for name, fn in (("gpu path", gpu_pass), ("cpu oracle", cpu_pass)):
     for _ in range(n): r = fn()
     dt = (time.perf_counter() - t0) / n
     print(f"{name}: {dt*1e3:.3f} ms per pass -> {400/dt:,.0f} acquisitions/s  (choice {r})")
+if "--profile" in sys.argv:
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(200): gpu_pass()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
