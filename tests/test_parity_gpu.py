@@ -676,6 +676,17 @@ def test_overlapped_refit_sweep_jitter_ladder_and_chunking(hip, monkeypatch):
     assert tries_seq >= 1 and (model.jitter_tries, model.jitter) == (tries_seq, jit_seq)
     np.testing.assert_allclose(b["acq"], a["acq"], rtol=1e-8, atol=1e-300)
     assert b["best_idx"] == a["best_idx"]
+    # candidates that need several workspace chunks: the call degrades to fit-then-sweep, bit-identical to it
+    from cbo_with_oop_amd import _lib
+    g = load_fixture("coral_max_d3")
+    monkeypatch.setenv("CBO_HIP_WORKSPACE_MB", "1")
+    small = _lib.Context(0)
+    m2 = HipGaussianProcess(g["X"], g["y"], context=small)
+    ei2 = CausalExpectedImprovement(float(g["y_best"]), "min", m2)
+    two = ei2.sweep(g["Xs"], want_acq=True)
+    one = ei2.sweep(g["Xs"], want_acq=True, refit=True)
+    assert np.array_equal(one["acq"], two["acq"]) and one["best_idx"] == two["best_idx"]
+    small.close()
 
 
 def test_deferred_refit_is_transparent(hip):
