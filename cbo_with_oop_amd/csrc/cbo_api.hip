@@ -45,6 +45,9 @@ struct cbo_ctx {
     hipEvent_t region_a = nullptr, region_b = nullptr;
     int pipe_chunk_blocks = 2;
     bool pipe_half_lds = true;
+    int n_cu = 256;
+    int sweep_mode = -1;             // CBO_HIP_SWEEP: 0 = always left-looking, 1 = always right-looking, else automatic
+    int overlap_mode = -1;           // CBO_HIP_OVERLAP: 0 = cbo_gp_fit_sweep never overlaps, 1 = always, else automatic
     bool profiling = false;
     std::vector<EventPair> pending;
     std::vector<hipEvent_t> pool;
@@ -56,7 +59,7 @@ struct cbo_ctx {
     double *best_val = nullptr; int64_t *best_idx = nullptr;   // device
     double *h_best_val = nullptr; int64_t *h_best_idx = nullptr; // pinned host
     int *h_info = nullptr;
-    size_t max_ws_bytes = (size_t)4 << 30;
+    size_t max_ws_bytes = (size_t)32 << 30;   // V workspace cap: 288 GB of HBM per GPU, one chunk whenever possible
     char name[128] = {0};
 };
 
@@ -236,6 +239,11 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
     if (ws) c->max_ws_bytes = (size_t)std::atoll(ws) << 20;
     const char *cb = std::getenv("CBO_HIP_PIPE_CHUNK");
     if (cb && std::atoi(cb) >= 1) c->pipe_chunk_blocks = std::atoi(cb);
+    c->n_cu = prop.multiProcessorCount;
+    const char *sm = std::getenv("CBO_HIP_SWEEP");
+    if (sm) c->sweep_mode = std::atoi(sm);
+    const char *om = std::getenv("CBO_HIP_OVERLAP");
+    if (om) c->overlap_mode = std::atoi(om);
     const char *kb = std::getenv("CBO_HIP_PIPE_KB");
     if (kb && std::atoi(kb) == 32) c->pipe_half_lds = false;
     *out = c;
@@ -677,6 +685,72 @@ static int prepare_cands(cbo_gp *g, cbo_cands *k)
     return CBO_OK;
 }
 
+// timers of the right-looking sweep: one event pair per launch on the stream it goes to
+static void pipe_mark(void *user, hipStream_t st, int begin, double flops)
+{
+    cbo_ctx *c = static_cast<cbo_ctx *>(user);
+    if (!c->profiling) return;
+    static thread_local EventPair cur;
+    if (begin) {
+        cur.a = get_event(c);
+        cur.b = get_event(c);
+        cur.phase = PH_TRSM;
+        hipEventRecord(cur.a, st);
+        c->timers.n_trsm_launches += 1;
+        c->timers.trsm_flops += flops;
+    } else {
+        hipEventRecord(cur.b, st);
+        c->pending.push_back(cur);
+    }
+}
+
+static SweepPipe make_pipe(cbo_gp *g, double *V, int64_t ldv, int64_t cols, double *q, double *mu)
+{
+    cbo_ctx *c = g->ctx;
+    SweepPipe pipe{};
+    pipe.stream = c->sweep_stream;
+    pipe.bulk = c->bulk_stream;
+    pipe.V = V; pipe.ldv = ldv; pipe.m_pad = cols;
+    pipe.zvec = g->z; pipe.q = q; pipe.mu = mu;
+    pipe.chunk_blocks = c->pipe_chunk_blocks;
+    pipe.half_lds = c->pipe_half_lds;
+    pipe.events = &c->pipe_events;
+    pipe.mark = pipe_mark; pipe.user = c;
+    return pipe;
+}
+
+// Which schedule for a sweep of `cols` candidate columns against a factor that is already complete?
+// The left-looking strip kernel is the more efficient one (no read-modify-write of V, no launch chain) but it
+// has one workgroup per 64 columns: its time is whole rounds of n_cu strips.  The right-looking schedule
+// (strip kernel on a panel pair, then trsm_update_kernel over strips x row chunks, pair after pair) fills the
+// device whatever the column count and costs about a sixth more per column.  Same bits either way.
+static bool prefer_right_looking(const cbo_ctx *c, int64_t n_pad, int64_t cols)
+{
+    if (c->sweep_mode == 0) return false;
+    if (c->sweep_mode == 1) return true;
+    if (n_pad < 1024) return false;
+    const int64_t strips = cols / kStrip;
+    const int64_t rounds = (strips + c->n_cu - 1) / c->n_cu;
+    return rounds * c->n_cu * 5 >= strips * 6;
+}
+
+static int enqueue_right_looking(cbo_gp *g, double *V, int64_t ldv, int64_t cols, double *q, double *mu)
+{
+    cbo_ctx *c = g->ctx;
+    const SweepPipe pipe = make_pipe(g, V, ldv, cols, q, mu);
+    HIP_TRY(hipMemsetAsync(q, 0, sizeof(double) * cols, c->stream));
+    HIP_TRY(hipMemsetAsync(mu, 0, sizeof(double) * cols, c->stream));
+    int p = 0;
+    for (int r0 = 0; r0 < (int)g->n_pad; r0 += 256, ++p)
+        sweep_pipe_pair(pipe, c->stream, g->A, g->lda, g->invDt, g->n_pad, p, r0,
+                        (r0 + 256 <= (int)g->n_pad) ? 256 : 128);
+    HIP_TRY(hipEventRecord(c->ev_join, c->sweep_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    HIP_TRY(hipEventRecord(c->ev_join2, c->bulk_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
+    return CBO_OK;
+}
+
 // q = colsum((L^-1 K*)^2), mu = (L^-1 K*)^T z for all candidates, chunk by chunk.
 static int enqueue_posterior(cbo_gp *g, cbo_cands *k)
 {
@@ -691,6 +765,11 @@ static int enqueue_posterior(cbo_gp *g, cbo_cands *k)
         {
             PhaseScope ps(c, PH_KSTAR);
             launch_kstar(c->stream, g->X, k->P, c0, cols, g->h, c->V, ldv, g->n_pad);
+        }
+        if (prefer_right_looking(c, g->n_pad, cols)) {
+            rc = enqueue_right_looking(g, c->V, ldv, cols, c->q + c0, c->mu + c0);
+            if (rc != CBO_OK) return rc;
+            continue;
         }
         {
             PhaseScope ps(c, PH_TRSM);
@@ -760,25 +839,6 @@ extern "C" int cbo_acq_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task, d
     return finish_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
 }
 
-// timers of the pipelined sweep: one event pair per launch on the sweep stream
-static void pipe_mark(void *user, hipStream_t st, int begin, double flops)
-{
-    cbo_ctx *c = static_cast<cbo_ctx *>(user);
-    if (!c->profiling) return;
-    static thread_local EventPair cur;
-    if (begin) {
-        cur.a = get_event(c);
-        cur.b = get_event(c);
-        cur.phase = PH_TRSM;
-        hipEventRecord(cur.a, st);
-        c->timers.n_trsm_launches += 1;
-        c->timers.trsm_flops += flops;
-    } else {
-        hipEventRecord(cur.b, st);
-        c->pending.push_back(cur);
-    }
-}
-
 // Refit and sweep in one call, the two overlapped: what CBO.intervene() does for the set it has just
 // intervened on (set_data -> refit, then find_next_y_point -> acquisition over the candidates,
 // /root/reference/src/Monitor.py:160, src/CBO.py:250-257).  The factorisation is a chain of short kernels
@@ -805,16 +865,18 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
         if (rc != CBO_OK) return rc;
         return cbo_acq_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
     }
+    // overlapping pays while the factorisation's chain is a sizeable part of the step and the sweep's
+    // read-modify-write of V still fits the caches' appetite (scripts/overlap_crossover.py); otherwise the plain
+    // sequence, whose sweep picks its own schedule
+    const bool overlap = c->overlap_mode == 1 ||
+                         (c->overlap_mode != 0 && g->n_pad >= 1024 && (double)g->n_pad * (double)k->m_pad <= 1.5e8);
+    if (!overlap) {
+        rc = cbo_gp_fit(g, tries_out, jitter_out);
+        if (rc != CBO_OK) return rc;
+        return cbo_acq_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
+    }
     g->fitted = false;
-    SweepPipe pipe{};
-    pipe.stream = c->sweep_stream;
-    pipe.bulk = c->bulk_stream;
-    pipe.V = c->V; pipe.ldv = ldv; pipe.m_pad = k->m_pad;
-    pipe.zvec = g->z; pipe.q = c->q; pipe.mu = c->mu;
-    pipe.chunk_blocks = c->pipe_chunk_blocks;
-    pipe.half_lds = c->pipe_half_lds;
-    pipe.events = &c->pipe_events;
-    pipe.mark = pipe_mark; pipe.user = c;
+    const SweepPipe pipe = make_pipe(g, c->V, ldv, k->m_pad, c->q, c->mu);
     double jitter = 0.0;
     int tries = 0;
     for (;;) {

@@ -170,7 +170,10 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
 #endif
     int buf = 0;                 // buffer of the current stage; stage g+2 goes to (buf + 2) % 3
     int extra_prev = 0;          // VMEM operations the previous stage issued after its DMA (its V stores)
-    double qacc = 0.0, macc = 0.0;
+    // q = sum V^2 and mu = V^T z: lane partials over a PAIR of row blocks (256 rows), reduced over the four
+    // lane groups and added to a running total pair by pair -- the grouping the right-looking pipeline produces
+    // naturally (one launch of this kernel per pair, accumulate = 1), so both schedules give the same bits
+    double qacc = 0.0, macc = 0.0, qtot = 0.0, mtot = 0.0;
 
     // top of a stage: this wave's DMA of the stage has landed once only the next stage's 12 DMA instructions
     // (plus whatever the previous stage issued after them) are outstanding -- vmcnt retires in order; the
@@ -310,20 +313,26 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
         }
 #pragma unroll
         for (int t = 0; t < kT; ++t) acc[t] = accn[t];
+        if (SWEEP && (((i0 / kRB) & 1) || i0 + kRB >= n)) {
+            qacc += __shfl_xor(qacc, 16);
+            qacc += __shfl_xor(qacc, 32);
+            macc += __shfl_xor(macc, 16);
+            macc += __shfl_xor(macc, 32);
+            qtot += qacc;
+            mtot += macc;
+            qacc = 0.0;
+            macc = 0.0;
+        }
     }
 #undef STAGE_TOP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the clamped tail DMA before the LDS goes away
     __builtin_amdgcn_s_barrier();
 
     if (SWEEP) {
-        qacc += __shfl_xor(qacc, 16);
-        qacc += __shfl_xor(qacc, 32);
-        macc += __shfl_xor(macc, 16);
-        macc += __shfl_xor(macc, 32);
         if (kq == 0) {
-            // accumulate: the rows of this call are one panel of a sweep that is spread over several launches
-            q_out[colw + lc] = accumulate ? q_out[colw + lc] + qacc : qacc;
-            mu_out[colw + lc] = accumulate ? mu_out[colw + lc] + macc : macc;
+            // accumulate: the rows of this call are one panel pair of a sweep that is spread over several launches
+            q_out[colw + lc] = accumulate ? q_out[colw + lc] + qtot : qtot;
+            mu_out[colw + lc] = accumulate ? mu_out[colw + lc] + mtot : mtot;
         }
     }
 }
