@@ -9,7 +9,7 @@ from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
 lib, ctx = _lib.load(), _lib.Context.get()
 rng = np.random.default_rng(0)
 bv, bi = ctypes.c_double(), ctypes.c_int64()
-sizes = [(512, 16384), (1024, 16384), (2048, 16384), (4096, 4096), (4096, 16384), (4096, 65536), (8192, 16384), (8192, 65536), (12288, 32768)]
+sizes = [(512, 16384), (1024, 16384), (2048, 16384), (4096, 200), (4096, 4096), (4096, 12288), (4096, 16384), (4096, 20480), (4096, 32768), (4096, 65536), (8192, 16384), (8192, 65536)]
 for n, mm in sizes:
     X = rng.uniform(-5, 5, (n, 3)); y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.standard_normal((n, 1))
     Xs = rng.uniform(-5, 5, (mm, 3))
@@ -20,13 +20,15 @@ for n, mm in sizes:
     def two():
         _lib.check(lib.cbo_gp_fit(m._handle, None, None))
         _lib.check(lib.cbo_acq_sweep(m._handle, g._handle, float(y.min()), 0, 0.0, 3.0, None, None, None, ctypes.byref(bv), ctypes.byref(bi)))
+    def sweep_only():
+        _lib.check(lib.cbo_acq_sweep(m._handle, g._handle, float(y.min()), 0, 0.0, 3.0, None, None, None, ctypes.byref(bv), ctypes.byref(bi)))
     out = []
-    for fn in (fused, two):
+    for fn in (fused, two, sweep_only):
         fn(); fn(); ctx.synchronize()
         reps = 5 if n <= 4096 else 2
         t0 = time.perf_counter()
         for _ in range(reps): fn()
         ctx.synchronize()
         out.append((time.perf_counter() - t0) / reps * 1e3)
-    print(f"N={n:6d} M={mm:6d}: overlapped {out[0]:8.2f} ms, two calls {out[1]:8.2f} ms, ratio {out[1]/out[0]:.3f}", flush=True)
+    print(f"N={n:6d} M={mm:6d}: fit_sweep {out[0]:8.2f} ms, two calls {out[1]:8.2f} ms, ratio {out[1]/out[0]:.3f}; sweep alone {out[2]:8.2f} ms", flush=True)
     g.close(); m.close()
