@@ -45,6 +45,7 @@ struct cbo_ctx {
     hipEvent_t region_a = nullptr, region_b = nullptr;
     int pipe_chunk_blocks = 2;
     bool pipe_half_lds = true;
+    double pipe_tail_frac = -1.0;    // CBO_HIP_PIPE_TAIL: rows (fraction) left to the closing left-looking launch; < 0 = automatic
     int n_cu = 256;
     int sweep_mode = -1;             // CBO_HIP_SWEEP: 0 = always left-looking, 1 = always right-looking, else automatic
     int overlap_mode = -1;           // CBO_HIP_OVERLAP: 0 = cbo_gp_fit_sweep never overlaps, 1 = always, else automatic
@@ -199,7 +200,7 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
     // CU's LDS and would otherwise wait behind a queue of half-LDS sweep workgroups that keep every CU partly
     // occupied.  CU-mask bit b is CU b/8 of XCD b%8 on this device (scripts/probes/cumask_probe.hip).
     if (e == hipSuccess) {
-        int reserve = 1;
+        int reserve = 4;
         const char *rv = std::getenv("CBO_HIP_PIPE_RESERVE");
         if (rv) reserve = std::atoi(rv);
         const int n_cu = prop.multiProcessorCount;
@@ -244,6 +245,8 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
     if (sm) c->sweep_mode = std::atoi(sm);
     const char *om = std::getenv("CBO_HIP_OVERLAP");
     if (om) c->overlap_mode = std::atoi(om);
+    const char *tf = std::getenv("CBO_HIP_PIPE_TAIL");
+    if (tf) c->pipe_tail_frac = std::atof(tf);
     const char *kb = std::getenv("CBO_HIP_PIPE_KB");
     if (kb && std::atoi(kb) == 32) c->pipe_half_lds = false;
     *out = c;
@@ -716,6 +719,7 @@ static SweepPipe make_pipe(cbo_gp *g, double *V, int64_t ldv, int64_t cols, doub
     pipe.half_lds = c->pipe_half_lds;
     pipe.events = &c->pipe_events;
     pipe.mark = pipe_mark; pipe.user = c;
+    pipe.tail_begin = (int)g->n_pad;                     // no tail unless the caller sets one
     return pipe;
 }
 
@@ -732,6 +736,39 @@ static bool prefer_right_looking(const cbo_ctx *c, int64_t n_pad, int64_t cols)
     const int64_t strips = cols / kStrip;
     const int64_t rounds = (strips + c->n_cu - 1) / c->n_cu;
     return rounds * c->n_cu * 5 >= strips * 6;
+}
+
+// How many panel pairs of the overlapped refit + sweep go through the right-looking pipeline before the rest is
+// left to one left-looking launch after the factorisation?  The pipeline's work runs on CUs the chain leaves
+// idle, but it is the less efficient schedule (~2.9 us per 32-row stage and strip round, co-scheduled, against
+// 2.33 us for the strip kernel alone) and it slows the chain it shares the device with.  The best split found by
+// measurement (scripts/overlap_crossover.py with CBO_HIP_PIPE_TAIL, N = 2048 / 4096 / 8192 at 16384 candidates:
+// 4-5 of 8, 6 of 16, 10 of 32 pairs) is reproduced by taking pairs while their device time stays within
+// 72 us x panels x (panels / 16)^0.72 -- the chain's own time, which stretches with size as more of it turns
+// from launch latency into trailing-update work that shares the CUs.  With fewer strips than CUs the strip kernel
+// could not fill the device, so everything stays in the pipeline.  CBO_HIP_PIPE_TAIL (fraction of rows for the
+// closing launch) overrides.
+static int pipeline_pairs(const cbo_ctx *c, int64_t n_pad, int64_t m_pad)
+{
+    const int nb = (int)(n_pad / 128);
+    const int all_pairs = (nb + 1) / 2;
+    if (c->pipe_tail_frac >= 0.0) {
+        int tail_blocks = (int)(c->pipe_tail_frac * nb + 0.5);
+        tail_blocks += (nb - tail_blocks) & 1;
+        return (nb - (tail_blocks > nb ? nb : tail_blocks)) / 2;
+    }
+    if (prefer_right_looking(c, n_pad, m_pad)) return all_pairs;     // the strip kernel would leave CUs idle
+    const double rounds = (double)(m_pad / kStrip) / (double)c->n_cu;
+    const double budget_us = 72.0 * nb * std::pow((double)nb / 16.0, 0.72);
+    double used_us = 0.0;
+    int pairs = 0;
+    while (pairs < all_pairs) {
+        const int rows_below = nb - 2 * (pairs + 1);
+        used_us += rounds * 2.9 * (12.0 + 8.0 * (rows_below > 0 ? rows_below : 0));
+        if (used_us > budget_us) break;
+        ++pairs;
+    }
+    return pairs;
 }
 
 static int enqueue_right_looking(cbo_gp *g, double *V, int64_t ldv, int64_t cols, double *q, double *mu)
@@ -865,18 +902,18 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
         if (rc != CBO_OK) return rc;
         return cbo_acq_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
     }
-    // overlapping pays while the factorisation's chain is a sizeable part of the step and the sweep's
-    // read-modify-write of V still fits the caches' appetite (scripts/overlap_crossover.py); otherwise the plain
-    // sequence, whose sweep picks its own schedule
-    const bool overlap = c->overlap_mode == 1 ||
-                         (c->overlap_mode != 0 && g->n_pad >= 1024 && (double)g->n_pad * (double)k->m_pad <= 1.5e8);
+    // below ~1000 rows the chain is a handful of launches and there is nothing to hide it under; above, the number
+    // of pairs that go through the pipeline adapts to the shape (pipeline_pairs)
+    const bool overlap = c->overlap_mode == 1 || (c->overlap_mode != 0 && g->n_pad >= 1024);
     if (!overlap) {
         rc = cbo_gp_fit(g, tries_out, jitter_out);
         if (rc != CBO_OK) return rc;
         return cbo_acq_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
     }
     g->fitted = false;
-    const SweepPipe pipe = make_pipe(g, c->V, ldv, k->m_pad, c->q, c->mu);
+    SweepPipe pipe = make_pipe(g, c->V, ldv, k->m_pad, c->q, c->mu);
+    pipe.tail_begin = pipeline_pairs(c, g->n_pad, k->m_pad) * 256;
+    if (pipe.tail_begin > (int)g->n_pad) pipe.tail_begin = (int)g->n_pad;
     double jitter = 0.0;
     int tries = 0;
     for (;;) {
@@ -903,9 +940,11 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
                 hipMemcpy2DAsync(g->z, sizeof(double), g->A + g->n_pad, sizeof(double) * g->lda, sizeof(double),
                                  (size_t)g->n_pad, hipMemcpyDeviceToDevice, c->stream);
                 int pr = 0;
-                for (int r0 = 0; r0 < (int)g->n_pad; r0 += 256, ++pr)
+                for (int r0 = 0; r0 < pipe.tail_begin; r0 += 256, ++pr)
                     sweep_pipe_pair(pipe, c->stream, g->A, g->lda, g->invDt, g->n_pad, pr, r0,
                                     (r0 + 256 <= (int)g->n_pad) ? 256 : 128);
+                if (pipe.tail_begin < (int)g->n_pad)
+                    sweep_pipe_tail(pipe, c->stream, g->A, g->lda, g->invDt, g->n_pad, pr);
             } else
 #endif
             launch_cholesky(c->stream, c->side_stream, c->chol_events, g->A, g->lda, g->n_pad, g->invDt, g->info, &pipe);

@@ -96,6 +96,8 @@ struct SweepPipe {
     double *q, *mu;                      // zeroed on `stream` by the caller
     int chunk_blocks;                    // row blocks per workgroup of the update kernel
     bool half_lds;                       // 16-row stages (two workgroups per CU) for every kernel of the pipeline
+    int tail_begin;                      // rows from here on (a multiple of 256; n_pad = none) are left to ONE
+                                         // left-looking strip launch once the factorisation is complete
     std::vector<hipEvent_t> *events;     // factorisation -> sweep dependencies, grown on demand
     void (*mark)(void *user, hipStream_t st, int begin, double flops);   // optional: around every sweep launch (timers)
     void *user;
@@ -105,6 +107,8 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
 // pair p of the pipelined sweep: rows [r0, r0 + klen) of the factor are final on stream `chain`
 void sweep_pipe_pair(const SweepPipe &pipe, hipStream_t chain, const double *A, int64_t lda, const double *invDt,
                      int64_t n_pad, int p, int r0, int klen);
+void sweep_pipe_tail(const SweepPipe &pipe, hipStream_t chain, const double *A, int64_t lda, const double *invDt,
+                     int64_t n_pad, int pairs_done);
 // alpha = U^-1 z  (z = first rhs column of A).
 void launch_backsolve(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt, double *alpha);
 void launch_backsolve_vec(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt,

@@ -418,6 +418,33 @@ void sweep_pipe_pair(const SweepPipe &pipe, hipStream_t chain, const double *A, 
     hipEventRecord(pipe_event(2, p), pipe.bulk);
 }
 
+// The rows the pairs did not take, [tail_begin, n_pad): every earlier pair has been folded into them (first of the
+// last pair on `stream`, rest of the last pair on `bulk`) and the factor is complete on `chain`: one left-looking
+// launch of the strip kernel on the sub-problem, on the chain stream itself (every CU, full-LDS variant).
+void sweep_pipe_tail(const SweepPipe &pipe, hipStream_t chain, const double *A, int64_t lda, const double *invDt,
+                     int64_t n_pad, int pairs_done)
+{
+    std::vector<hipEvent_t> &ev = *pipe.events;
+    const size_t slot = (size_t)(3 * pairs_done);
+    while (ev.size() <= slot) {
+        hipEvent_t e;
+        hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence);
+        ev.push_back(e);
+    }
+    if (pairs_done > 0) {
+        hipEventRecord(ev[slot], pipe.stream);                                   // sd and first of the last pair
+        hipStreamWaitEvent(chain, ev[slot], 0);
+        hipStreamWaitEvent(chain, ev[(size_t)(3 * (pairs_done - 1) + 2)], 0);      // rest of the last pair
+    }
+    const int t0 = pipe.tail_begin;
+    const double rows = (double)((int)n_pad - t0);
+    if (pipe.mark) pipe.mark(pipe.user, chain, 1, rows * rows * (double)pipe.m_pad);
+    launch_trsm_strips(chain, A + (int64_t)t0 * lda + t0, lda, invDt + (int64_t)(t0 / 16) * 256,
+                       pipe.V + (int64_t)t0 * pipe.ldv, pipe.ldv, (int64_t)n_pad - t0, pipe.m_pad, pipe.zvec + t0, pipe.q,
+                       pipe.mu, true, false);
+    if (pipe.mark) pipe.mark(pipe.user, chain, 0, 0.0);
+}
+
 // Look-ahead: the bulk of panel k-1's trailing update (tile rows below the next panel) runs on the side
 // stream while the main stream factors the diagonal block of panel k and solves its row panel; the two
 // meet again before the next panel's own rows are updated.
@@ -452,7 +479,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     const bool half_lds = pipe && pipe->half_lds;
     int pair = 0;
     auto sweep_rows = [&](int r0, int klen) {
-        if (pipe) sweep_pipe_pair(*pipe, s, A, lda, invDt, n_pad, pair++, r0, klen);
+        if (pipe && r0 < pipe->tail_begin) sweep_pipe_pair(*pipe, s, A, lda, invDt, n_pad, pair++, r0, klen);
     };
     int pending = -1;                      // event index of the bulk update still in flight
     for (int k = 0; k < np; k += 2) {
@@ -489,6 +516,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     // awaited before the following panel's syrk); make that explicit for robustness
     hipEventRecord(events[2 * np + 1], side);
     hipStreamWaitEvent(s, events[2 * np + 1], 0);
+    if (pipe && pipe->tail_begin < (int)n_pad) sweep_pipe_tail(*pipe, s, A, lda, invDt, n_pad, pair);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -174,6 +174,10 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
     // lane groups and added to a running total pair by pair -- the grouping the right-looking pipeline produces
     // naturally (one launch of this kernel per pair, accumulate = 1), so both schedules give the same bits
     double qacc = 0.0, macc = 0.0, qtot = 0.0, mtot = 0.0;
+    if (SWEEP && accumulate) {            // continue the running totals of the launches before this one
+        qtot = q_out[colw + lc];
+        mtot = mu_out[colw + lc];
+    }
 
     // top of a stage: this wave's DMA of the stage has landed once only the next stage's 12 DMA instructions
     // (plus whatever the previous stage issued after them) are outstanding -- vmcnt retires in order; the
@@ -330,9 +334,8 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
 
     if (SWEEP) {
         if (kq == 0) {
-            // accumulate: the rows of this call are one panel pair of a sweep that is spread over several launches
-            q_out[colw + lc] = accumulate ? q_out[colw + lc] + qtot : qtot;
-            mu_out[colw + lc] = accumulate ? mu_out[colw + lc] + mtot : mtot;
+            q_out[colw + lc] = qtot;
+            mu_out[colw + lc] = mtot;
         }
     }
 }

@@ -9,7 +9,10 @@ from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
 lib, ctx = _lib.load(), _lib.Context.get()
 rng = np.random.default_rng(0)
 bv, bi = ctypes.c_double(), ctypes.c_int64()
-sizes = [(512, 16384), (1024, 16384), (2048, 16384), (4096, 200), (4096, 4096), (4096, 12288), (4096, 16384), (4096, 20480), (4096, 32768), (4096, 65536), (8192, 16384), (8192, 65536)]
+if len(sys.argv) > 1:
+    sizes = [tuple(int(t) for t in a.split('x')) for a in sys.argv[1:]]
+else:
+  sizes = [(512, 16384), (1024, 16384), (2048, 16384), (4096, 200), (4096, 4096), (4096, 12288), (4096, 16384), (4096, 20480), (4096, 32768), (4096, 65536), (8192, 16384), (8192, 65536)]
 for n, mm in sizes:
     X = rng.uniform(-5, 5, (n, 3)); y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.standard_normal((n, 1))
     Xs = rng.uniform(-5, 5, (mm, 3))
