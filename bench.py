@@ -9,7 +9,7 @@ input, exactly what CBO.intervene() triggers each trial for the set it intervene
     sweep : K(X,X*) -> V = L^-1 K* (variance, mean) -> EI / cost -> arg-max over the rank's candidates
     pick  : arg-max exchange across ranks (RCCL all-gather of 16 B per rank when --gpus > 1)
 The timed steps make ONE device call for fit + sweep (cbo_gp_fit_sweep): the sweep's substitution advances
-panel by panel on two extra streams underneath the factorisation's chain of short kernels.
+pair of panels by pair on two extra streams underneath the factorisation's chain of short kernels.
 --sequential times the same work as two calls (cbo_gp_fit, then cbo_acq_sweep), nothing overlapped.
 Inputs (X, y, candidate grid) are resident in HBM before the timed region starts; the only host
 traffic inside it is the jitchol status word and the 16-byte winner.
@@ -194,7 +194,7 @@ def main():
         step_flops = float(n_pad) ** 2 * m_rank + float(n_pad) ** 3 / 3.0
         step_tflops = step_flops / (region_ms / args.steps * 1e-3) / 1e12
         mode = "two calls, nothing overlapped" if args.sequential else \
-            "cbo_gp_fit_sweep: sweep pipelined under the factorisation (5 streams)"
+            "cbo_gp_fit_sweep: right-looking sweep pairs under the factorisation (4 streams), left-looking launch for the rest"
         out = {
             "metric": "candidate-intervention acquisitions/sec (16k grid, d=3)",
             "value": total_cands / (elapsed / args.steps),
