@@ -1,23 +1,27 @@
-// Strip-parallel forward substitution  V <- L^-1 V  on fp64 MFMA (v_mfma_f64_16x16x4_f64), gfx950.
+// Forward substitution  V <- L^-1 V  on fp64 MFMA (v_mfma_f64_16x16x4_f64), gfx950: the work of the acquisition
+// sweep (predictive variance = kss - |L^-1 k*|^2, GPy Posterior._raw_predict, triangular form) and the panel
+// solve of the blocked Cholesky.  Two kernels share one decomposition, LDS staging and MFMA order:
 //
-// This is the dominant kernel of the acquisition sweep (predictive variance = kss - |L^-1 k*|^2,
-// GPy Posterior._raw_predict, triangular form) and also the panel solve of the blocked Cholesky.
+//   trsm_strip_kernel<SWEEP, KB>   left-looking: a workgroup owns a strip of 64 right-hand-side columns for ALL
+//                                  rows of its (sub-)problem
+//   trsm_update_kernel<KB>         the right-looking cut of the same sums, C -= U_panel^T V_panel over strips x
+//                                  row chunks, used to run the sweep underneath the factorisation
 //
-// Decomposition: one 256-thread workgroup per strip of 64 right-hand-side columns; wave w owns the
-// 16 columns [16w, 16w+16) of the strip for ALL rows, so the four waves never exchange V data and a
-// lane only ever re-reads V elements it stored itself.  Rows are processed in blocks of RB (left-
-// looking):   R = V[blk] - L[blk, 0:i0] * V[0:i0]      (MFMA GEMM, K-loop over all previous rows)
-//             V[blk] = L[blk,blk]^-1 R                 (16x16 diagonal inverses + MFMA updates)
+// Decomposition: 256-thread workgroups, 64 columns per strip; wave w owns the 16 columns [16w, 16w+16), so the four
+// waves never exchange V data and a lane only ever re-reads V elements it stored itself.  Rows go in blocks of
+// 128:    R = V[blk] - L[blk, 0:i0] * V[0:i0]      (MFMA GEMM, K-loop over the previous rows)
+//         V[blk] = L[blk,blk]^-1 R                 (16x16 diagonal inverses + MFMA updates)
 // The L operand is the transposed factor U (U[k][i] = L[i][k], row-major) so an A fragment
-// "A[i = lane&15][k = lane>>4]" is a read of 4 row segments of 128 B; U tiles of 32 x RB are staged
-// through LDS (double-buffered, shared by the four waves), and the diagonal block's 16x16 tiles are
-// staged through the same LDS for the in-block phase.  The B fragment "B[k = lane>>4][j = lane&15]"
-// comes straight from V in global memory.  The f64 MFMA result map (row = (lane>>4) + 4*reg, col =
-// lane&15) is exactly the B-operand map of k-step `reg`, so results feed the next MFMA with no data
-// movement.  A fragments of k-step j+1 are read from LDS while the MFMAs of k-step j issue.
+// "A[i = lane&15][k = lane>>4]" is a read of 4 row segments of 128 B; U tiles of KB x 128 are staged through LDS
+// by LDS-DMA (3-deep ring shared by the four waves), together with the wave's own V rows (B fragments
+// "B[k = lane>>4][j = lane&15]") or, in the diagonal stages, the 16x16 diagonal inverses.  The f64 MFMA result
+// map (row = (lane>>4) + 4*reg, col = lane&15) is exactly the B-operand map of k-step `reg`, so results feed
+// the next MFMA with no data movement.  A fragments of k-step j+1 are read from LDS while the MFMAs of k-step j
+// issue.
 //
-// Roofline: fp64 MFMA bound.  Algorithmic work n^2 flops per column (n^2/2 FMAs); V re-read traffic is
-// n^2/(2*RB) * 8 B per column (left-looking), U traffic n^2/2*8 B per strip served from L2/MALL.
+// Roofline: fp64 MFMA bound.  Algorithmic work n^2 flops per column (n^2/2 FMAs); left-looking V re-read traffic
+// n^2/(2*128) * 8 B per column, U traffic n^2/2*8 B per strip served from L2/MALL; right-looking adds one
+// read-modify-write of the rows below per panel pair.
 #include <cstdlib>
 
 #include "cbo_internal.h"
