@@ -51,6 +51,7 @@ struct cbo_ctx {
     int overlap_mode = -1;           // CBO_HIP_OVERLAP: 0 = cbo_gp_fit_sweep never overlaps, 1 = always, else automatic
     bool profiling = false;
     std::vector<EventPair> pending;
+    EventPair pipe_cur{};                     // the launch pipe_mark is currently bracketing
     std::vector<hipEvent_t> pool;
     cbo_timers timers{};
     // sweep workspaces (grown on demand)
@@ -693,7 +694,7 @@ static void pipe_mark(void *user, hipStream_t st, int begin, double flops)
 {
     cbo_ctx *c = static_cast<cbo_ctx *>(user);
     if (!c->profiling) return;
-    static thread_local EventPair cur;
+    EventPair &cur = c->pipe_cur;
     if (begin) {
         cur.a = get_event(c);
         cur.b = get_event(c);
