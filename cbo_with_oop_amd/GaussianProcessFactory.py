@@ -213,8 +213,20 @@ class HipGaussianProcess:
             self.set_hyperparameters(v0, ls0, nv0, fit=False)
         self.set_data(X, Y, fit=fit)
 
+    def log_likelihood_gradients(self):
+        """(d log p(y)/d variance, d/d lengthscale (array), d/d noise_var) of the fitted model: the gradients GPy's
+        inference hands its optimiser, computed on the device (``cbo_gp_lml_gradients``)."""
+        self.ensure_fitted()
+        lml, dv, dn = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        dls = np.zeros(self.lengthscale.size)
+        _lib.check(self._lib.cbo_gp_lml_gradients(self._handle, ctypes.byref(lml), ctypes.byref(dv), _lib.dptr(dls),
+                                                  ctypes.byref(dn)))
+        self._last_lml = lml.value
+        return dv.value, dls, dn.value
+
     def _objective(self, log_theta):
-        """Negative log marginal likelihood at exp(log_theta) = [variance, lengthscale(s), (noise)]."""
+        """(negative log marginal likelihood, its gradient) at exp(log_theta) = [variance, lengthscale(s), (noise)],
+        the gradient taken with respect to log_theta."""
         theta = np.exp(log_theta)
         nl = self.lengthscale.size
         noise = self.noise_var if self.fix_noise else theta[1 + nl]
@@ -222,24 +234,27 @@ class HipGaussianProcess:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore", RuntimeWarning)
                 self.set_hyperparameters(theta[0], theta[1:1 + nl], noise)
-            return -self.log_likelihood()
+            dv, dls, dn = self.log_likelihood_gradients()
         except np.linalg.LinAlgError:
-            return 1e25                       # GPy's optimiser treats a failed Cholesky as a rejected step
+            return 1e25, np.zeros_like(log_theta)      # GPy's optimiser treats a failed Cholesky as a rejected step
+        g = [dv * theta[0], *(dls * theta[1:1 + nl])] + ([] if self.fix_noise else [dn * noise])
+        return -self._last_lml, -np.asarray(g, dtype=np.float64)
 
     def optimize(self, max_iters=1000, **kwargs):
         """Hyper-parameter MLE (emukit ``GPyModelWrapper.optimize`` -> GPy ``optimize_restarts(1)``, src/CBO.py:173;
         ``gp.optimize()`` in src/utils_functions/utils.py:44): maximise the log marginal likelihood over kernel
         variance, lengthscale(s) and -- unless fixed, as for graph-level GPs -- the noise variance.  Host logic:
-        scipy L-BFGS-B (GPy's default optimiser) in log-parameter space with finite-difference gradients, every
-        objective evaluation being a device refit + device likelihood reduction.  GPy uses analytic gradients and
-        a softplus transform; the optimum is the same stationary point, reached to optimiser tolerance."""
+        scipy L-BFGS-B (GPy's default optimiser) in log-parameter space; every evaluation is a device refit plus the
+        device likelihood and its analytic gradients.  GPy optimises through a softplus transform; the optimum is
+        the same stationary point, reached to optimiser tolerance."""
         from scipy.optimize import minimize
         x0 = [self.variance, *self.lengthscale]
         if not self.fix_noise:
             x0.append(self.noise_var)
         x0 = np.log(np.asarray(x0, dtype=np.float64))
-        f0 = self._objective(x0)
-        res = minimize(self._objective, x0, method="L-BFGS-B", options={"maxiter": int(max_iters), "maxfun": 15000})
+        f0 = self._objective(x0)[0]
+        res = minimize(self._objective, x0, jac=True, method="L-BFGS-B",
+                       options={"maxiter": int(max_iters), "maxfun": 15000})
         best = res.x if res.fun <= f0 else x0
         self._objective(best)                 # leave the model fitted at the optimum
         self.optimization_result = res

@@ -87,6 +87,7 @@ SIGNATURES = {
                                       ctypes.c_int, c_double_p, c_double_p]),
     "cbo_gp_set_hyper": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, c_double_p, ctypes.c_double]),
     "cbo_gp_log_marginal": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
+    "cbo_gp_lml_gradients": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "cbo_gp_predict_gradients": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_double_p, c_double_p, c_double_p,
                                                 c_double_p]),
     "cbo_gp_predict_grouped": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, c_double_p, c_double_p,

@@ -56,6 +56,8 @@ struct cbo_ctx {
     cbo_timers timers{};
     // sweep workspaces (grown on demand)
     double *V = nullptr; size_t V_bytes = 0;
+    double *W = nullptr; size_t W_bytes = 0;          // -Ky^-1 for the likelihood gradients
+    double *gpart = nullptr; size_t gpart_elems = 0;
     double *q = nullptr, *mu = nullptr, *mean = nullptr, *var = nullptr, *acq = nullptr; size_t vec_elems = 0;
     double *part_val = nullptr; int64_t *part_idx = nullptr;
     double *best_val = nullptr; int64_t *best_idx = nullptr;   // device
@@ -261,6 +263,7 @@ extern "C" void cbo_shutdown(cbo_ctx *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->pool) hipEventDestroy(e);
+    hipFree(c->W); hipFree(c->gpart);
     hipFree(c->V); hipFree(c->q); hipFree(c->mu); hipFree(c->mean); hipFree(c->var); hipFree(c->acq);
     hipFree(c->part_val); hipFree(c->part_idx); hipFree(c->best_val); hipFree(c->best_idx);
     hipHostFree(c->h_best_val); hipHostFree(c->h_best_idx); hipHostFree(c->h_info);
@@ -772,10 +775,12 @@ static int pipeline_pairs(const cbo_ctx *c, int64_t n_pad, int64_t m_pad)
     return pairs;
 }
 
-static int enqueue_right_looking(cbo_gp *g, double *V, int64_t ldv, int64_t cols, double *q, double *mu)
+static int enqueue_right_looking(cbo_gp *g, double *V, int64_t ldv, int64_t cols, double *q, double *mu,
+                                 bool lower_tri = false)
 {
     cbo_ctx *c = g->ctx;
-    const SweepPipe pipe = make_pipe(g, V, ldv, cols, q, mu);
+    SweepPipe pipe = make_pipe(g, V, ldv, cols, q, mu);
+    pipe.lower_tri = lower_tri;
     HIP_TRY(hipMemsetAsync(q, 0, sizeof(double) * cols, c->stream));
     HIP_TRY(hipMemsetAsync(mu, 0, sizeof(double) * cols, c->stream));
     int p = 0;
@@ -1057,6 +1062,77 @@ extern "C" int cbo_gp_log_marginal(cbo_gp *g, double *lml_out)
     HIP_TRY(hipStreamSynchronize(c->stream));
     // GPy: 0.5 * (-n log(2 pi) - W_logdet - sum(alpha * (Y - m))),  W_logdet = 2 sum log L_ii
     *lml_out = 0.5 * (-(double)g->n * 1.8378770664093453 - 2.0 * h2[1] - h2[0]);
+    return CBO_OK;
+}
+
+// Gradients of the log marginal likelihood with respect to the kernel variance, the lengthscale(s) and the noise
+// variance: 1/2 sum_ij (alpha alpha^T - Ky^-1)_ij dKy_ij/dtheta (GPy ExactGaussianInference: dL_dK ->
+// kern.update_gradients_full, dL_dthetaL).  Ky^-1 = L^-T L^-1 on the device: L^-1 by the sweep machinery on
+// identity right-hand sides (its q output is diag(Ky^-1)), the product by the GEMM form of the update kernel over
+// the non-zero lower-triangular part only, the contraction with dK/dtheta by one pass over the upper tiles.
+extern "C" int cbo_gp_lml_gradients(cbo_gp *g, double *lml_out, double *dvariance_out, double *dlengthscale_out,
+                                    double *dnoise_out)
+{
+    if (!g || !dvariance_out || !dlengthscale_out || !dnoise_out) return fail(CBO_ERR_INVALID, "NULL argument");
+    if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
+    cbo_ctx *c = g->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_alpha(g);
+    if (rc != CBO_OK) return rc;
+    const int64_t n_pad = g->n_pad;
+    int64_t chunk = 0, ldv = 0;
+    rc = ensure_workspaces(c, n_pad, n_pad, &chunk, &ldv);
+    if (rc != CBO_OK) return rc;
+    if (chunk < n_pad) return fail(CBO_ERR_UNSUPPORTED, "likelihood gradients need an n_pad x n_pad workspace (raise CBO_HIP_WORKSPACE_MB)");
+    const int64_t ldw = n_pad + kLdExtra;
+    const size_t w_bytes = sizeof(double) * (size_t)n_pad * (size_t)ldw;
+    const size_t part_elems = (size_t)lml_grad_tiles(n_pad) * (size_t)(1 + g->d);
+    if (w_bytes > c->W_bytes || part_elems > c->gpart_elems) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->W); hipFree(c->gpart);
+        c->W = nullptr; c->gpart = nullptr; c->W_bytes = 0; c->gpart_elems = 0;
+        HIP_TRY(hipMalloc(&c->W, w_bytes));
+        c->W_bytes = w_bytes;
+        HIP_TRY(hipMalloc(&c->gpart, sizeof(double) * part_elems));
+        c->gpart_elems = part_elems;
+    }
+    // V = L^-1 (identity right-hand sides), q_j = (Ky^-1)_jj
+    launch_set_identity(c->stream, c->V, ldv, n_pad);
+    if (prefer_right_looking(c, n_pad, n_pad)) {
+        rc = enqueue_right_looking(g, c->V, ldv, n_pad, c->q, c->mu, true);
+        if (rc != CBO_OK) return rc;
+    } else {
+        launch_trsm_strips(c->stream, g->A, g->lda, g->invDt, c->V, ldv, n_pad, n_pad, g->z, c->q, c->mu);
+    }
+    // -Ky^-1 = -(L^-1)^T L^-1: rows [k0, k0+256) of L^-1 only reach columns < k0+256, so pair p touches the
+    // leading (k0+256)^2 block; upper part only
+    HIP_TRY(hipMemsetAsync(c->W, 0, w_bytes, c->stream));
+    for (int k0 = 0; k0 < (int)n_pad; k0 += 256) {
+        const int klen = (k0 + 256 <= (int)n_pad) ? 256 : 128;
+        launch_gemm_update(c->stream, c->V, ldv, c->V, ldv, c->W, ldw, k0, klen, 0, k0 + klen, k0 + klen,
+                           c->pipe_chunk_blocks, true, true);
+    }
+    launch_lml_grad(c->stream, g->X, g->h, g->alpha, c->W, ldw, n_pad, c->gpart, c->part_val);
+    launch_lml_terms(c->stream, g->A, g->lda, n_pad, g->z, c->part_val + 16);
+    HIP_TRY(hipGetLastError());
+    double hs[18];
+    std::vector<double> hq((size_t)g->n), ha((size_t)g->n);
+    HIP_TRY(hipMemcpyAsync(hs, c->part_val, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(hq.data(), c->q, sizeof(double) * g->n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(ha.data(), g->alpha, sizeof(double) * g->n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double tr_w = 0.0, aa = 0.0;
+    for (int64_t i = 0; i < g->n; ++i) { tr_w += hq[(size_t)i]; aa += ha[(size_t)i] * ha[(size_t)i]; }
+    *dvariance_out = 0.5 * hs[0] / g->h.variance;
+    if (g->h.ard) {
+        for (int k = 0; k < g->d; ++k) dlengthscale_out[k] = 0.5 * hs[1 + k] / g->ls[(size_t)k];
+    } else {
+        double sum = 0.0;
+        for (int k = 0; k < g->d; ++k) sum += hs[1 + k];
+        dlengthscale_out[0] = 0.5 * sum / g->h.lengthscale;
+    }
+    *dnoise_out = 0.5 * (aa - tr_w);
+    if (lml_out) *lml_out = 0.5 * (-(double)g->n * 1.8378770664093453 - 2.0 * hs[17] - hs[16]);
     return CBO_OK;
 }
 

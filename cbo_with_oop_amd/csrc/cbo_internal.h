@@ -96,6 +96,8 @@ struct SweepPipe {
     double *q, *mu;                      // zeroed on `stream` by the caller
     int chunk_blocks;                    // row blocks per workgroup of the update kernel
     bool half_lds;                       // 16-row stages (two workgroups per CU) for every kernel of the pipeline
+    bool lower_tri;                      // the right-hand sides are lower triangular (identity: V = L^-1), so rows
+                                         // [r0, r0+klen) only reach columns < r0+klen: launch just those strips
     int tail_begin;                      // rows from here on (a multiple of 256; n_pad = none) are left to ONE
                                          // left-looking strip launch once the factorisation is complete
     std::vector<hipEvent_t> *events;     // factorisation -> sweep dependencies, grown on demand
@@ -126,6 +128,12 @@ void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const doubl
 // C[i0_begin:i0_end, :] -= U[k0:k0+klen, i0_begin:i0_end]^T V[k0:k0+klen, :]  (C and V share the workspace V)
 void launch_trsm_update(hipStream_t s, const double *U, int64_t ldu, double *V, int64_t ldv, int k0, int klen,
                         int i0_begin, int i0_end, int64_t m_pad, int chunk_blocks, bool half_lds = true);
+// the same kernel as a plain GEMM update with its own output:
+// C[i0_begin:i0_end, 0:m_pad] -= U[k0:k0+klen, i0_begin:i0_end]^T V[k0:k0+klen, 0:m_pad]; upper_only skips the
+// workgroups that lie entirely below the diagonal
+void launch_gemm_update(hipStream_t s, const double *U, int64_t ldu, const double *V, int64_t ldv, double *C,
+                        int64_t ldc, int k0, int klen, int i0_begin, int i0_end, int64_t m_pad, int chunk_blocks,
+                        bool half_lds, bool upper_only);
 
 struct AcqParams {
     double variance, noise_var, y_best, ei_jitter, cost;
@@ -143,6 +151,12 @@ void launch_group_mean(hipStream_t s, const double *in, int64_t n_groups, int64_
 
 // out[0] = sum z_i^2, out[1] = sum log U_ii over the n_pad rows (padding contributes 0)
 void launch_lml_terms(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *z, double *out2);
+// likelihood gradients: out[0] = sum M k, out[1 + k] = sum M k ((x_ik - x_jk)/l_k)^2 over all i, j < n with
+// M = alpha alpha^T + negW; partial: lml_grad_tiles(n_pad) * (1 + d) doubles
+int lml_grad_tiles(int64_t n_pad);
+void launch_lml_grad(hipStream_t s, const PointSet &X, const KernelHyper &h, const double *alpha, const double *negW,
+                     int64_t ldw, int64_t n_pad, double *partial, double *out);
+void launch_set_identity(hipStream_t s, double *V, int64_t ldv, int64_t n_pad);
 void launch_gather_diag(hipStream_t s, const double *A, int64_t lda, int64_t n, double *diag);
 void launch_export_lower(hipStream_t s, const double *A, int64_t lda, int64_t n, double *L_rowmajor);
 void launch_export_sym(hipStream_t s, const double *A, int64_t lda, int64_t n, double *K_rowmajor);

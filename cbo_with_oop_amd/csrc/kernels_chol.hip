@@ -391,12 +391,13 @@ void sweep_pipe_pair(const SweepPipe &pipe, hipStream_t chain, const double *A, 
         }
         return ev[slot];
     };
-    const double m = (double)pipe.m_pad;
+    const int64_t cols = (pipe.lower_tri && r0 + klen < pipe.m_pad) ? (int64_t)(r0 + klen) : pipe.m_pad;
+    const double m = (double)cols;
     hipEventRecord(pipe_event(0, p), chain);
     hipStreamWaitEvent(pipe.stream, pipe_event(0, p), 0);
     if (pipe.mark) pipe.mark(pipe.user, pipe.stream, 1, (double)klen * (double)klen * m);
     launch_trsm_strips(pipe.stream, A + (int64_t)r0 * lda + r0, lda, invDt + (int64_t)(r0 / 16) * 256,
-                       pipe.V + (int64_t)r0 * pipe.ldv, pipe.ldv, klen, pipe.m_pad, pipe.zvec + r0, pipe.q, pipe.mu, true,
+                       pipe.V + (int64_t)r0 * pipe.ldv, pipe.ldv, klen, cols, pipe.zvec + r0, pipe.q, pipe.mu, true,
                        pipe.half_lds);
     if (pipe.mark) pipe.mark(pipe.user, pipe.stream, 0, 0.0);
     hipEventRecord(pipe_event(1, p), pipe.stream);
@@ -405,13 +406,13 @@ void sweep_pipe_pair(const SweepPipe &pipe, hipStream_t chain, const double *A, 
     const int first_end = (below + 256 < (int)n_pad) ? below + 256 : (int)n_pad;
     if (p > 0) hipStreamWaitEvent(pipe.stream, pipe_event(2, p - 1), 0);
     if (pipe.mark) pipe.mark(pipe.user, pipe.stream, 1, 2.0 * (double)klen * (double)(first_end - below) * m);
-    launch_trsm_update(pipe.stream, A, lda, pipe.V, pipe.ldv, r0, klen, below, first_end, pipe.m_pad, pipe.chunk_blocks,
+    launch_trsm_update(pipe.stream, A, lda, pipe.V, pipe.ldv, r0, klen, below, first_end, cols, pipe.chunk_blocks,
                        pipe.half_lds);
     if (pipe.mark) pipe.mark(pipe.user, pipe.stream, 0, 0.0);
     hipStreamWaitEvent(pipe.bulk, pipe_event(1, p), 0);
     if (first_end < (int)n_pad) {
         if (pipe.mark) pipe.mark(pipe.user, pipe.bulk, 1, 2.0 * (double)klen * (double)((int)n_pad - first_end) * m);
-        launch_trsm_update(pipe.bulk, A, lda, pipe.V, pipe.ldv, r0, klen, first_end, (int)n_pad, pipe.m_pad,
+        launch_trsm_update(pipe.bulk, A, lda, pipe.V, pipe.ldv, r0, klen, first_end, (int)n_pad, cols,
                            pipe.chunk_blocks, pipe.half_lds);
         if (pipe.mark) pipe.mark(pipe.user, pipe.bulk, 0, 0.0);
     }

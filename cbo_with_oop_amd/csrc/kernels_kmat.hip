@@ -283,6 +283,123 @@ void launch_lml_terms(hipStream_t s, const double *A, int64_t lda, int64_t n_pad
     hipLaunchKernelGGL(lml_terms_kernel, dim3(1), dim3(256), 0, s, A, lda, n_pad, z, out2);
 }
 
+// ---- log marginal likelihood gradients ----------------------------------------------------
+// dL/dtheta = 1/2 sum_ij M_ij dK_ij/dtheta with M = alpha alpha^T - Ky^-1 (GPy: dL_dK, passed to
+// kern.update_gradients_full).  For the RBF part k = s2 exp(-r2/2), r2 = sum_k (x_ik - x_jk)^2 / l_k^2:
+//     dK/ds2 = k / s2,    dK/dl_k = k (x_ik - x_jk)^2 / l_k^3
+// so one pass over the upper 64x64 tiles accumulates  S0 = sum M k  and  S_k = sum M k ((x_ik - x_jk)/l_k)^2
+// (off-diagonal elements twice), per-tile partials in a fixed order -> reproducible.  negW holds -Ky^-1 (the GEMM
+// kernel subtracts).  Coordinates are the resident ones: pre-scaled per dimension when ard, raw otherwise.
+template <int D>
+__global__ __launch_bounds__(256) void lml_grad_tile_kernel(const double *__restrict__ xs, int64_t ldx, int64_t n,
+                                                            const double *__restrict__ alpha,
+                                                            const double *__restrict__ negW, int64_t ldw,
+                                                            double variance, double inv_l2_iso,
+                                                            double *__restrict__ partial /* [tiles][1 + D] */)
+{
+    const int tj = blockIdx.x, ti = blockIdx.y;
+    const int tile = ti * gridDim.x + tj;
+    __shared__ double sx[D][64], sy[D][64], sa[64], sb[64];
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    double s[1 + D];
+#pragma unroll
+    for (int k = 0; k <= D; ++k) s[k] = 0.0;
+    if (tj >= ti) {
+        const int64_t i0 = (int64_t)ti * 64, j0 = (int64_t)tj * 64;
+        if (tid < 64) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) sx[k][tid] = xs[(int64_t)k * ldx + i0 + tid];
+            sa[tid] = (i0 + tid < n) ? alpha[i0 + tid] : 0.0;
+        } else if (tid < 128) {
+            const int t = tid - 64;
+#pragma unroll
+            for (int k = 0; k < D; ++k) sy[k][t] = xs[(int64_t)k * ldx + j0 + t];
+            sb[t] = (j0 + t < n) ? alpha[j0 + t] : 0.0;
+        }
+        __syncthreads();
+        const int tx = tid & 63, ty = tid >> 6;                  // column tx, rows ty, ty+4, ...
+        const int64_t gj = j0 + tx;
+        for (int rr = 0; rr < 16; ++rr) {
+            const int ii = ty + 4 * rr;
+            const int64_t gi = i0 + ii;
+            if (gi >= n || gj >= n || gj < gi) continue;
+            double r2 = 0.0, d2k[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const double df = sx[k][ii] - sy[k][tx];
+                d2k[k] = df * df * inv_l2_iso;
+                r2 += d2k[k];
+            }
+            const double kv = variance * exp(-0.5 * r2);
+            const double m = (gi == gj ? 1.0 : 2.0) * (sa[ii] * sb[tx] + negW[gi * ldw + gj]);
+            const double mk = m * kv;
+            s[0] += mk;
+#pragma unroll
+            for (int k = 0; k < D; ++k) s[1 + k] = fma(mk, d2k[k], s[1 + k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k <= D; ++k) {
+        __syncthreads();
+        red[tid] = s[k];
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) red[tid] = __dadd_rn(red[tid], red[tid + st]);
+            __syncthreads();
+        }
+        if (tid == 0) partial[(int64_t)tile * (1 + D) + k] = red[0];
+    }
+}
+
+__global__ void lml_grad_final_kernel(const double *__restrict__ partial, int tiles, int terms, double *__restrict__ out)
+{
+    const int k = threadIdx.x;
+    if (k >= terms) return;
+    double t = 0.0;
+    for (int i = 0; i < tiles; ++i) t = __dadd_rn(t, partial[(int64_t)i * terms + k]);
+    out[k] = t;
+}
+
+int lml_grad_tiles(int64_t n_pad) { const int nt = (int)(n_pad / 64); return nt * nt; }
+
+void launch_lml_grad(hipStream_t s, const PointSet &X, const KernelHyper &h, const double *alpha, const double *negW,
+                     int64_t ldw, int64_t n_pad, double *partial, double *out)
+{
+    const int nt = (int)(n_pad / 64);
+    const dim3 grid(nt, nt);
+    const double inv_l2 = h.ard ? 1.0 : 1.0 / (h.lengthscale * h.lengthscale);
+#define CBO_LAUNCH_GRAD(D)                                                                                     \
+    hipLaunchKernelGGL(lml_grad_tile_kernel<D>, grid, dim3(256), 0, s, X.xs, X.ld, X.n, alpha, negW, ldw, h.variance, \
+                       inv_l2, partial)
+    switch (X.d) {
+        case 1: CBO_LAUNCH_GRAD(1); break;
+        case 2: CBO_LAUNCH_GRAD(2); break;
+        case 3: CBO_LAUNCH_GRAD(3); break;
+        case 4: CBO_LAUNCH_GRAD(4); break;
+        case 5: CBO_LAUNCH_GRAD(5); break;
+        case 6: CBO_LAUNCH_GRAD(6); break;
+        case 7: CBO_LAUNCH_GRAD(7); break;
+        default: CBO_LAUNCH_GRAD(8); break;
+    }
+#undef CBO_LAUNCH_GRAD
+    hipLaunchKernelGGL(lml_grad_final_kernel, dim3(1), dim3(16), 0, s, partial, nt * nt, 1 + X.d, out);
+}
+
+// V = identity (n_pad x n_pad) in a workspace with leading dimension ldv: the right-hand sides of L^-1.
+__global__ void set_identity_kernel(double *__restrict__ V, int64_t ldv, int64_t n_pad)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pad * n_pad) return;
+    const int64_t i = idx / n_pad, j = idx % n_pad;
+    V[i * ldv + j] = (i == j) ? 1.0 : 0.0;
+}
+
+void launch_set_identity(hipStream_t s, double *V, int64_t ldv, int64_t n_pad)
+{
+    hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((n_pad * n_pad + 255) / 256)), dim3(256), 0, s, V, ldv, n_pad);
+}
+
 // L (row-major lower, upper zero) from the upper factor U: L[i][k] = U[k][i].
 __global__ void export_lower_kernel(const double *__restrict__ A, int64_t lda, int64_t n, double *__restrict__ L)
 {

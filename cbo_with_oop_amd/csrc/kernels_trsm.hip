@@ -360,10 +360,13 @@ constexpr int kAccMoves = kT * 4;         // global loads (next block's C) or st
 // KB = rows of U / V per pipeline stage.  With KB = 16 a workgroup needs 79,872 B of LDS and 192 registers per
 // lane, so two workgroups share a CU (two waves per SIMD): while one waits at its stage barrier or for an LDS
 // read the other keeps the matrix pipe busy, and a workgroup's prologue/epilogue hides under its neighbour.
+// C may be the V workspace itself (the pipeline: C rows lie below the panel) or a separate array (W = V^T V for
+// the likelihood gradients, where U = V = L^-1 and upper_only skips the workgroups entirely below the diagonal).
 template <int KB>
-__global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restrict__ U, int64_t ldu, double *V,
-                                                          int64_t ldv, int k0, int klen, int i0_begin, int i0_end,
-                                                          int chunk_rows)
+__global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restrict__ U, int64_t ldu,
+                                                          const double *V, int64_t ldv, double *C, int64_t ldc, int k0,
+                                                          int klen, int i0_begin, int i0_end, int chunk_rows,
+                                                          int upper_only)
 {
     using G = StageGeom<KB>;
     constexpr int kA = G::kA, kB = G::kB, kRA = G::kRA, kParts = G::kParts, kDma = G::kDma, kKS = G::kKS;
@@ -377,8 +380,9 @@ __global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restri
     const int ib = i0_begin + (int)blockIdx.y * chunk_rows;
     const int ie = (ib + chunk_rows < i0_end) ? ib + chunk_rows : i0_end;
     if (ib >= ie) return;                                              // uniform for the workgroup
+    if (upper_only && (int)blockIdx.x * kStrip + kStrip <= ib) return;  // every column left of every row: lower part
     const int nst = klen / KB;
-    double *Cc = V + colw + lc;
+    double *Cc = C + colw + lc;
     double *ldsB = lds + kNBuf * kA;
     const unsigned lds_byte0 = lds_byte_address(lds);
     const double *ug = U + (int64_t)(k0 + wave * kRA) * ldu + lane * 2;
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restri
 #pragma unroll
     for (int t = 0; t < kT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = -Cc[(int64_t)(ib + 16 * t + kq + 4 * r) * ldv];
+        for (int r = 0; r < 4; ++r) acc[t][r] = -Cc[(int64_t)(ib + 16 * t + kq + 4 * r) * ldc];
 
     locate();
 #pragma unroll
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restri
 #pragma unroll
                 for (int t = 0; t < kT; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) accn[t][r] = -Cc[(int64_t)(i0 + kRB + 16 * t + kq + 4 * r) * ldv];
+                    for (int r = 0; r < 4; ++r) accn[t][r] = -Cc[(int64_t)(i0 + kRB + 16 * t + kq + 4 * r) * ldc];
                 asm volatile("" ::: "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restri
 #pragma unroll
         for (int t = 0; t < kT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Cc[(int64_t)(i0 + 16 * t + kq + 4 * r) * ldv] = -acc[t][r];
+            for (int r = 0; r < 4; ++r) Cc[(int64_t)(i0 + 16 * t + kq + 4 * r) * ldc] = -acc[t][r];
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int t = 0; t < kT; ++t) acc[t] = accn[t];
@@ -518,18 +522,26 @@ void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const doubl
 void launch_trsm_update(hipStream_t s, const double *U, int64_t ldu, double *V, int64_t ldv, int k0, int klen,
                         int i0_begin, int i0_end, int64_t m_pad, int chunk_blocks, bool half_lds)
 {
+    launch_gemm_update(s, U, ldu, V, ldv, V, ldv, k0, klen, i0_begin, i0_end, m_pad, chunk_blocks, half_lds, false);
+}
+
+void launch_gemm_update(hipStream_t s, const double *U, int64_t ldu, const double *V, int64_t ldv, double *C,
+                        int64_t ldc, int k0, int klen, int i0_begin, int i0_end, int64_t m_pad, int chunk_blocks,
+                        bool half_lds, bool upper_only)
+{
     if (i0_begin >= i0_end || m_pad <= 0 || klen <= 0) return;
     // klen is 128 or 256 (a multiple of the 32-row stage and at least two stages, which the vmcnt bookkeeping
     // assumes), the row range a multiple of 128
     const int chunk_rows = chunk_blocks * kRB;
     const unsigned chunks = (unsigned)((i0_end - i0_begin + chunk_rows - 1) / chunk_rows);
     const dim3 grid((unsigned)(m_pad / kStrip), chunks);
+    const int up = upper_only ? 1 : 0;
     if (!half_lds)
-        hipLaunchKernelGGL(trsm_update_kernel<32>, grid, dim3(256), 0, s, U, ldu, V, ldv, k0, klen, i0_begin, i0_end,
-                           chunk_rows);
+        hipLaunchKernelGGL(trsm_update_kernel<32>, grid, dim3(256), 0, s, U, ldu, V, ldv, C, ldc, k0, klen, i0_begin,
+                           i0_end, chunk_rows, up);
     else
-        hipLaunchKernelGGL(trsm_update_kernel<16>, grid, dim3(256), 0, s, U, ldu, V, ldv, k0, klen, i0_begin, i0_end,
-                           chunk_rows);
+        hipLaunchKernelGGL(trsm_update_kernel<16>, grid, dim3(256), 0, s, U, ldu, V, ldv, C, ldc, k0, klen, i0_begin,
+                           i0_end, chunk_rows, up);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -119,6 +119,11 @@ int cbo_gp_predict(cbo_gp *gp, int64_t m, const double *Xs, const double *prior_
  * device from the factor's diagonal and z = L^-1 r.  The optimiser loop itself is host logic. */
 int cbo_gp_set_hyper(cbo_gp *gp, double variance, const double *lengthscale, double noise_var);
 int cbo_gp_log_marginal(cbo_gp *gp, double *lml_out);
+/* The gradients GPy hands its optimiser (ExactGaussianInference dL_dK -> kern.update_gradients_full, dL_dthetaL):
+ * d log p(y) / d variance, / d lengthscale (1 value, or d values if ard), / d noise_var, of the fitted model, all on
+ * the device (Ky^-1 = L^-T L^-1 through the sweep and GEMM kernels, then one contraction pass).  lml_out may be NULL. */
+int cbo_gp_lml_gradients(cbo_gp *gp, double *lml_out, double *dvariance_out, double *dlengthscale_out,
+                         double *dnoise_out);
 
 /* Prediction gradients: emukit GPyModelWrapper.get_prediction_gradients -> GPy
  * predictive_gradients, called from CausalExpectedImprovement.evaluate_with_gradients

@@ -205,12 +205,30 @@ def log_marginal_likelihood(post):
     return float(0.5 * (-n * np.log(2 * np.pi) - 2.0 * np.sum(np.log(np.diag(post.L))) - np.sum(post.alpha * r)))
 
 
+def log_marginal_likelihood_gradients(post):
+    """What GPy's ExactGaussianInference hands the optimiser: dL_dK = 0.5 (alpha alpha^T - Ky^-1), contracted with
+    dK/dtheta by ``kern.update_gradients_full`` (GPy RBF / Stationary: dK/dvariance = K_rbf / variance,
+    dK/dlengthscale_k = K_rbf r_k^2 / lengthscale_k with r_k = (x_ik - x_jk) / lengthscale_k, summed over k when not
+    ARD) and dL_dthetaL = trace(dL_dK) for the Gaussian noise variance.  The causal rank-1 term of CausalRBF has no
+    parameter of its own.  Returns (dL/dvariance, dL/dlengthscale (array), dL/dnoise_var)."""
+    ls = np.atleast_1d(np.asarray(post.lengthscale, dtype=np.float64))
+    dL_dK = 0.5 * (post.alpha @ post.alpha.T - post.woodbury_inv)
+    Krbf = rbf_K(post.X, post.X, post.variance, post.lengthscale)
+    d_var = float(np.sum(dL_dK * Krbf) / post.variance)
+    diff2 = (post.X[:, None, :] - post.X[None, :, :]) ** 2                       # (N, N, d)
+    if ls.size == 1:
+        d_ls = np.array([np.sum(dL_dK * Krbf * diff2.sum(-1)) / ls[0] ** 3])
+    else:
+        d_ls = np.einsum("ij,ij,ijk->k", dL_dK, Krbf, diff2) / ls ** 3
+    return d_var, d_ls, float(np.trace(dL_dK))
+
+
 def optimize_hyperparameters(X, y, mX=None, vX=None, variance=REF_VARIANCE, lengthscale=REF_LENGTHSCALE,
                              noise_var=REF_NOISE_VAR, fix_noise=False, max_iters=1000):
     """Counterpart of GPy ``model.optimize()`` (src/CBO.py:173, src/utils_functions/utils.py:44) for the
-    product's host-side optimiser: same objective, same scipy L-BFGS-B call in log-parameter space with
-    finite-difference gradients.  (GPy itself uses analytic gradients and a softplus transform -- not
-    reproducible here, 'parity unpinned'.)  Returns (variance, lengthscale array, noise_var, lml)."""
+    product's host-side optimiser: same objective and analytic gradients, same scipy L-BFGS-B call in
+    log-parameter space.  (GPy itself optimises through a softplus transform -- not reproducible here,
+    'parity unpinned'.)  Returns (variance, lengthscale array, noise_var, lml)."""
     from scipy.optimize import minimize
     ls0 = np.atleast_1d(np.asarray(lengthscale, dtype=np.float64))
     nl = ls0.size
@@ -222,15 +240,18 @@ def optimize_hyperparameters(X, y, mX=None, vX=None, variance=REF_VARIANCE, leng
     def f(x):
         v, l, nz = unpack(x)
         try:
-            return -log_marginal_likelihood(fit(X, y, mX, vX, v, l, nz))
+            post = fit(X, y, mX, vX, v, l, nz)
         except np.linalg.LinAlgError:
-            return 1e25
+            return 1e25, np.zeros_like(x)
+        d_var, d_ls, d_noise = log_marginal_likelihood_gradients(post)
+        g = [d_var * v, *(d_ls * np.atleast_1d(l))] + ([] if fix_noise else [d_noise * nz])   # d/dlog(theta)
+        return -log_marginal_likelihood(post), -np.asarray(g, dtype=np.float64)
 
     x0 = np.log(np.asarray([variance, *ls0] + ([] if fix_noise else [noise_var]), dtype=np.float64))
-    res = minimize(f, x0, method="L-BFGS-B", options={"maxiter": int(max_iters), "maxfun": 15000})
-    best = res.x if res.fun <= f(x0) else x0
+    res = minimize(f, x0, jac=True, method="L-BFGS-B", options={"maxiter": int(max_iters), "maxfun": 15000})
+    best = res.x if res.fun <= f(x0)[0] else x0
     v, l, nz = unpack(best)
-    return float(v), np.atleast_1d(l), float(nz), -f(best)
+    return float(v), np.atleast_1d(l), float(nz), -f(best)[0]
 
 
 def predict_gradients(post, Xs, vXs=None):

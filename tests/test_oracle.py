@@ -160,3 +160,31 @@ def test_prediction_and_ei_gradients_against_finite_differences():
         ep, _ = O.expected_improvement_with_gradients(post, xs + e, float(y.min()))
         em, _ = O.expected_improvement_with_gradients(post, xs - e, float(y.min()))
         assert np.allclose((ep - em)[:, 0] / (2 * h), dei[:, k], rtol=1e-4, atol=1e-8)
+
+
+def test_likelihood_gradients_against_finite_differences():
+    """The analytic d log p(y)/d theta of the restatement (GPy's dL_dK contraction) against central differences of
+    its own likelihood: isotropic, ARD and causal kernels."""
+    rng = np.random.default_rng(12)
+    X = rng.uniform(-2, 2, (40, 3))
+    y = np.sin(X[:, :1]) + 0.3 * X[:, 1:2] + 0.05 * rng.standard_normal((40, 1))
+    mX = 0.1 * X[:, :1]
+    vX = 0.2 + 0.1 * np.cos(X[:, 2:3]) ** 2
+    for kw in (dict(variance=1.3, lengthscale=0.8, noise_var=0.05),
+               dict(variance=0.7, lengthscale=np.array([0.6, 1.1, 2.0]), noise_var=0.02),
+               dict(mX=mX, vX=vX, variance=1.1, lengthscale=0.9, noise_var=0.03)):
+        post = O.fit(X, y, **kw)
+        d_var, d_ls, d_noise = O.log_marginal_likelihood_gradients(post)
+
+        def lml(**over):
+            return O.log_marginal_likelihood(O.fit(X, y, **{**kw, **over}))
+        h = 1e-6
+        assert d_var == pytest.approx((lml(variance=kw["variance"] + h) - lml(variance=kw["variance"] - h)) / (2 * h), rel=1e-6)
+        assert d_noise == pytest.approx((lml(noise_var=kw["noise_var"] + h) - lml(noise_var=kw["noise_var"] - h)) / (2 * h), rel=1e-5)
+        ls = np.atleast_1d(np.asarray(kw["lengthscale"], dtype=np.float64))
+        for k in range(ls.size):
+            up, dn = ls.copy(), ls.copy()
+            up[k] += h; dn[k] -= h
+            wrap = (lambda a: a[0]) if ls.size == 1 else (lambda a: a)
+            fd = (lml(lengthscale=wrap(up)) - lml(lengthscale=wrap(dn))) / (2 * h)
+            assert d_ls[k] == pytest.approx(fd, rel=1e-6), k

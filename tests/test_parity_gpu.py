@@ -693,6 +693,8 @@ def test_schedule_selection(hip):
     (checked through the launch count the timers report)."""
     from cbo_with_oop_amd import CandidateGrid, CausalExpectedImprovement, _lib
     from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    if os.environ.get("CBO_HIP_SWEEP") is not None:
+        pytest.skip("the schedule is pinned by CBO_HIP_SWEEP")
     rng = np.random.default_rng(2)
     X = rng.uniform(-3, 3, (1100, 2)); y = np.cos(X[:, :1])
     model = HipGaussianProcess(X, y, noise_var=1e-2)
@@ -793,3 +795,38 @@ def test_path_with_deferred_refit_takes_the_same_decisions(hip):
         picks.append(trace)
     assert [t[0] for t in picks[0]] == [t[0] for t in picks[1]]
     np.testing.assert_allclose([t[1] for t in picks[0]], [t[1] for t in picks[1]], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,d,ard,causal", [(60, 1, False, False), (200, 3, False, False), (333, 4, True, False),
+                                            (1100, 3, False, True), (1500, 2, True, False)])
+def test_likelihood_gradients_match_the_restatement(hip, n, d, ard, causal):
+    """cbo_gp_lml_gradients (Ky^-1 = L^-T L^-1 by the sweep and GEMM kernels, contraction on the device) against the
+    oracle's analytic gradients; n >= 1024 exercises the right-looking inverse and several panel pairs."""
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    rng = np.random.default_rng(n + d)
+    X = rng.uniform(-2, 2, (n, d))
+    y = np.sin(X[:, :1]) + 0.2 * X[:, -1:] + 0.05 * rng.standard_normal((n, 1))
+    ls = np.linspace(0.7, 1.6, d) if ard else 0.9
+    kw = dict(variance=1.2, lengthscale=ls, noise_var=0.04)
+    okw = dict(kw)
+    if causal:
+        mean_fn = lambda a: 0.1 * a[:, :1]
+        var_fn = lambda a: 0.2 + 0.1 * np.cos(a[:, 1:2]) ** 2
+        kw.update(mean_function=mean_fn, variance_adjustment=var_fn)
+        okw.update(mX=mean_fn(X), vX=var_fn(X))
+    m = HipGaussianProcess(X, y, ard=ard, **kw)
+    dv, dls, dn = m.log_likelihood_gradients()
+    post = O.fit(X, y, **okw)
+    o_dv, o_dls, o_dn = O.log_marginal_likelihood_gradients(post)
+    scale = max(abs(o_dv), np.max(np.abs(o_dls)), abs(o_dn))
+    assert m._last_lml == pytest.approx(O.log_marginal_likelihood(post), rel=1e-9)
+    assert dv == pytest.approx(o_dv, rel=1e-6, abs=1e-8 * scale)
+    assert dn == pytest.approx(o_dn, rel=1e-6, abs=1e-8 * scale)
+    np.testing.assert_allclose(dls, o_dls, rtol=1e-6, atol=1e-8 * scale)
+    # the sweep state is untouched by the gradient call: a sweep afterwards equals one before
+    from cbo_with_oop_amd import CausalExpectedImprovement
+    Xs = rng.uniform(-2, 2, (130, d))
+    a = CausalExpectedImprovement(0.0, "min", m).sweep(Xs, want_acq=True)
+    m.log_likelihood_gradients()
+    b = CausalExpectedImprovement(0.0, "min", m).sweep(Xs, want_acq=True)
+    assert np.array_equal(a["acq"], b["acq"])
