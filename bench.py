@@ -129,6 +129,7 @@ def main():
     ctx = _lib.Context.get(local_rank % max(1, _lib.device_count()))
     lib = _lib.load()
     X, y, Xs, grid = make_problem(world)
+    lo_box, hi_box = np.array([b[0] for b in BOX]), np.array([b[1] for b in BOX])
     y_best, cost = float(y.min()), 3.0                     # incumbent = best observation; type_cost 1 -> |set| = 3
     begin, end = shard_bounds(Xs.shape[0], world, rank)
 
@@ -243,6 +244,26 @@ def main():
                                    "unit": "GB/s", "frac": (kxx_bytes / (kxx_ms * 1e-3) / 1e9 / 8000.0) if kxx_ms > 0 else 0.0,
                                    "avg_launch_ms": kxx_ms, "algorithmic_bytes_per_launch": kxx_bytes,
                                    "note": "fp64 exp per element: ALU-bound below the HBM roof (DESIGN.md 4)"}
+        if world == 1 and args.post_steps > 0:
+            # the north-star's HBM-bound size: K(X,X) assembly for 16384 points (one fit of such a model)
+            n16 = 16384
+            X16 = np.random.default_rng(2).uniform(lo_box, hi_box, (n16, 3))
+            y16 = np.sin(X16).sum(1, keepdims=True)
+            m16 = HipGaussianProcess(X16, y16, context=ctx, noise_var=1e-2, fit=False)
+            _lib.check(lib.cbo_gp_fit(m16._handle, None, None))
+            ctx.set_profiling(True)
+            ctx.reset_timers()
+            _lib.check(lib.cbo_gp_fit(m16._handle, None, None))
+            t16 = ctx.timers()
+            ctx.set_profiling(False)
+            m16.close()
+            nt16 = n16 // 64
+            b16 = nt16 * (nt16 + 1) // 2 * 64 * 64 * 8
+            out["roofline_kxx_16k"] = {"kernel": "kmat_tile_kernel<3> + rhs at 16384 points (BASELINE north_star size)",
+                                       "bound": "hbm", "achieved": b16 / (t16["ms_kxx"] * 1e-3) / 1e9, "peak": 8000.0,
+                                       "unit": "GB/s", "frac": b16 / (t16["ms_kxx"] * 1e-3) / 1e9 / 8000.0,
+                                       "avg_launch_ms": t16["ms_kxx"], "algorithmic_bytes_per_launch": b16,
+                                       "cholesky_ms": t16["ms_chol"]}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(X, y, Xs, y_best, cost, min(args.cpu_sample, Xs.shape[0]))
         else:
