@@ -1,6 +1,7 @@
 // C-ABI host side of libcbo_hip.so (declared in include/cbo_hip.h): handle management, the jitchol
 // retry ladder, candidate chunking, profiling events.  All arithmetic of the path runs in the HIP
 // kernels of kernels_*.hip; there is no CPU fallback here.
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -12,6 +13,7 @@
 using namespace cbo;
 
 static thread_local std::string g_err;
+static std::atomic<uint64_t> g_fit_stamp{0};
 
 static int fail(int code, const std::string &msg)
 {
@@ -47,6 +49,7 @@ struct cbo_ctx {
     bool pipe_half_lds = true;
     double pipe_tail_frac = -1.0;    // CBO_HIP_PIPE_TAIL: rows (fraction) left to the closing left-looking launch; < 0 = automatic
     int n_cu = 256;
+    bool sweep_cache = true;         // CBO_HIP_SWEEP_CACHE=0: never reuse a candidate set's q, mu between sweeps
     int sweep_mode = -1;             // CBO_HIP_SWEEP: 0 = always left-looking, 1 = always right-looking, else automatic
     int overlap_mode = -1;           // CBO_HIP_OVERLAP: 0 = cbo_gp_fit_sweep never overlaps, 1 = always, else automatic
     bool profiling = false;
@@ -84,6 +87,7 @@ struct cbo_gp {
     double *z = nullptr;             // [n_pad] contiguous copy of L^-1 r
     int *info = nullptr;
     bool fitted = false;
+    uint64_t fit_stamp = 0;          // unique per successful fit (0 = not fitted); candidates key their cache on it
     bool alpha_ready = false;
     int tries = 0;
     double jitter = 0.0;
@@ -100,6 +104,10 @@ struct cbo_cands {
     PointSet P;
     const cbo_gp *prepared_for = nullptr;
     std::vector<double> prepared_ls;
+    // q = sum V^2 and mu = V^T z of the last sweep, valid while the model's fit stamp is the one recorded here:
+    // between refits only the incumbent changes, and EI / cost / arg-max are recomputed from these two vectors
+    double *q = nullptr, *mu = nullptr;
+    uint64_t fit_stamp = 0;
 };
 
 // ---- profiling helpers ---------------------------------------------------------------------------
@@ -246,6 +254,8 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
     c->n_cu = prop.multiProcessorCount;
     const char *sm = std::getenv("CBO_HIP_SWEEP");
     if (sm) c->sweep_mode = std::atoi(sm);
+    const char *sc = std::getenv("CBO_HIP_SWEEP_CACHE");
+    if (sc && std::atoi(sc) == 0) c->sweep_cache = false;
     const char *om = std::getenv("CBO_HIP_OVERLAP");
     if (om) c->overlap_mode = std::atoi(om);
     const char *tf = std::getenv("CBO_HIP_PIPE_TAIL");
@@ -519,6 +529,7 @@ extern "C" int cbo_gp_fit(cbo_gp *g, int *tries_out, double *jitter_out)
                              (size_t)g->n_pad, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipGetLastError());
     g->fitted = true;
+    g->fit_stamp = ++g_fit_stamp;
     g->alpha_ready = false;
     g->tries = tries;
     g->jitter = jitter;
@@ -643,7 +654,7 @@ extern "C" void cbo_cands_destroy(cbo_cands *k)
     if (!k) return;
     hipSetDevice(k->ctx->device);
     hipStreamSynchronize(k->ctx->stream);
-    hipFree(k->raw); hipFree(k->pm); hipFree(k->pv);
+    hipFree(k->raw); hipFree(k->pm); hipFree(k->pv); hipFree(k->q); hipFree(k->mu);
     hipFree(k->P.xs); hipFree(k->P.sq); hipFree(k->P.sv);
     delete k;
 }
@@ -844,6 +855,19 @@ static int finish_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task, double
                         double *acq_out, double *mean_out, double *var_out, double *best_val, int64_t *best_idx)
 {
     cbo_ctx *c = g->ctx;
+    // keep q, mu with the candidates (two small device copies): the next sweep of an unchanged model skips the
+    // substitution altogether
+    const bool cached = k->fit_stamp != 0 && k->fit_stamp == g->fit_stamp;
+    if (!cached && c->sweep_cache) {
+        if (!k->q) {
+            HIP_TRY(hipMalloc(&k->q, sizeof(double) * k->m_pad));
+            HIP_TRY(hipMalloc(&k->mu, sizeof(double) * k->m_pad));
+        }
+        HIP_TRY(hipMemcpyAsync(k->q, c->q, sizeof(double) * k->m_pad, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(k->mu, c->mu, sizeof(double) * k->m_pad, hipMemcpyDeviceToDevice, c->stream));
+        k->fit_stamp = g->fit_stamp;
+    }
+    const double *q_src = cached ? k->q : c->q, *mu_src = cached ? k->mu : c->mu;
     const bool causal = g->X.sv != nullptr;
     AcqParams p;
     p.variance = g->h.variance; p.noise_var = g->noise_var; p.y_best = y_best; p.ei_jitter = ei_jitter; p.cost = cost;
@@ -851,7 +875,7 @@ static int finish_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task, double
     const int nb = acq_blocks_for(k->m);
     {
         PhaseScope ps(c, PH_ACQ);
-        launch_acq(c->stream, c->q, c->mu, causal ? k->pm : nullptr, causal ? k->pv : nullptr, k->m, p,
+        launch_acq(c->stream, q_src, mu_src, causal ? k->pm : nullptr, causal ? k->pv : nullptr, k->m, p,
                    mean_out ? c->mean : nullptr, var_out ? c->var : nullptr, acq_out ? c->acq : nullptr, c->part_val,
                    c->part_idx, k->index_offset, nb);
         launch_argmax_final(c->stream, c->part_val, c->part_idx, nb, c->best_val, c->best_idx);
@@ -877,8 +901,15 @@ extern "C" int cbo_acq_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task, d
     if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
     cbo_ctx *c = g->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    rc = enqueue_posterior(g, k);
-    if (rc != CBO_OK) return rc;
+    if (!(c->sweep_cache && k->fit_stamp != 0 && k->fit_stamp == g->fit_stamp)) {
+        k->fit_stamp = 0;
+        rc = enqueue_posterior(g, k);
+        if (rc != CBO_OK) return rc;
+    } else if ((size_t)k->m_pad > c->vec_elems) {
+        int64_t chunk = 0, ldv = 0;                      // mean / var / acq scratch of the epilogue
+        rc = ensure_workspaces(c, g->n_pad, k->m_pad, &chunk, &ldv);
+        if (rc != CBO_OK) return rc;
+    }
     return finish_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
 }
 
@@ -970,6 +1001,7 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
         if (rc != CBO_OK) return rc;
     }
     g->fitted = true;
+    g->fit_stamp = ++g_fit_stamp;
     g->alpha_ready = false;
     g->tries = tries;
     g->jitter = jitter;

@@ -894,3 +894,40 @@ def test_complete_graph_trial_loop_end_to_end(hip):
     dev, cpu = run(True), run(False)
     assert [(s, x) for s, x, _ in dev] == [(s, x) for s, x, _ in cpu], (dev, cpu)
     np.testing.assert_allclose([y for _, _, y in dev], [y for _, _, y in cpu], rtol=1e-12)
+
+
+def test_unchanged_model_resweeps_from_cached_q_mu(hip, monkeypatch):
+    """Between refits only the incumbent (and the cost) change: a candidate set keeps q = sum V^2 and mu = V^T z of
+    its last sweep, stamped with the model's fit, and the next sweep of the unchanged model recomputes EI / cost /
+    arg-max from them without touching the substitution.  Same bits as a cold sweep; a refit invalidates."""
+    from cbo_with_oop_amd import CandidateGrid, CausalExpectedImprovement, _lib
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    rng = np.random.default_rng(77)
+    X = rng.uniform(-2, 2, (700, 2)); y = np.cos(X[:, :1]) * X[:, 1:2] + 0.05 * rng.standard_normal((700, 1))
+    Xs = rng.uniform(-2, 2, (3000, 2))
+    ctx = _lib.Context.get()
+    model = HipGaussianProcess(X, y, noise_var=1e-3)
+    grid = CandidateGrid(Xs, model)
+    first = CausalExpectedImprovement(0.3, "min", model).sweep(grid, cost=1.0, want_acq=True, want_posterior=True)
+    ctx.set_profiling(True); ctx.reset_timers()
+    warm = CausalExpectedImprovement(-0.2, "max", model).sweep(grid, cost=2.5, want_acq=True, want_posterior=True)
+    launches = ctx.timers()["n_trsm_launches"]
+    ctx.set_profiling(False)
+    assert launches == 0
+    cold_ctx = forced_context(monkeypatch, CBO_HIP_SWEEP_CACHE=0)
+    cold_model = HipGaussianProcess(X, y, noise_var=1e-3, context=cold_ctx)
+    cold = CausalExpectedImprovement(-0.2, "max", cold_model).sweep(CandidateGrid(Xs, cold_model, context=cold_ctx), cost=2.5,
+                                                                    want_acq=True, want_posterior=True)
+    for key in ("acq", "mean", "var"):
+        assert np.array_equal(warm[key], cold[key]), key
+    assert warm["best_idx"] == cold["best_idx"] and np.array_equal(warm["mean"], first["mean"])
+    # new data -> new fit stamp -> the substitution runs again
+    X2 = np.vstack([X, [[0.1, 0.2]]]); y2 = np.vstack([y, [[1.5]]])
+    model.set_data(X2, y2)
+    ctx.set_profiling(True); ctx.reset_timers()
+    after = CausalExpectedImprovement(-0.2, "max", model).sweep(grid, cost=2.5, want_posterior=True)
+    assert ctx.timers()["n_trsm_launches"] >= 1
+    ctx.set_profiling(False)
+    mu, var = O.predict(O.fit(X2, y2, noise_var=1e-3), Xs)
+    np.testing.assert_allclose(after["mean"], mu, rtol=1e-6, atol=1e-9)
+    cold_model.close(); cold_ctx.close()
