@@ -931,3 +931,43 @@ def test_unchanged_model_resweeps_from_cached_q_mu(hip, monkeypatch):
     mu, var = O.predict(O.fit(X2, y2, noise_var=1e-3), Xs)
     np.testing.assert_allclose(after["mean"], mu, rtol=1e-6, atol=1e-9)
     cold_model.close(); cold_ctx.close()
+
+
+def test_overlapped_call_retries_with_jitter_and_handles_causal_ard(hip, monkeypatch):
+    """The pipelined schedule itself (n_pad >= 1024, so no fallback) on the awkward inputs: (1) duplicated rows
+    without noise -> the first factorisation fails while sweep kernels are already in flight; the whole pipeline
+    (K* included) is redone along GPy's jitter ladder and ends where the two calls end; (2) a causal kernel
+    (prior mean / variance on observations and candidates) with ARD lengthscales."""
+    import warnings
+    from cbo_with_oop_amd import CandidateGrid, CausalExpectedImprovement
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    rng = np.random.default_rng(5)
+    base = rng.uniform(-2, 2, (600, 2))
+    X = np.vstack([base, base])                              # every row twice ...
+    y = np.vstack([np.sin(base[:, :1]), np.sin(base[:, :1])])
+    Xs = rng.uniform(-2, 2, (5000, 2))
+    kw = dict(noise_var=-1e-8 - 1e-9)                       # ... and a 'noise' that cancels GPy's 1e-8: singular Ky
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        eager = HipGaussianProcess(X, y, **kw)
+        assert eager.jitter_tries >= 1
+        two = CausalExpectedImprovement(0.0, "min", eager).sweep(Xs, want_acq=True, want_posterior=True)
+        lazy = HipGaussianProcess(X, y, fit=False, **kw)
+        one = CausalExpectedImprovement(0.0, "min", lazy).sweep(Xs, want_acq=True, want_posterior=True)
+    assert (lazy.jitter_tries, lazy.jitter) == (eager.jitter_tries, eager.jitter)
+    for key in ("acq", "mean", "var"):
+        assert np.array_equal(one[key], two[key]), key
+    # causal + ARD through the pipeline, against the oracle
+    n, d = 1300, 3
+    X = rng.uniform(-2, 2, (n, d)); y = np.cos(X[:, :1]) + 0.3 * X[:, 1:2] + 0.05 * rng.standard_normal((n, 1))
+    Xs = rng.uniform(-2, 2, (2500, d))
+    mean_fn = lambda a: 0.2 * a[:, :1]
+    var_fn = lambda a: 0.1 + 0.05 * np.sin(a[:, 2:3]) ** 2
+    ls = np.array([0.8, 1.2, 1.7])
+    m = HipGaussianProcess(X, y, variance=1.1, lengthscale=ls, ard=True, noise_var=1e-2, mean_function=mean_fn,
+                           variance_adjustment=var_fn, fit=False)
+    res = CausalExpectedImprovement(float(y.min()), "min", m).sweep(CandidateGrid(Xs, m), cost=2.0, want_posterior=True)
+    post = O.fit(X, y, mean_fn(X), var_fn(X), 1.1, ls, 1e-2)
+    mu, var = O.predict(post, Xs, mean_fn(Xs), var_fn(Xs))
+    np.testing.assert_allclose(res["mean"], mu, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(res["var"], var, rtol=1e-6, atol=1e-10)
