@@ -18,7 +18,7 @@ class CBOAcquisitionPath:
     ``exploration_set``, ``costs``, ``task``, per-set data, spaces, prior closures and models."""
 
     def __init__(self, gp_type, exploration_set, costs, task, data_x, data_y, space_list, mean_functions=None,
-                 var_functions=None, grid_shapes=None):
+                 var_functions=None, grid_shapes=None, keep_solutions=True):
         self.gp_type = gp_type
         self.exploration_set = exploration_set
         self.es_size = len(exploration_set)
@@ -33,6 +33,9 @@ class CBOAcquisitionPath:
         self.models = []
         self.last_intervention = None
         self._grids = {}          # per set: (grid shape, prior closures, device-resident candidate grid)
+        # keep L^-1 K* of every set's grid on the device: a trial then costs the set intervened on one forward
+        # solve and one new row (append-only step) instead of a refit and a full sweep
+        self.keep_solutions = bool(keep_solutions)
 
     def update_all_gaussian_processes(self):
         """CBO.py:209-222."""
@@ -68,7 +71,8 @@ class CBOAcquisitionPath:
         if cached is None or cached[0] != key:
             if cached is not None:
                 cached[1].close()
-            cached = (key, CandidateGrid(meshgrid_candidates(bounds, shape), self.models[s]))
+            cached = (key, CandidateGrid(meshgrid_candidates(bounds, shape), self.models[s],
+                                         keep_solution=self.keep_solutions))
             self._grids[s] = cached
         return cached[1]
 

@@ -175,6 +175,26 @@ class HipGaussianProcess:
         _lib.check(self._lib.cbo_gp_jitter(self._handle, ctypes.byref(tries), ctypes.byref(jitter)))
         self.jitter_tries, self.jitter = tries.value, jitter.value
 
+    def append(self, x_new, y_new):
+        """One more observation (what every CBO trial adds to the set it intervened on): the factor grows by one
+        column on the device instead of being rebuilt (``cbo_gp_append``).  Returns False -- and changes nothing --
+        when the shortcut does not apply (model not fitted yet, jitter in the factor, padded size exhausted,
+        non-positive pivot); the caller then uses ``set_data``."""
+        if self.stale:
+            return False
+        x_new = _lib.as_f64(x_new).reshape(1, self.input_dim)
+        y_val = float(np.asarray(y_new, dtype=np.float64).reshape(-1)[0])
+        pm, pv = self._prior(x_new)
+        done = ctypes.c_int(0)
+        _lib.check(self._lib.cbo_gp_append(self._handle, _lib.dptr(x_new), y_val, float(pm[0]) if pm is not None else 0.0,
+                                           float(pv[0]) if pv is not None else 0.0, ctypes.byref(done)))
+        if not done.value:
+            return False
+        self.X = np.vstack([self.X, x_new])
+        self.Y = np.vstack([self.Y, [[y_val]]])
+        self._y_flat = np.ascontiguousarray(self.Y[:, 0])
+        return True
+
     def ensure_fitted(self):
         """Fit now if the data were replaced with ``set_data(..., fit=False)`` and nothing has refitted since."""
         if self.stale:
@@ -209,7 +229,13 @@ class HipGaussianProcess:
         trial): the hyper-parameters the constructor was given, the new data.  Same device handle and buffers, so
         nothing is allocated when the padded size does not change."""
         v0, ls0, nv0 = self._initial_hyper
-        if (self.variance, self.noise_var) != (v0, nv0) or not np.array_equal(self.lengthscale, ls0):
+        same_hyper = (self.variance, self.noise_var) == (v0, nv0) and np.array_equal(self.lengthscale, ls0)
+        X = _lib.as_f64(X)
+        Y = _lib.as_f64(Y).reshape(-1, 1)
+        if same_hyper and not self.stale and X.shape[0] == self.X.shape[0] + 1 and X.shape[1:] == self.X.shape[1:] \
+                and np.array_equal(X[:-1], self.X) and np.array_equal(Y[:-1], self.Y) and self.append(X[-1], Y[-1]):
+            return                                   # the data grew by one row: the factor grew by one column
+        if not same_hyper:
             self.set_hyperparameters(v0, ls0, nv0, fit=False)
         self.set_data(X, Y, fit=fit)
 

@@ -99,6 +99,9 @@ SIGNATURES = {
     "cbo_cands_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, c_double_p, c_double_p,
                                         c_double_p, ctypes.c_int64, c_void_pp]),
     "cbo_cands_destroy": (None, [ctypes.c_void_p]),
+    "cbo_cands_keep_solution": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "cbo_gp_append": (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                     c_int_p]),
     "cbo_acq_sweep": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_int,
                                      ctypes.c_double, ctypes.c_double, c_double_p, c_double_p, c_double_p,
                                      c_double_p, c_int64_p]),

@@ -91,6 +91,11 @@ struct cbo_gp {
     bool alpha_ready = false;
     int tries = 0;
     double jitter = 0.0;
+    // append-only trial step: the fit this one extends by one observation, and what extending V needs
+    uint64_t parent_stamp = 0;
+    double append_d = 0.0, append_zn = 0.0;
+    double *lvec = nullptr;          // [n_pad] the new column of U, contiguous
+    cbo_cands *probe = nullptr;      // the appended point as a one-candidate set (scaled coordinates, prior)
 };
 
 struct cbo_cands {
@@ -108,6 +113,12 @@ struct cbo_cands {
     // between refits only the incumbent changes, and EI / cost / arg-max are recomputed from these two vectors
     double *q = nullptr, *mu = nullptr;
     uint64_t fit_stamp = 0;
+    // cbo_cands_keep_solution: V = L^-1 K* stays resident so that an appended observation extends it by one row
+    bool keep_v = false;
+    double *V = nullptr;
+    int64_t v_ld = 0, v_rows_cap = 0, v_rows = 0;
+    uint64_t v_stamp = 0;
+    double *partial = nullptr;       // [64][m_pad] slice sums of the row update
 };
 
 // ---- profiling helpers ---------------------------------------------------------------------------
@@ -360,9 +371,10 @@ extern "C" int cbo_device_name(cbo_ctx *c, char *buf, int buflen)
 static void free_gp_data(cbo_gp *g)
 {
     hipFree(g->X.xs); hipFree(g->X.sq); hipFree(g->X.sv); hipFree(g->X.pm); hipFree(g->X.pv);
-    hipFree(g->raw); hipFree(g->y); hipFree(g->A); hipFree(g->invDt); hipFree(g->alpha); hipFree(g->z);
+    hipFree(g->raw); hipFree(g->y); hipFree(g->A); hipFree(g->invDt); hipFree(g->alpha); hipFree(g->z); hipFree(g->lvec);
     g->X = PointSet{};
-    g->raw = g->y = g->A = g->invDt = g->alpha = g->z = nullptr;
+    g->raw = g->y = g->A = g->invDt = g->alpha = g->z = g->lvec = nullptr;
+    g->parent_stamp = 0;
     g->n = g->n_pad = 0;             // no storage: every entry point that needs data checks g->n
     g->fitted = false;
 }
@@ -391,6 +403,7 @@ static int upload_gp_data(cbo_gp *g, int64_t n, const double *X, const double *y
         HIP_TRY(hipMalloc(&g->invDt, sizeof(double) * (n_pad / 16) * 256));
         HIP_TRY(hipMalloc(&g->alpha, sizeof(double) * 2 * n_pad));
         HIP_TRY(hipMalloc(&g->z, sizeof(double) * n_pad));
+        HIP_TRY(hipMalloc(&g->lvec, sizeof(double) * n_pad));
         g->n_pad = n_pad;            // only now: a failed allocation above leaves the handle empty (n_pad == 0)
     }
     g->n = n;
@@ -445,6 +458,7 @@ extern "C" int cbo_gp_create(cbo_ctx *c, int dtype, int64_t n, int d, const doub
 
 extern "C" void cbo_gp_destroy(cbo_gp *g)
 {
+    if (g && g->probe) { cbo_cands_destroy(g->probe); g->probe = nullptr; }
     if (!g) return;
     hipSetDevice(g->ctx->device);
     hipStreamSynchronize(g->ctx->stream);
@@ -530,6 +544,7 @@ extern "C" int cbo_gp_fit(cbo_gp *g, int *tries_out, double *jitter_out)
     HIP_TRY(hipGetLastError());
     g->fitted = true;
     g->fit_stamp = ++g_fit_stamp;
+    g->parent_stamp = 0;
     g->alpha_ready = false;
     g->tries = tries;
     g->jitter = jitter;
@@ -654,7 +669,7 @@ extern "C" void cbo_cands_destroy(cbo_cands *k)
     if (!k) return;
     hipSetDevice(k->ctx->device);
     hipStreamSynchronize(k->ctx->stream);
-    hipFree(k->raw); hipFree(k->pm); hipFree(k->pv); hipFree(k->q); hipFree(k->mu);
+    hipFree(k->raw); hipFree(k->pm); hipFree(k->pv); hipFree(k->q); hipFree(k->mu); hipFree(k->V); hipFree(k->partial);
     hipFree(k->P.xs); hipFree(k->P.sq); hipFree(k->P.sv);
     delete k;
 }
@@ -805,6 +820,24 @@ static int enqueue_right_looking(cbo_gp *g, double *V, int64_t ldv, int64_t cols
     return CBO_OK;
 }
 
+// The candidates' own V buffer (cbo_cands_keep_solution), sized for the model's padded row count.
+static int own_solution_buffer(cbo_gp *g, cbo_cands *k, double **V, int64_t *ldv)
+{
+    cbo_ctx *c = g->ctx;
+    if (!k->V || k->v_rows_cap != g->n_pad) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(k->V); hipFree(k->partial);
+        k->V = nullptr; k->partial = nullptr; k->v_stamp = 0;
+        k->v_ld = k->m_pad + kLdExtra;
+        HIP_TRY(hipMalloc(&k->V, sizeof(double) * (size_t)g->n_pad * (size_t)k->v_ld));
+        HIP_TRY(hipMalloc(&k->partial, sizeof(double) * 64 * (size_t)k->m_pad));
+        k->v_rows_cap = g->n_pad;
+    }
+    *V = k->V;
+    *ldv = k->v_ld;
+    return CBO_OK;
+}
+
 // q = colsum((L^-1 K*)^2), mu = (L^-1 K*)^T z for all candidates, chunk by chunk.
 static int enqueue_posterior(cbo_gp *g, cbo_cands *k)
 {
@@ -814,20 +847,26 @@ static int enqueue_posterior(cbo_gp *g, cbo_cands *k)
     int64_t chunk = 0, ldv = 0;
     rc = ensure_workspaces(c, g->n_pad, k->m_pad, &chunk, &ldv);
     if (rc != CBO_OK) return rc;
+    double *Vws = c->V;
+    k->v_stamp = 0;
+    if (k->keep_v && chunk >= k->m_pad) {                    // one chunk: the solution can stay with the candidates
+        rc = own_solution_buffer(g, k, &Vws, &ldv);
+        if (rc != CBO_OK) return rc;
+    }
     for (int64_t c0 = 0; c0 < k->m_pad; c0 += chunk) {
         const int64_t cols = (k->m_pad - c0 < chunk) ? (k->m_pad - c0) : chunk;
         {
             PhaseScope ps(c, PH_KSTAR);
-            launch_kstar(c->stream, g->X, k->P, c0, cols, g->h, c->V, ldv, g->n_pad);
+            launch_kstar(c->stream, g->X, k->P, c0, cols, g->h, Vws, ldv, g->n_pad);
         }
         if (prefer_right_looking(c, g->n_pad, cols)) {
-            rc = enqueue_right_looking(g, c->V, ldv, cols, c->q + c0, c->mu + c0);
+            rc = enqueue_right_looking(g, Vws, ldv, cols, c->q + c0, c->mu + c0);
             if (rc != CBO_OK) return rc;
             continue;
         }
         {
             PhaseScope ps(c, PH_TRSM);
-            launch_trsm_strips(c->stream, g->A, g->lda, g->invDt, c->V, ldv, g->n_pad, cols, g->z, c->q + c0,
+            launch_trsm_strips(c->stream, g->A, g->lda, g->invDt, Vws, ldv, g->n_pad, cols, g->z, c->q + c0,
                                c->mu + c0);
         }
         if (c->profiling) {
@@ -836,6 +875,7 @@ static int enqueue_posterior(cbo_gp *g, cbo_cands *k)
         }
     }
     HIP_TRY(hipGetLastError());
+    if (Vws != c->V) { k->v_stamp = g->fit_stamp; k->v_rows = g->n; }
     return CBO_OK;
 }
 
@@ -893,6 +933,104 @@ static int finish_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task, double
     return CBO_OK;
 }
 
+// V[n-1, :] for a model that was extended by cbo_gp_append: k(x_new, X*) by the K* kernel with the appended point as
+// its only row, then the row update; q, mu (the candidates' cached copies) move along and take the new fit stamp.
+static int extend_solution_by_one_row(cbo_gp *g, cbo_cands *k)
+{
+    cbo_ctx *c = g->ctx;
+    int rc = prepare_cands(g, k);
+    if (rc != CBO_OK) return rc;
+    int64_t chunk = 0, ldv = 0;
+    rc = ensure_workspaces(c, g->n_pad, k->m_pad, &chunk, &ldv);      // c->V: scratch for the 64-row K* slab
+    if (rc != CBO_OK) return rc;
+    if (chunk < k->m_pad) return CBO_OK;                               // cannot happen for a resident V; fall through
+    const int64_t row = g->n - 1;
+    PointSet one = g->probe->P;                                        // the appended point, scaled as the model's
+    one.n = 1;
+    launch_kstar(c->stream, one, k->P, 0, k->m_pad, g->h, c->V, ldv, 64);
+    launch_append_row(c->stream, k->V, k->v_ld, row, g->lvec, k->m_pad, c->V, g->append_d, g->append_zn, k->partial,
+                      k->q, k->mu);
+    HIP_TRY(hipGetLastError());
+    k->v_rows = g->n;
+    k->v_stamp = g->fit_stamp;
+    k->fit_stamp = g->fit_stamp;
+    return CBO_OK;
+}
+
+extern "C" int cbo_cands_keep_solution(cbo_cands *k, int on)
+{
+    if (!k) return fail(CBO_ERR_INVALID, "cands is NULL");
+    k->keep_v = on != 0;
+    if (!k->keep_v) {
+        hipSetDevice(k->ctx->device);
+        hipStreamSynchronize(k->ctx->stream);
+        hipFree(k->V); hipFree(k->partial);
+        k->V = nullptr; k->partial = nullptr; k->v_stamp = 0; k->v_rows_cap = 0;
+    }
+    return CBO_OK;
+}
+
+// One more observation for a fitted model (the step src/Monitor.py:148-160 + src/CBO.py:224-235 take every trial):
+// the factor, z and the resident data grow by one row instead of being rebuilt.  *appended_out = 0 (and nothing
+// changed) when the shortcut does not apply -- the current factor carries jitter, the padded size is exhausted, or
+// the new pivot is not positive -- and the caller refits with cbo_gp_set_data.
+extern "C" int cbo_gp_append(cbo_gp *g, const double *x_new, double y_new, double prior_mean_new, double prior_var_new,
+                             int *appended_out)
+{
+    if (!g || !x_new || !appended_out) return fail(CBO_ERR_INVALID, "NULL argument");
+    *appended_out = 0;
+    if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
+    if (g->tries != 0 || g->n >= g->n_pad) return CBO_OK;
+    cbo_ctx *c = g->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const bool causal = g->X.sv != nullptr;
+    // the new point as a one-candidate set (kept with the model: no allocation after the first append)
+    if (g->probe) {
+        cbo_cands *p = g->probe;
+        HIP_TRY(hipMemcpyAsync(p->raw, x_new, sizeof(double) * g->d, hipMemcpyHostToDevice, c->stream));
+        if (causal) {
+            HIP_TRY(hipMemcpyAsync(p->pm, &prior_mean_new, sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(p->pv, &prior_var_new, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));          // x_new and the two scalars are the caller's / this frame's
+        p->prepared_for = nullptr;
+        p->fit_stamp = 0;
+    } else {
+        int rc = cbo_cands_create(c, 1, g->d, x_new, causal ? &prior_mean_new : nullptr, causal ? &prior_var_new : nullptr,
+                                  0, &g->probe);
+        if (rc != CBO_OK) return rc;
+    }
+    int rc = enqueue_posterior(g, g->probe);               // c->V[:, 0] = l, c->q[0] = l^T l, c->mu[0] = l^T z
+    if (rc != CBO_OK) return rc;
+    double h2[2];
+    HIP_TRY(hipMemcpyAsync(&h2[0], c->q, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&h2[1], c->mu, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const double kappa = g->h.variance + (causal ? prior_var_new : 0.0) + (g->noise_var + kGpyDiagJitter);
+    const double d2 = kappa - h2[0];
+    if (!(d2 > 0.0) || !std::isfinite(d2)) return CBO_OK;  // jitchol's business: full refit
+    const double d = std::sqrt(d2);
+    const double zn = ((y_new - (causal ? prior_mean_new : 0.0)) - h2[1]) / d;
+    int64_t chunk = 0, ldv = 0;
+    rc = ensure_workspaces(c, g->n_pad, g->probe->m_pad, &chunk, &ldv);   // only to learn ldv of c->V
+    if (rc != CBO_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(g->raw + g->n * g->d, x_new, sizeof(double) * g->d, hipMemcpyHostToDevice, c->stream));
+    launch_append_commit(c->stream, g->A, g->lda, g->n, g->n_pad, c->V, ldv, d, zn, g->z, g->lvec, g->X, g->probe->P,
+                         prior_mean_new, prior_var_new, g->y, y_new, g->invDt);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (causal) g->h_pv.push_back(prior_var_new);
+    g->n += 1;
+    g->X.n = g->n;
+    g->append_d = d;
+    g->append_zn = zn;
+    g->parent_stamp = g->fit_stamp;
+    g->fit_stamp = ++g_fit_stamp;
+    g->alpha_ready = false;
+    *appended_out = 1;
+    return CBO_OK;
+}
+
 extern "C" int cbo_acq_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task, double ei_jitter, double cost,
                              double *acq_out, double *mean_out, double *var_out, double *best_val, int64_t *best_idx)
 {
@@ -901,6 +1039,12 @@ extern "C" int cbo_acq_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task, d
     if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
     cbo_ctx *c = g->ctx;
     HIP_TRY(hipSetDevice(c->device));
+    if (k->keep_v && k->V && k->v_stamp != 0 && k->v_stamp == g->parent_stamp && k->v_rows == g->n - 1 &&
+        k->v_rows_cap == g->n_pad && k->fit_stamp == k->v_stamp && k->q) {
+        // the model is the one this V belongs to plus one observation: one new row instead of the substitution
+        rc = extend_solution_by_one_row(g, k);
+        if (rc != CBO_OK) return rc;
+    }
     if (!(c->sweep_cache && k->fit_stamp != 0 && k->fit_stamp == g->fit_stamp)) {
         k->fit_stamp = 0;
         rc = enqueue_posterior(g, k);
@@ -948,7 +1092,13 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
         return cbo_acq_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
     }
     g->fitted = false;
-    SweepPipe pipe = make_pipe(g, c->V, ldv, k->m_pad, c->q, c->mu);
+    double *Vws = c->V;
+    k->v_stamp = 0;
+    if (k->keep_v) {
+        rc = own_solution_buffer(g, k, &Vws, &ldv);
+        if (rc != CBO_OK) return rc;
+    }
+    SweepPipe pipe = make_pipe(g, Vws, ldv, k->m_pad, c->q, c->mu);
     pipe.tail_begin = pipeline_pairs(c, g->n_pad, k->m_pad) * 256;
     if (pipe.tail_begin > (int)g->n_pad) pipe.tail_begin = (int)g->n_pad;
     double jitter = 0.0;
@@ -959,7 +1109,7 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
         HIP_TRY(hipStreamWaitEvent(c->sweep_stream, c->ev_fork, 0));
         {
             PhaseScope ps(c, PH_KSTAR, c->sweep_stream);
-            launch_kstar(c->sweep_stream, g->X, k->P, 0, k->m_pad, g->h, c->V, ldv, g->n_pad);
+            launch_kstar(c->sweep_stream, g->X, k->P, 0, k->m_pad, g->h, Vws, ldv, g->n_pad);
         }
         HIP_TRY(hipMemsetAsync(c->q, 0, sizeof(double) * k->m_pad, c->sweep_stream));
         HIP_TRY(hipMemsetAsync(c->mu, 0, sizeof(double) * k->m_pad, c->sweep_stream));
@@ -1002,12 +1152,14 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
     }
     g->fitted = true;
     g->fit_stamp = ++g_fit_stamp;
+    g->parent_stamp = 0;
     g->alpha_ready = false;
     g->tries = tries;
     g->jitter = jitter;
     if (c->profiling) c->timers.n_fit += 1;
     if (tries_out) *tries_out = tries;
     if (jitter_out) *jitter_out = jitter;
+    if (Vws != c->V) { k->v_stamp = g->fit_stamp; k->v_rows = g->n; }
     return finish_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
 }
 

@@ -163,6 +163,15 @@ void launch_export_sym(hipStream_t s, const double *A, int64_t lda, int64_t n, d
 
 int run_mfma_selftest(hipStream_t s, double *max_err);
 
+// append-only trial step (kernels_acq.hip): commit column n of the factor (l from column 0 of l_src), the new
+// diagonal entry, z_n, the point's coordinates and the diagonal tile's inverse; extend a resident V by row n
+void launch_append_commit(hipStream_t s, double *A, int64_t lda, int64_t n, int64_t n_pad, const double *l_src,
+                          int64_t ld_src, double d, double zn, double *z, double *lvec, PointSet &X, const PointSet &P,
+                          double pm_new, double pv_new, double *y, double y_new, double *invDt);
+int append_row_slices(int64_t n);
+void launch_append_row(hipStream_t s, double *V, int64_t ldv, int64_t n, const double *lvec, int64_t m_pad,
+                       const double *krow, double d, double zn, double *partial, double *q, double *mu);
+
 // Monte-Carlo target of an additive SEM: mean_out[i] = mean over draws of node `target` under intervention i.
 // partial: m * sem_partial_blocks(n_draws) doubles of workspace.
 int sem_partial_blocks(int64_t n_draws);

@@ -233,4 +233,121 @@ void launch_argmax_final(hipStream_t s, const double *part_val, const int64_t *p
     hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, s, part_val, part_idx, n, best_val, best_idx);
 }
 
+// ---- append-only trial step --------------------------------------------------------------------------------
+// A CBO trial adds ONE observation to one set (src/Monitor.py:148-160) while hyper-parameters and candidate grid
+// stay put.  Appending row/column n to Ky leaves the first n rows of its factor and of V = L^-1 K* unchanged:
+//     U[0:n, n] = l = L^-1 k(X, x_new),   U[n, n] = d = sqrt(k(x_new, x_new) + noise + 1e-8 - l^T l),
+//     z_n = (y_new - m(x_new) - l^T z) / d,      V[n, :] = (k(x_new, X*) - l^T V[0:n, :]) / d,
+//     q += V[n, :]^2,   mu += V[n, :] z_n
+// l, l^T l and l^T z come out of an ordinary sweep with x_new as the only candidate; the kernels below commit
+// the new column and extend a resident V by one row.
+
+// column n of U, the new diagonal entry, z_n, the new point's coordinates; one thread per row
+__global__ void append_commit_kernel(double *__restrict__ A, int64_t lda, int64_t n, int64_t n_pad,
+                                     const double *__restrict__ l_src, int64_t ld_src, double d, double zn,
+                                     double *__restrict__ z, double *__restrict__ lvec, int dims, double *__restrict__ xs,
+                                     int64_t ldx, double *__restrict__ sq, double *__restrict__ sv, double *__restrict__ pm,
+                                     double *__restrict__ pv, const double *__restrict__ pxs, int64_t ldp,
+                                     const double *__restrict__ psq, const double *__restrict__ psv, double pm_new,
+                                     double pv_new, double *__restrict__ y, double y_new)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const double li = l_src[i * ld_src];
+        A[i * lda + n] = li;
+        lvec[i] = li;
+    } else if (i == n) {
+        A[n * lda + n] = d;
+        A[n * lda + n_pad] = zn;             // the rhs column carries z
+        z[n] = zn;
+        y[n] = y_new;
+        for (int k = 0; k < dims; ++k) xs[(int64_t)k * ldx + n] = pxs[(int64_t)k * ldp];
+        sq[n] = psq[0];
+        if (sv) { sv[n] = psv[0]; pm[n] = pm_new; pv[n] = pv_new; }
+    }
+}
+
+// Column n%16 of the inverse of the 16x16 upper-triangular diagonal tile that contains row n (row-major, what the
+// strip kernel reads).  The other columns do not change: column b of the inverse of an upper-triangular matrix
+// depends on its leading (b+1)x(b+1) block only, and the columns right of n are still identity padding.
+__global__ void append_tile_inverse_kernel(const double *__restrict__ A, int64_t lda, int64_t tile, int col,
+                                           double *__restrict__ invDt)
+{
+    __shared__ double T[16][17];
+    const int t = threadIdx.x;                 // 256 threads: element (a, b)
+    const int a = t >> 4, b = t & 15;
+    T[a][b] = (b >= a) ? A[(tile * 16 + a) * lda + tile * 16 + b] : 0.0;
+    __syncthreads();
+    if (t == col) {                            // column t of the inverse by back substitution
+        double x[16];
+        for (int r = 0; r < 16; ++r) x[r] = 0.0;
+        x[t] = 1.0 / T[t][t];
+        for (int r = t - 1; r >= 0; --r) {
+            double s = 0.0;
+            for (int c = r + 1; c <= t; ++c) s = fma(T[r][c], x[c], s);
+            x[r] = -s / T[r][r];
+        }
+        for (int r = 0; r < 16; ++r) invDt[tile * 256 + r * 16 + t] = x[r];
+    }
+}
+
+// partial[r][j] = sum over the r-th slice of rows i < n of l_i V[i][j]
+__global__ __launch_bounds__(256) void append_row_partial_kernel(const double *__restrict__ V, int64_t ldv, int64_t n,
+                                                                 int rows_per_slice, const double *__restrict__ lvec,
+                                                                 int64_t m_pad, double *__restrict__ partial)
+{
+    __shared__ double ls[512];
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.y * rows_per_slice;
+    const int64_t i1 = (i0 + rows_per_slice < n) ? i0 + rows_per_slice : n;
+    double s = 0.0;
+    for (int64_t base = i0; base < i1; base += 512) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < 512; t += 256) ls[t] = (base + t < i1) ? lvec[base + t] : 0.0;
+        __syncthreads();
+        const int cnt = (int)((i1 - base < 512) ? i1 - base : 512);
+        if (j < m_pad)
+            for (int t = 0; t < cnt; ++t) s = fma(ls[t], V[(base + t) * ldv + j], s);
+    }
+    if (j < m_pad) partial[(int64_t)blockIdx.y * m_pad + j] = s;
+}
+
+__global__ void append_row_final_kernel(const double *__restrict__ partial, int slices, int64_t m_pad,
+                                        const double *__restrict__ krow, double d, double zn, double *__restrict__ Vrow,
+                                        double *__restrict__ q, double *__restrict__ mu)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m_pad) return;
+    double s = 0.0;
+    for (int r = 0; r < slices; ++r) s += partial[(int64_t)r * m_pad + j];
+    const double v = (krow[j] - s) / d;
+    Vrow[j] = v;
+    q[j] = fma(v, v, q[j]);
+    mu[j] = fma(v, zn, mu[j]);
+}
+
+void launch_append_commit(hipStream_t s, double *A, int64_t lda, int64_t n, int64_t n_pad, const double *l_src,
+                          int64_t ld_src, double d, double zn, double *z, double *lvec, PointSet &X, const PointSet &P,
+                          double pm_new, double pv_new, double *y, double y_new, double *invDt)
+{
+    hipLaunchKernelGGL(append_commit_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s, A, lda, n, n_pad,
+                       l_src, ld_src, d, zn, z, lvec, X.d, X.xs, X.ld, X.sq, X.sv, X.pm, X.pv, P.xs, P.ld, P.sq, P.sv,
+                       pm_new, pv_new, y, y_new);
+    hipLaunchKernelGGL(append_tile_inverse_kernel, dim3(1), dim3(256), 0, s, A, lda, n / 16, (int)(n % 16), invDt);
+}
+
+int append_row_slices(int64_t n) { const int64_t s = (n + 127) / 128; return (int)(s < 1 ? 1 : (s > 64 ? 64 : s)); }
+
+void launch_append_row(hipStream_t s, double *V, int64_t ldv, int64_t n, const double *lvec, int64_t m_pad,
+                       const double *krow, double d, double zn, double *partial, double *q, double *mu)
+{
+    const int slices = append_row_slices(n);
+    const int rows_per_slice = (int)(((n + slices - 1) / slices + 7) / 8 * 8);
+    if (n > 0)
+        hipLaunchKernelGGL(append_row_partial_kernel, dim3((unsigned)((m_pad + 255) / 256), slices), dim3(256), 0, s, V, ldv,
+                           n, rows_per_slice, lvec, m_pad, partial);
+    hipLaunchKernelGGL(append_row_final_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, partial,
+                       n > 0 ? slices : 0, m_pad, krow, d, zn, V + n * ldv, q, mu);
+}
+
 }  // namespace cbo

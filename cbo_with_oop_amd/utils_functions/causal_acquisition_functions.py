@@ -19,7 +19,7 @@ class CandidateGrid:
     """Candidate interventions (M,d) resident in HBM (cbo_cands).  ``index_offset`` makes reported
     arg-max indices global when this is one shard of a larger grid (one shard per GPU)."""
 
-    def __init__(self, points, model=None, index_offset=0, context=None):
+    def __init__(self, points, model=None, index_offset=0, context=None, keep_solution=False):
         self.points = _lib.as_f64(points)
         if self.points.ndim != 2:
             raise ValueError("points must be (M, d)")
@@ -36,6 +36,10 @@ class CandidateGrid:
         _lib.check(self._lib.cbo_cands_create(ctx.handle, self.points.shape[0], self.points.shape[1],
                                               _lib.dptr(self.points), _lib.dptr(pm), _lib.dptr(pv),
                                               self.index_offset, ctypes.byref(self._handle)))
+        if keep_solution:
+            # V = L^-1 K* stays on the device after a sweep, so that a model extended by ``append`` costs this
+            # candidate set one new row instead of the whole substitution (n_pad * m doubles of HBM)
+            _lib.check(self._lib.cbo_cands_keep_solution(self._handle, 1))
 
     def __len__(self):
         return self.points.shape[0]

@@ -106,6 +106,15 @@ int cbo_gp_set_data(cbo_gp *gp, int64_t n, const double *X, const double *y,
 int cbo_gp_upload_data(cbo_gp *gp, int64_t n, const double *X, const double *y,
                        const double *prior_mean_X, const double *prior_var_X);
 
+/* One more observation for a fitted model -- what every CBO trial does to the set it intervened on
+ * (src/Monitor.py:148-160 appends to data_x/data_y, src/CBO.py:224-235 rebuilds the model from them).  Appending
+ * row/column n to Ky leaves the first n rows of its factor unchanged: the new column is one forward solve, done as
+ * an ordinary one-candidate sweep.  *appended_out = 1: the model is fitted on n+1 points; 0: nothing changed, the
+ * shortcut does not apply (jitter in the current factor, padded size exhausted, non-positive pivot) and the caller
+ * refits with cbo_gp_set_data.  Same results as a full refit up to rounding. */
+int cbo_gp_append(cbo_gp *gp, const double *x_new, double y_new, double prior_mean_new, double prior_var_new,
+                  int *appended_out);
+
 /* GPyModelWrapper.predict -> GP.predict -> Posterior._raw_predict (called from
  * src/utils_functions/causal_acquisition_functions.py:33 and src/DoCalculus.py:77):
  * mean = K*^T Ky^-1 (y-m) + m(X*), var = clip(Kdiag - |L^-1 K*|^2, 1e-15) (+ noise). */
@@ -162,6 +171,10 @@ int cbo_gp_jitter(const cbo_gp *gp, int *jitter_tries_out, double *jitter_out);
 int cbo_cands_create(cbo_ctx *ctx, int64_t m, int d, const double *Xs, const double *prior_mean_s,
                      const double *prior_var_s, int64_t index_offset, cbo_cands **out);
 void cbo_cands_destroy(cbo_cands *c);
+/* Keep V = L^-1 K* of this candidate set resident after a sweep (n_pad * m_pad doubles): when the model is then
+ * extended with cbo_gp_append, the next sweep adds ONE row to V (O(n m)) instead of redoing the substitution
+ * (O(n^2 m)).  Off by default. */
+int cbo_cands_keep_solution(cbo_cands *c, int on);
 
 /* ---- acquisition sweep -------------------------------------------------------------------------
  * Replaces the batched `acquisition.evaluate(X)` of the anchor scoring step

@@ -971,3 +971,52 @@ def test_overlapped_call_retries_with_jitter_and_handles_causal_ard(hip, monkeyp
     mu, var = O.predict(post, Xs, mean_fn(Xs), var_fn(Xs))
     np.testing.assert_allclose(res["mean"], mu, rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(res["var"], var, rtol=1e-6, atol=1e-10)
+
+
+@pytest.mark.parametrize("n0,d,causal", [(40, 1, False), (250, 2, False), (1100, 3, False), (300, 2, True)])
+def test_append_only_trial_step_matches_full_refit(hip, n0, d, causal):
+    """Appending one observation at a time (cbo_gp_append + one new row of the resident V) against refitting and
+    re-sweeping from scratch: factor, alpha, mean, variance and acquisition agree to rounding, the winner is the
+    same, trial after trial -- including the appends that cross a 16-row tile and (n0 = 250) the 128-row padding
+    boundary, where the shortcut declines and the full path takes over."""
+    from cbo_with_oop_amd import CandidateGrid, CausalExpectedImprovement
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    rng = np.random.default_rng(n0 + d)
+    f = lambda a: np.sin(a[:, :1]) + 0.3 * np.cos(2 * a[:, -1:])
+    X = rng.uniform(-2, 2, (n0, d)); y = f(X) + 0.05 * rng.standard_normal((n0, 1))
+    Xs = rng.uniform(-2, 2, (1500, d))
+    kw = dict(noise_var=1e-2, lengthscale=0.9)
+    if causal:
+        kw.update(mean_function=lambda a: 0.1 * a[:, :1], variance_adjustment=lambda a: 0.2 + 0.1 * np.cos(a[:, 1:2]) ** 2)
+    inc = HipGaussianProcess(X, y, **kw)
+    grid = CandidateGrid(Xs, inc, keep_solution=True)
+    CausalExpectedImprovement(float(y.min()), "min", inc).sweep(grid)
+    appended = 0
+    for step in range(9):
+        x_new = rng.uniform(-2, 2, (1, d)); y_new = f(x_new) + 0.05 * rng.standard_normal((1, 1))
+        X = np.vstack([X, x_new]); y = np.vstack([y, y_new])
+        ok = inc.append(x_new, y_new)
+        appended += int(ok)
+        if not ok:
+            inc.set_data(X, y)
+        best = float(y.min())
+        a = CausalExpectedImprovement(best, "min", inc).sweep(grid, cost=2.0, want_acq=True, want_posterior=True)
+        ref_model = HipGaussianProcess(X, y, **kw)
+        b = CausalExpectedImprovement(best, "min", ref_model).sweep(Xs, cost=2.0, want_acq=True, want_posterior=True)
+        np.testing.assert_allclose(a["mean"], b["mean"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(a["var"], b["var"], rtol=1e-8, atol=1e-13)
+        big = b["acq"][:, 0] > 1e-6 * b["acq"].max()
+        np.testing.assert_allclose(a["acq"][big], b["acq"][big], rtol=1e-6)
+        assert a["best_idx"] == b["best_idx"], step
+        La, alpha_a = inc.posterior_state()
+        Lb, alpha_b = ref_model.posterior_state()
+        np.testing.assert_allclose(La, Lb, rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(alpha_a, alpha_b, rtol=1e-7, atol=1e-9)
+        assert inc.log_likelihood() == pytest.approx(ref_model.log_likelihood(), rel=1e-10)
+        assert np.array_equal(inc.X, X) and np.array_equal(inc.Y, y)
+        ref_model.close()
+    assert appended >= (6 if n0 == 250 else 9)       # 250 + 6 = 256: the padded size runs out once
+    # a full refit of the grown model reproduces itself (the resident data are complete)
+    inc.set_data(X, y)
+    c = CausalExpectedImprovement(best, "min", inc).sweep(grid, cost=2.0, want_acq=True)
+    np.testing.assert_allclose(c["acq"][big], b["acq"][big], rtol=1e-9)
