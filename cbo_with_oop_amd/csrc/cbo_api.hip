@@ -1000,22 +1000,34 @@ extern "C" int cbo_gp_append(cbo_gp *g, const double *x_new, double y_new, doubl
                                   0, &g->probe);
         if (rc != CBO_OK) return rc;
     }
-    int rc = enqueue_posterior(g, g->probe);               // c->V[:, 0] = l, c->q[0] = l^T l, c->mu[0] = l^T z
+    // k(X, x_new) by the K* kernel (64 padded columns, column 0 is the point), then l = L^-1 k by the
+    // single-right-hand-side forward solve; l^T l and l^T z on the host (two n-vectors come back)
+    int rc = prepare_cands(g, g->probe);
     if (rc != CBO_OK) return rc;
-    double h2[2];
-    HIP_TRY(hipMemcpyAsync(&h2[0], c->q, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&h2[1], c->mu, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    int64_t chunk = 0, ldv = 0;
+    rc = ensure_workspaces(c, g->n_pad, g->probe->m_pad, &chunk, &ldv);
+    if (rc != CBO_OK) return rc;
+    launch_kstar(c->stream, g->X, g->probe->P, 0, g->probe->m_pad, g->h, c->V, ldv, g->n_pad);
+    launch_gather_column(c->stream, c->V, ldv, g->n_pad, g->alpha + g->n_pad);      // work vector (alpha's scratch half)
+    launch_forward_vec(c->stream, g->A, g->lda, g->n_pad, g->invDt, g->alpha + g->n_pad, g->lvec);
+    HIP_TRY(hipGetLastError());
+    std::vector<double> hl((size_t)g->n), hz((size_t)g->n);
+    HIP_TRY(hipMemcpyAsync(hl.data(), g->lvec, sizeof(double) * g->n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(hz.data(), g->z, sizeof(double) * g->n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    double h2[2] = {0.0, 0.0};
+    for (int64_t i = 0; i < g->n; ++i) {
+        h2[0] = std::fma(hl[(size_t)i], hl[(size_t)i], h2[0]);
+        h2[1] = std::fma(hl[(size_t)i], hz[(size_t)i], h2[1]);
+    }
+    g->alpha_ready = false;                                 // its scratch half was used
     const double kappa = g->h.variance + (causal ? prior_var_new : 0.0) + (g->noise_var + kGpyDiagJitter);
     const double d2 = kappa - h2[0];
     if (!(d2 > 0.0) || !std::isfinite(d2)) return CBO_OK;  // jitchol's business: full refit
     const double d = std::sqrt(d2);
     const double zn = ((y_new - (causal ? prior_mean_new : 0.0)) - h2[1]) / d;
-    int64_t chunk = 0, ldv = 0;
-    rc = ensure_workspaces(c, g->n_pad, g->probe->m_pad, &chunk, &ldv);   // only to learn ldv of c->V
-    if (rc != CBO_OK) return rc;
     HIP_TRY(hipMemcpyAsync(g->raw + g->n * g->d, x_new, sizeof(double) * g->d, hipMemcpyHostToDevice, c->stream));
-    launch_append_commit(c->stream, g->A, g->lda, g->n, g->n_pad, c->V, ldv, d, zn, g->z, g->lvec, g->X, g->probe->P,
+    launch_append_commit(c->stream, g->A, g->lda, g->n, g->n_pad, g->lvec, 1, d, zn, g->z, g->lvec, g->X, g->probe->P,
                          prior_mean_new, prior_var_new, g->y, y_new, g->invDt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -113,6 +113,10 @@ void sweep_pipe_tail(const SweepPipe &pipe, hipStream_t chain, const double *A, 
                      int64_t n_pad, int pairs_done);
 // alpha = U^-1 z  (z = first rhs column of A).
 void launch_backsolve(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt, double *alpha);
+// out = L^-1 w for one contiguous n_pad vector (w is destroyed): the forward counterpart, one launch per block
+void launch_forward_vec(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt, double *w,
+                        double *out);
+void launch_gather_column(hipStream_t s, const double *V, int64_t ldv, int64_t n_pad, double *dst);
 void launch_backsolve_vec(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt,
                           const double *src, int64_t src_stride, double *work, double *out);
 // Gradients of the posterior mean and variance w.r.t. the prediction inputs (GPy predictive_gradients):

@@ -598,4 +598,75 @@ void launch_backsolve_vec(hipStream_t s, const double *A, int64_t lda, int64_t n
         hipLaunchKernelGGL(backsolve_step_kernel, dim3(blk + 1), dim3(256), 0, s, A, lda, invDt, blk, work, out);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Forward solve U^T l = k (l = L^-1 k) for ONE right-hand side, 128-row blocks from the top, one launch per block:
+// the mirror image of backsolve_step_kernel.  Every workgroup first solves the 128x128 diagonal system redundantly
+// in LDS (16-row sub-blocks: multiply by the transposed stored inv(U_ss), then fold into the rows below), then
+// workgroup g folds l_blk into the 128 entries of block blk + 1 + g:  w[i] -= sum_k U[blk rows k][i] l_k -- a row of
+// U is contiguous in i, so the 128 threads of the update read coalesced.  The strip kernel needs 64 columns and a
+// workgroup per strip; for a single column this is what fills the device.
+__global__ __launch_bounds__(256) void forward_step_kernel(const double *__restrict__ A, int64_t lda,
+                                                           const double *__restrict__ invDt, int blk, int nb, double *w,
+                                                           double *__restrict__ out)
+{
+    __shared__ double rs[128];
+    __shared__ double ls[128];
+    const int tid = threadIdx.x;
+    const int b0 = blk * 128;
+    if (tid < 128) rs[tid] = w[b0 + tid];
+    __syncthreads();
+    for (int s = 0; s < 8; ++s) {
+        const int o = 16 * s;
+        // l_s = inv(U_ss)^T r_s : thread (i, part) sums 4 of the 16 terms; Y[k][i] = inv(U_ss)[k][i]
+        if (tid < 64) {
+            const int i = tid >> 2, part = tid & 3;
+            const double *Y = invDt + (int64_t)(b0 / 16 + s) * 256;
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = fma(Y[(4 * part + k) * 16 + i], rs[o + 4 * part + k], acc);
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            if (part == 0) ls[o + i] = acc;
+        }
+        __syncthreads();
+        // rows below inside the block: rs[c] -= sum_k U[b0+o+k][b0+c] l_{o+k}, c >= o + 16
+        if (tid >= o + 16 && tid < 128) {
+            double acc = rs[tid];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc = fma(-A[(int64_t)(b0 + o + k) * lda + b0 + tid], ls[o + k], acc);
+            rs[tid] = acc;
+        }
+        __syncthreads();
+    }
+    const int g = blockIdx.x;
+    if (g == 0 && tid < 128) out[b0 + tid] = ls[tid];
+    // block blk + 1 + g: two threads per entry, each over 64 of the 128 panel rows
+    if (blk + 1 + g >= nb) return;                             // the last block has nothing below it (uniform)
+    const int c = tid & 127, half = tid >> 7;
+    const int64_t col = (int64_t)(blk + 1 + g) * 128 + c;
+    double acc = 0.0;
+    for (int k = 64 * half; k < 64 * half + 64; ++k) acc = fma(A[(int64_t)(b0 + k) * lda + col], ls[k], acc);
+    __syncthreads();
+    if (half == 1) rs[c] = acc;
+    __syncthreads();
+    if (half == 0) w[col] -= acc + rs[c];
+}
+
+// out = L^-1 w for one contiguous vector of n_pad entries (w is used as the work vector and destroyed).
+void launch_forward_vec(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt, double *w,
+                        double *out)
+{
+    const int nb = (int)(n_pad / 128);
+    for (int blk = 0; blk < nb; ++blk) {
+        const int below = nb - 1 - blk;                       // blocks that receive this block's contribution
+        hipLaunchKernelGGL(forward_step_kernel, dim3(below > 0 ? below : 1), dim3(256), 0, s, A, lda, invDt, blk, nb, w, out);
+    }
+}
+
+// dst[i] = V[i * ldv] for i < n_pad: one column of a row-major workspace as a contiguous vector
+void launch_gather_column(hipStream_t s, const double *V, int64_t ldv, int64_t n_pad, double *dst)
+{
+    hipLaunchKernelGGL(copy_strided_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, V, ldv, n_pad, dst);
+}
+
 }  // namespace cbo
