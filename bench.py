@@ -264,6 +264,27 @@ def main():
                                        "unit": "GB/s", "frac": b16 / (t16["ms_kxx"] * 1e-3) / 1e9 / 8000.0,
                                        "avg_launch_ms": t16["ms_kxx"], "algorithmic_bytes_per_launch": b16,
                                        "cholesky_ms": t16["ms_chol"]}
+        if world == 1 and args.post_steps > 0:
+            # what a CBO trial costs once data only grow by one observation (not part of `value`: the timed steps
+            # refit from scratch): append one point to a 4000-point model, then sweep the same 16384-candidate grid
+            n0 = 4000
+            mA = HipGaussianProcess(X[:n0], y[:n0], context=ctx)
+            gA = CandidateGrid(Xs[:GRID_PER_GPU[0] * GRID_PER_GPU[1] * GRID_PER_GPU[2]], mA, context=ctx, keep_solution=True)
+            eiA = CausalExpectedImprovement(y_best, "min", mA)
+            eiA.sweep(gA, cost=cost)
+            per_trial = []
+            for i in range(n0, n0 + 24):
+                t1 = time.perf_counter()
+                ok = mA.append(X[i:i + 1], y[i:i + 1])
+                eiA.sweep(gA, cost=cost)
+                per_trial.append(time.perf_counter() - t1)
+                assert ok
+            out["append_trial_step"] = {"ms_per_trial": float(np.median(per_trial) * 1e3), "n_obs": n0 + 24,
+                                        "candidates": len(gA),
+                                        "what": "cbo_gp_append (one new column of the factor) + sweep that adds one row to "
+                                                "the resident L^-1 K*; same results as a refit to rounding"}
+            gA.close()
+            mA.close()
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(X, y, Xs, y_best, cost, min(args.cpu_sample, Xs.shape[0]))
         else:
