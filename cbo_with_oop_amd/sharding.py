@@ -43,6 +43,29 @@ def reduce_pairs(vals, idxs):
 NO_CANDIDATE = np.iinfo(np.int64).max     # index sent by a rank whose shard is empty
 
 
+_exchange_buffers = {}     # (device, world size) -> persistent tensors of the per-step exchange
+
+
+def _buffers(device, world):
+    """Persistent pinned/device tensors and, on a GPU, a side stream of torch's own: the exchange then allocates
+    nothing per step and never touches the legacy default stream (whose operations synchronise with every blocking
+    stream of the process, the library's CU-masked ones included)."""
+    import torch
+    key = (str(device), world)
+    buf = _exchange_buffers.get(key)
+    if buf is None:
+        on_gpu = device.type == "cuda"
+        buf = {
+            "host_in": torch.empty(2, dtype=torch.int64, pin_memory=on_gpu),
+            "host_out": torch.empty(2 * world, dtype=torch.int64, pin_memory=on_gpu),
+            "mine": torch.empty(2, dtype=torch.int64, device=device),
+            "out": torch.empty(2 * world, dtype=torch.int64, device=device),
+            "stream": torch.cuda.Stream(device=device) if on_gpu else None,
+        }
+        _exchange_buffers[key] = buf
+    return buf
+
+
 def exchange_argmax(best_val, best_idx, group=None, device=None):
     """All-gather this rank's (best_val, best_global_idx) and reduce.  Returns (val, idx) identical on
     every rank.  Without an initialised process group (plain single-GPU run) it is the identity; a group of
@@ -56,12 +79,22 @@ def exchange_argmax(best_val, best_idx, group=None, device=None):
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" \
             else torch.device("cpu")
+    device = torch.device(device)
+    buf = _buffers(device, world)
     # one 16-byte record per rank: the value's bits and the index, both as int64 (one collective)
-    mine = torch.tensor([np.float64(best_val).view(np.int64).item(), int(best_idx)], dtype=torch.int64,
-                        device=device)
-    out = torch.empty(2 * world, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(out, mine, group=group)
-    rec = out.cpu().numpy().reshape(world, 2)
+    buf["host_in"][0] = np.float64(best_val).view(np.int64).item()
+    buf["host_in"][1] = int(best_idx)
+    if buf["stream"] is not None:
+        with torch.cuda.stream(buf["stream"]):
+            buf["mine"].copy_(buf["host_in"], non_blocking=True)
+            dist.all_gather_into_tensor(buf["out"], buf["mine"], group=group)
+            buf["host_out"].copy_(buf["out"], non_blocking=True)
+        buf["stream"].synchronize()
+    else:
+        buf["mine"].copy_(buf["host_in"])
+        dist.all_gather_into_tensor(buf["out"], buf["mine"], group=group)
+        buf["host_out"].copy_(buf["out"])
+    rec = buf["host_out"].numpy().reshape(world, 2)
     vals = rec[:, 0].copy().view(np.float64)
     idxs = rec[:, 1].copy()
     keep = idxs != NO_CANDIDATE
