@@ -155,11 +155,15 @@ class HipGaussianProcess:
         return self.predict(x, include_likelihood=False)
 
     def set_data(self, X, Y, fit=True):
-        """GPyModelWrapper.set_data -> GP.set_XY: replace the data and refit (src/Monitor.py:160).
+        """GPyModelWrapper.set_data -> GP.set_XY: replace the data and refit (src/Monitor.py:160).  When the new data
+        are the resident ones plus one observation -- what that call site passes every trial -- the factor grows by
+        one column on the device (``append``) instead of being rebuilt; same posterior up to rounding.
 
         ``fit=False`` uploads only and leaves the refit to the next use: an acquisition sweep then runs the
         refit and the sweep overlapped (``cbo_gp_fit_sweep``); any other consumer (predict, log_likelihood, ...)
         fits first.  A not-positive-definite error then surfaces at that use instead of here."""
+        if self._grew_by_one_row(X, Y) and self.append(np.asarray(X)[-1], np.asarray(Y).reshape(-1)[-1]):
+            return                                   # the factor grew by one column instead of being rebuilt
         self._set_arrays(X, Y)
         pm, pv = self._prior(self.X)
         if not fit:
@@ -195,6 +199,16 @@ class HipGaussianProcess:
         self._y_flat = np.ascontiguousarray(self.Y[:, 0])
         return True
 
+    def _grew_by_one_row(self, X, Y):
+        """The new data are the resident ones plus one observation (what src/Monitor.py:148-160 produces every
+        trial) and the model is fitted: the append shortcut applies."""
+        if self.stale:
+            return False
+        X = np.asarray(X, dtype=np.float64)
+        Y = np.asarray(Y, dtype=np.float64).reshape(-1, 1)
+        return (X.ndim == 2 and X.shape[0] == self.X.shape[0] + 1 and X.shape[1] == self.X.shape[1]
+                and Y.shape[0] == X.shape[0] and np.array_equal(X[:-1], self.X) and np.array_equal(Y[:-1], self.Y))
+
     def ensure_fitted(self):
         """Fit now if the data were replaced with ``set_data(..., fit=False)`` and nothing has refitted since."""
         if self.stale:
@@ -229,15 +243,9 @@ class HipGaussianProcess:
         trial): the hyper-parameters the constructor was given, the new data.  Same device handle and buffers, so
         nothing is allocated when the padded size does not change."""
         v0, ls0, nv0 = self._initial_hyper
-        same_hyper = (self.variance, self.noise_var) == (v0, nv0) and np.array_equal(self.lengthscale, ls0)
-        X = _lib.as_f64(X)
-        Y = _lib.as_f64(Y).reshape(-1, 1)
-        if same_hyper and not self.stale and X.shape[0] == self.X.shape[0] + 1 and X.shape[1:] == self.X.shape[1:] \
-                and np.array_equal(X[:-1], self.X) and np.array_equal(Y[:-1], self.Y) and self.append(X[-1], Y[-1]):
-            return                                   # the data grew by one row: the factor grew by one column
-        if not same_hyper:
+        if (self.variance, self.noise_var) != (v0, nv0) or not np.array_equal(self.lengthscale, ls0):
             self.set_hyperparameters(v0, ls0, nv0, fit=False)
-        self.set_data(X, Y, fit=fit)
+        self.set_data(X, Y, fit=fit)                 # appends when the data merely grew by one row
 
     def log_likelihood_gradients(self):
         """(d log p(y)/d variance, d/d lengthscale (array), d/d noise_var) of the fitted model: the gradients GPy's
