@@ -99,13 +99,23 @@ struct KmatArgs {
     double *out; int64_t ldo;
     double variance, lengthscale, diag_add, jitter;
     int symmetric, zero_diag;
+    int sym_tiles;                 // symmetric: tiles per side (grid = upper triangle, linearised)
 };
 
 template <int D>
 __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a)
 {
-    const int tj = blockIdx.x, ti = blockIdx.y;
-    if (a.symmetric && tj < ti) return;               // only upper tiles of Ky are ever read
+    int tj = blockIdx.x, ti = blockIdx.y;
+    if (a.symmetric) {
+        // only the upper tiles of Ky are ever read: the grid is the nt (nt + 1) / 2 tiles of the upper triangle,
+        // row by row (row ti starts at ti nt - ti (ti - 1) / 2)
+        const int nt = a.sym_tiles;
+        const int t = blockIdx.x;
+        ti = (int)((2.0 * nt + 1.0 - sqrt((2.0 * nt + 1.0) * (2.0 * nt + 1.0) - 8.0 * (double)t)) * 0.5);
+        while (ti > 0 && ti * nt - ti * (ti - 1) / 2 > t) --ti;               // guard the rounding of the root
+        while ((ti + 1) * nt - (ti + 1) * ti / 2 <= t) ++ti;
+        tj = ti + (t - (ti * nt - ti * (ti - 1) / 2));
+    }
     __shared__ double sx[D][64], sy[D][64];
     __shared__ double sxq[64], syq[64], sxv[64], syv[64];
     const int tid = threadIdx.x;
@@ -205,7 +215,8 @@ void launch_kxx(hipStream_t s, const PointSet &X, const KernelHyper &h, double d
     a.variance = h.variance; a.lengthscale = h.lengthscale; a.diag_add = diag_add; a.jitter = jitter;
     a.symmetric = 1; a.zero_diag = h.zero_diag;
     const int nt = (int)(n_pad / 64);
-    launch_kmat(s, X.d, a, dim3(nt, nt));
+    a.sym_tiles = nt;
+    launch_kmat(s, X.d, a, dim3((unsigned)(nt * (nt + 1) / 2), 1));
 }
 
 void launch_kstar(hipStream_t s, const PointSet &X, const PointSet &C, int64_t c_begin, int64_t m_pad,
@@ -217,7 +228,7 @@ void launch_kstar(hipStream_t s, const PointSet &X, const PointSet &C, int64_t c
     a.n_rows = X.n; a.n_cols = C.ld; a.col_begin = c_begin;   // all padded columns are computable
     a.out = V; a.ldo = ldv;
     a.variance = h.variance; a.lengthscale = h.lengthscale; a.diag_add = 0.0; a.jitter = 0.0;
-    a.symmetric = 0; a.zero_diag = 0;
+    a.symmetric = 0; a.zero_diag = 0; a.sym_tiles = 0;
     launch_kmat(s, X.d, a, dim3((unsigned)(m_pad / 64), (unsigned)(n_pad / 64)));
 }
 
