@@ -73,3 +73,25 @@ def test_shard_bounds_cover_the_grid():
             assert all(b[1] == nb[0] for b, nb in zip(blocks, blocks[1:]))
     assert reduce_pairs([0.5, 0.9, 0.9], [5, 900, 300]) == (0.9, 300)
     assert reduce_pairs([np.nan, 0.9], [7, 3]) [1] == 7          # NaN is maximal, like numpy.argmax
+
+
+def test_one_row_growth_detection():
+    """Host logic of the append shortcut: set_data only takes it when the new data are the resident ones plus exactly
+    one observation and the model is fitted (no device involved: the method only reads attributes)."""
+    from types import SimpleNamespace
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    X = np.arange(12.0).reshape(6, 2)
+    Y = np.arange(6.0).reshape(6, 1)
+    model = SimpleNamespace(stale=False, X=X, Y=Y)
+    grew = lambda x, y: HipGaussianProcess._grew_by_one_row(model, x, y)
+    x7, y7 = np.vstack([X, [[1.0, 2.0]]]), np.vstack([Y, [[3.0]]])
+    assert grew(x7, y7) and grew(x7, y7[:, 0])
+    assert not grew(X, Y)                                         # same data
+    assert not grew(np.vstack([x7, [[0.0, 0.0]]]), np.vstack([y7, [[0.0]]]))   # two new rows
+    changed = x7.copy(); changed[2, 0] += 1e-12
+    assert not grew(changed, y7)                                  # an old row changed
+    ychanged = y7.copy(); ychanged[0, 0] = -1.0
+    assert not grew(x7, ychanged)
+    assert not grew(np.hstack([x7, x7[:, :1]]), y7)               # another dimension
+    model.stale = True
+    assert not grew(x7, y7)                                       # nothing fitted to extend
