@@ -8,6 +8,7 @@ behind libcbo_hip.so (include/cbo_hip.h).  There is no CPU implementation in thi
 from __future__ import annotations
 
 import ctypes
+import os
 import warnings
 from enum import IntEnum
 
@@ -44,11 +45,16 @@ class HipGaussianProcess:
     """
 
     def __init__(self, x, y, *, variance=1.0, lengthscale=1.0, ard=False, noise_var=1e-10, mean_function=None,
-                 variance_adjustment=None, zero_diag=None, context=None, fix_noise=False, fit=True):
+                 variance_adjustment=None, zero_diag=None, context=None, fix_noise=False, fit=True, dtype=None):
         if (mean_function is None) != (variance_adjustment is None):
             raise ValueError("mean_function and variance_adjustment must be given together")
         self._lib = _lib.load()
         self._ctx = context if context is not None else _lib.Context.get()
+        # "f64" (default) or "f32": the fit is fp64 either way; "f32" runs every sweep / predict of this model on the
+        # f32 MFMA from a once-per-fit fp32 copy of the factor (BASELINE.json configs[4]; include/cbo_hip.h)
+        self.dtype = dtype if dtype is not None else os.environ.get("CBO_HIP_DTYPE", "f64")
+        if self.dtype not in _lib.DTYPE_CODE:
+            raise ValueError(f"dtype must be one of {sorted(_lib.DTYPE_CODE)}")
         self.mean_function = mean_function
         self.variance_adjustment = variance_adjustment
         self.causal = mean_function is not None
@@ -71,7 +77,7 @@ class HipGaussianProcess:
         self._set_arrays(x, y)
         pm, pv = self._prior(self.X)
         _lib.check(self._lib.cbo_gp_create(
-            self._ctx.handle, 0, self.X.shape[0], self.input_dim, _lib.dptr(self.X), _lib.dptr(self._y_flat),
+            self._ctx.handle, _lib.DTYPE_CODE[self.dtype], self.X.shape[0], self.input_dim, _lib.dptr(self.X), _lib.dptr(self._y_flat),
             _lib.dptr(pm), _lib.dptr(pv), self.variance, _lib.dptr(self.lengthscale), int(self.ard), self.noise_var,
             int(self.zero_diag), ctypes.byref(self._handle)))
         self._initial_hyper = (self.variance, self.lengthscale.copy(), self.noise_var)
@@ -344,9 +350,10 @@ class GaussianProcessFactory:
     """src/GaussianProcessFactory.py:18-73, same static methods."""
 
     @staticmethod
-    def create(gp_type, x, y, parameters=None, emukit_wrapper=False, fit=True):
+    def create(gp_type, x, y, parameters=None, emukit_wrapper=False, fit=True, dtype=None):
         """``fit=False`` (not in the reference) builds the model without fitting it; the first acquisition sweep
-        then refits and sweeps in one overlapped call."""
+        then refits and sweeps in one overlapped call.  ``dtype="f32"`` (not in the reference either; default from
+        ``CBO_HIP_DTYPE``, else "f64") selects the fp32 sweep."""
         gp_functions = {
             GaussianProcessType.GRAPH_GP: GaussianProcessFactory.create_graph_gp,
             GaussianProcessType.CAUSAL_GP: GaussianProcessFactory.create_causal_gp,
@@ -354,22 +361,22 @@ class GaussianProcessFactory:
         }
         # emukit_wrapper only selected the wrapper class in the reference; HipGaussianProcess answers
         # both interfaces, so the flag changes nothing here.
-        return gp_functions[gp_type](x, y, parameters, fit=fit)
+        return gp_functions[gp_type](x, y, parameters, fit=fit, dtype=dtype)
 
     @staticmethod
-    def create_graph_gp(x, y, parameters, fit=True):
+    def create_graph_gp(x, y, parameters, fit=True, dtype=None):
         """:49-54  RBF(lengthscale=p[0], variance=p[1], ARD=p[3]), noise fixed to 1e-2 after construction."""
         return HipGaussianProcess(x, y, variance=parameters[1], lengthscale=parameters[0], ard=parameters[3],
-                                  noise_var=1e-2, fix_noise=True, fit=fit)
+                                  noise_var=1e-2, fix_noise=True, fit=fit, dtype=dtype)
 
     @staticmethod
-    def create_non_causal_gp(x, y, _, fit=True):
+    def create_non_causal_gp(x, y, _, fit=True, dtype=None):
         """:57-60  RBF(lengthscale=1, variance=1), noise 1e-10."""
-        return HipGaussianProcess(x, y, variance=1.0, lengthscale=1.0, noise_var=1e-10, fit=fit)
+        return HipGaussianProcess(x, y, variance=1.0, lengthscale=1.0, noise_var=1e-10, fit=fit, dtype=dtype)
 
     @staticmethod
-    def create_causal_gp(x, y, parameters, fit=True):
+    def create_causal_gp(x, y, parameters, fit=True, dtype=None):
         """:63-73  CausalRBF(variance_adjustment=var_function) + mean function, noise 1e-10."""
         mean_function, var_function = parameters
         return HipGaussianProcess(x, y, variance=1.0, lengthscale=1.0, noise_var=1e-10,
-                                  mean_function=mean_function, variance_adjustment=var_function, fit=fit)
+                                  mean_function=mean_function, variance_adjustment=var_function, fit=fit, dtype=dtype)

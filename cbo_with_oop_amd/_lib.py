@@ -29,13 +29,14 @@ CBO_ERR_NO_DEVICE = -7
 CBO_ERR_COMM = -8
 
 TASK_CODE = {"min": 0, "max": 1}
+DTYPE_CODE = {"f64": 0, "f32": 1}
 
 
 class CboTimers(ctypes.Structure):
     _fields_ = [("ms_kxx", ctypes.c_double), ("ms_chol", ctypes.c_double), ("ms_alpha", ctypes.c_double),
                 ("ms_kstar", ctypes.c_double), ("ms_trsm", ctypes.c_double), ("ms_acq", ctypes.c_double),
                 ("n_fit", ctypes.c_int64), ("n_sweep", ctypes.c_int64), ("n_trsm_launches", ctypes.c_int64),
-                ("trsm_flops", ctypes.c_double)]
+                ("trsm_flops", ctypes.c_double), ("ms_f32_convert", ctypes.c_double)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -95,6 +96,7 @@ SIGNATURES = {
     "cbo_gp_get_posterior": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p]),
     "cbo_gp_assemble_kxx": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
     "cbo_gp_n": (ctypes.c_int64, [ctypes.c_void_p]),
+    "cbo_gp_dtype": (ctypes.c_int, [ctypes.c_void_p]),
     "cbo_gp_jitter": (ctypes.c_int, [ctypes.c_void_p, c_int_p, c_double_p]),
     "cbo_cands_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, c_double_p, c_double_p,
                                         c_double_p, ctypes.c_int64, c_void_pp]),

@@ -28,7 +28,7 @@ static int fail(int code, const std::string &msg)
             return fail(CBO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
     } while (0)
 
-enum Phase { PH_KXX = 0, PH_CHOL, PH_ALPHA, PH_KSTAR, PH_TRSM, PH_ACQ, PH_COUNT };
+enum Phase { PH_KXX = 0, PH_CHOL, PH_ALPHA, PH_KSTAR, PH_TRSM, PH_ACQ, PH_CONVERT, PH_COUNT };
 
 struct EventPair {
     hipEvent_t a, b;
@@ -61,6 +61,7 @@ struct cbo_ctx {
     double *V = nullptr; size_t V_bytes = 0;
     double *W = nullptr; size_t W_bytes = 0;          // -Ky^-1 for the likelihood gradients
     double *gpart = nullptr; size_t gpart_elems = 0;
+    double *mupart = nullptr; size_t mupart_elems = 0;   // fp32 sweep: per-row-tile partial sums of K*^T alpha
     double *q = nullptr, *mu = nullptr, *mean = nullptr, *var = nullptr, *acq = nullptr; size_t vec_elems = 0;
     double *part_val = nullptr; int64_t *part_idx = nullptr;
     double *best_val = nullptr; int64_t *best_idx = nullptr;   // device
@@ -96,6 +97,11 @@ struct cbo_gp {
     double append_d = 0.0, append_zn = 0.0;
     double *lvec = nullptr;          // [n_pad] the new column of U, contiguous
     cbo_cands *probe = nullptr;      // the appended point as a one-candidate set (scaled coordinates, prior)
+    // CBO_DTYPE_F32: fp32 copies of the factor for the sweep (kernels_f32.hip), refreshed by every successful fit
+    int dtype = CBO_DTYPE_F64;
+    int64_t n32 = 0, ldu32 = 0;
+    float *Uf = nullptr, *invF = nullptr;
+    uint64_t f32_stamp = 0;          // fit stamp the copies belong to
 };
 
 struct cbo_cands {
@@ -174,6 +180,7 @@ static void resolve_events(cbo_ctx *c)
             case PH_KSTAR: c->timers.ms_kstar += ms; break;
             case PH_TRSM: c->timers.ms_trsm += ms; break;
             case PH_ACQ: c->timers.ms_acq += ms; break;
+            case PH_CONVERT: c->timers.ms_f32_convert += ms; break;
         }
         c->pool.push_back(p.a);
         c->pool.push_back(p.b);
@@ -284,7 +291,7 @@ extern "C" void cbo_shutdown(cbo_ctx *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->pool) hipEventDestroy(e);
-    hipFree(c->W); hipFree(c->gpart);
+    hipFree(c->W); hipFree(c->gpart); hipFree(c->mupart);
     hipFree(c->V); hipFree(c->q); hipFree(c->mu); hipFree(c->mean); hipFree(c->var); hipFree(c->acq);
     hipFree(c->part_val); hipFree(c->part_idx); hipFree(c->best_val); hipFree(c->best_idx);
     hipHostFree(c->h_best_val); hipHostFree(c->h_best_idx); hipHostFree(c->h_info);
@@ -372,6 +379,8 @@ static void free_gp_data(cbo_gp *g)
 {
     hipFree(g->X.xs); hipFree(g->X.sq); hipFree(g->X.sv); hipFree(g->X.pm); hipFree(g->X.pv);
     hipFree(g->raw); hipFree(g->y); hipFree(g->A); hipFree(g->invDt); hipFree(g->alpha); hipFree(g->z); hipFree(g->lvec);
+    hipFree(g->Uf); hipFree(g->invF);
+    g->Uf = g->invF = nullptr; g->f32_stamp = 0;
     g->X = PointSet{};
     g->raw = g->y = g->A = g->invDt = g->alpha = g->z = g->lvec = nullptr;
     g->parent_stamp = 0;
@@ -404,6 +413,12 @@ static int upload_gp_data(cbo_gp *g, int64_t n, const double *X, const double *y
         HIP_TRY(hipMalloc(&g->alpha, sizeof(double) * 2 * n_pad));
         HIP_TRY(hipMalloc(&g->z, sizeof(double) * n_pad));
         HIP_TRY(hipMalloc(&g->lvec, sizeof(double) * n_pad));
+        if (g->dtype == CBO_DTYPE_F32) {
+            g->n32 = round_up(n_pad, kPadN32);
+            g->ldu32 = g->n32 + 32;
+            HIP_TRY(hipMalloc(&g->Uf, sizeof(float) * (size_t)g->n32 * (size_t)g->ldu32));
+            HIP_TRY(hipMalloc(&g->invF, sizeof(float) * (size_t)(g->n32 / 16) * 256));
+        }
         g->n_pad = n_pad;            // only now: a failed allocation above leaves the handle empty (n_pad == 0)
     }
     g->n = n;
@@ -430,12 +445,13 @@ extern "C" int cbo_gp_create(cbo_ctx *c, int dtype, int64_t n, int d, const doub
                              int ard, double noise_var, int zero_diag, cbo_gp **out)
 {
     if (!c || !out || !lengthscale) return fail(CBO_ERR_INVALID, "NULL argument");
-    if (dtype != CBO_DTYPE_F64) return fail(CBO_ERR_UNSUPPORTED, "only CBO_DTYPE_F64 is implemented");
+    if (dtype != CBO_DTYPE_F64 && dtype != CBO_DTYPE_F32) return fail(CBO_ERR_INVALID, "dtype must be CBO_DTYPE_F64 or CBO_DTYPE_F32");
     if (d < 1 || d > CBO_MAX_DIM) return fail(CBO_ERR_INVALID, "d must be in [1, CBO_MAX_DIM]");
     HIP_TRY(hipSetDevice(c->device));
     cbo_gp *g = new cbo_gp();
     g->ctx = c;
     g->d = d;
+    g->dtype = dtype;
     g->noise_var = noise_var;
     g->h.variance = variance;
     g->h.ard = ard ? 1 : 0;
@@ -469,6 +485,7 @@ extern "C" void cbo_gp_destroy(cbo_gp *g)
 }
 
 extern "C" int64_t cbo_gp_n(const cbo_gp *g) { return g ? g->n : -1; }
+extern "C" int cbo_gp_dtype(const cbo_gp *g) { return g ? g->dtype : -1; }
 
 extern "C" int cbo_gp_jitter(const cbo_gp *g, int *tries_out, double *jitter_out)
 {
@@ -674,14 +691,16 @@ extern "C" void cbo_cands_destroy(cbo_cands *k)
     delete k;
 }
 
-static int ensure_workspaces(cbo_ctx *c, int64_t n_pad, int64_t m_pad, int64_t *chunk_cols, int64_t *ldv)
+static int ensure_workspaces(cbo_ctx *c, int64_t n_pad, int64_t m_pad, int64_t *chunk_cols, int64_t *ldv,
+                             size_t elem = sizeof(double))
 {
-    // V chunk: as many 64-column strips as fit the workspace budget (at least one strip).
+    // V chunk: as many 64-column strips as fit the workspace budget (at least one strip).  elem = 4: the fp32
+    // sweep's workspace (n_pad is then its 256-padded row count), 128 B of row padding either way.
     int64_t cols = m_pad;
-    const int64_t max_cols = (int64_t)(c->max_ws_bytes / (sizeof(double) * (size_t)n_pad)) / kStrip * kStrip;
+    const int64_t max_cols = (int64_t)(c->max_ws_bytes / (elem * (size_t)n_pad)) / kStrip * kStrip;
     if (cols > max_cols) cols = max_cols < kStrip ? kStrip : max_cols;
-    const int64_t ld = cols + kLdExtra;
-    const size_t need = sizeof(double) * (size_t)n_pad * (size_t)ld;
+    const int64_t ld = cols + (int64_t)(128 / elem);
+    const size_t need = elem * (size_t)n_pad * (size_t)ld;
     if (need > c->V_bytes) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         hipFree(c->V);
@@ -838,12 +857,60 @@ static int own_solution_buffer(cbo_gp *g, cbo_cands *k, double **V, int64_t *ldv
     return CBO_OK;
 }
 
+// fp32 sweep (CBO_DTYPE_F32 models): K* in fp64 arithmetic rounded to fp32, substitution on the f32 MFMA, q and mu
+// accumulated in fp64.  Left-looking strip kernel only; the fp32 copies of the factor follow the fit lazily.
+static int ensure_alpha(cbo_gp *g);
+
+static int enqueue_posterior_f32(cbo_gp *g, cbo_cands *k)
+{
+    cbo_ctx *c = g->ctx;
+    int64_t chunk = 0, ldv = 0;
+    int rc = ensure_workspaces(c, g->n32, k->m_pad, &chunk, &ldv, sizeof(float));
+    if (rc != CBO_OK) return rc;
+    rc = ensure_alpha(g);                     // the mean is K*^T alpha in fp64 (GPy's formula), see kernels_f32.hip
+    if (rc != CBO_OK) return rc;
+    const size_t part_elems = (size_t)(g->n32 / 64) * (size_t)chunk;
+    if (part_elems > c->mupart_elems) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->mupart);
+        c->mupart = nullptr; c->mupart_elems = 0;
+        HIP_TRY(hipMalloc(&c->mupart, sizeof(double) * part_elems));
+        c->mupart_elems = part_elems;
+    }
+    if (g->f32_stamp != g->fit_stamp) {
+        PhaseScope ps(c, PH_CONVERT);
+        launch_factor_to_f32(c->stream, g->A, g->lda, g->n_pad, g->invDt, g->Uf, g->ldu32, g->invF, g->n32);
+        g->f32_stamp = g->fit_stamp;
+    }
+    float *Vf = reinterpret_cast<float *>(c->V);
+    k->v_stamp = 0;
+    for (int64_t c0 = 0; c0 < k->m_pad; c0 += chunk) {
+        const int64_t cols = (k->m_pad - c0 < chunk) ? (k->m_pad - c0) : chunk;
+        {
+            PhaseScope ps(c, PH_KSTAR);
+            launch_kstar_f32(c->stream, g->X, k->P, c0, cols, g->h, Vf, ldv, g->n32, g->alpha, c->mupart, c->mu + c0);
+        }
+        {
+            PhaseScope ps(c, PH_TRSM);
+            launch_trsm_strips_f32(c->stream, g->Uf, g->ldu32, g->invF, Vf, ldv, g->n32, cols, c->q + c0);
+        }
+        if (c->profiling) {
+            c->timers.n_trsm_launches += 1;
+            c->timers.trsm_flops += (double)g->n32 * (double)g->n32 * (double)cols;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return CBO_OK;
+}
+
 // q = colsum((L^-1 K*)^2), mu = (L^-1 K*)^T z for all candidates, chunk by chunk.
-static int enqueue_posterior(cbo_gp *g, cbo_cands *k)
+static int enqueue_posterior(cbo_gp *g, cbo_cands *k, bool want_f64_solution = false)
 {
     cbo_ctx *c = g->ctx;
     int rc = prepare_cands(g, k);
     if (rc != CBO_OK) return rc;
+    // (prediction gradients read V = L^-1 K* back from the fp64 workspace: they stay on the fp64 factor)
+    if (g->dtype == CBO_DTYPE_F32 && !want_f64_solution) return enqueue_posterior_f32(g, k);
     int64_t chunk = 0, ldv = 0;
     rc = ensure_workspaces(c, g->n_pad, k->m_pad, &chunk, &ldv);
     if (rc != CBO_OK) return rc;
@@ -981,6 +1048,7 @@ extern "C" int cbo_gp_append(cbo_gp *g, const double *x_new, double y_new, doubl
     *appended_out = 0;
     if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
     if (g->tries != 0 || g->n >= g->n_pad) return CBO_OK;
+    if (g->dtype != CBO_DTYPE_F64) return CBO_OK;       // the resident V of the row update is an fp64 object
     cbo_ctx *c = g->ctx;
     HIP_TRY(hipSetDevice(c->device));
     const bool causal = g->X.sv != nullptr;
@@ -1084,6 +1152,12 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
     if (g->n <= 0 || g->n_pad <= 0) return fail(CBO_ERR_INVALID, "gp holds no data (a previous upload failed)");
     cbo_ctx *c = g->ctx;
     HIP_TRY(hipSetDevice(c->device));
+    if (g->dtype == CBO_DTYPE_F32) {
+        // the fp32 sweep needs the finished fp64 factor (down-converted once): the plain sequence
+        rc = cbo_gp_fit(g, tries_out, jitter_out);
+        if (rc != CBO_OK) return rc;
+        return cbo_acq_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
+    }
     rc = prepare_cands(g, k);
     if (rc != CBO_OK) return rc;
     int64_t chunk = 0, ldv = 0;
@@ -1351,7 +1425,7 @@ extern "C" int cbo_gp_predict_gradients(cbo_gp *g, int64_t m, const double *Xs, 
     double *W = nullptr, *work = nullptr, *grads = nullptr, *inv_ls = nullptr;
     auto cleanup = [&]() { hipFree(W); hipFree(work); hipFree(grads); hipFree(inv_ls); cbo_cands_destroy(k); };
     rc = ensure_alpha(g);
-    if (rc == CBO_OK) rc = enqueue_posterior(g, k);            // V = L^-1 K*
+    if (rc == CBO_OK) rc = enqueue_posterior(g, k, true);      // V = L^-1 K* (fp64 workspace)
     int64_t chunk = 0, ldv = 0;
     if (rc == CBO_OK) rc = ensure_workspaces(c, g->n_pad, k->m_pad, &chunk, &ldv);
     if (rc == CBO_OK && chunk < k->m_pad) rc = fail(CBO_ERR_INVALID, "too many points for one workspace chunk");
@@ -1558,5 +1632,9 @@ extern "C" int cbo_selftest_mfma(cbo_ctx *c, double *max_abs_err_out)
     if (run_mfma_selftest(c->stream, &err) != 0) return fail(CBO_ERR_HIP, "mfma selftest launch failed");
     if (max_abs_err_out) *max_abs_err_out = err;
     if (err != 0.0) return fail(CBO_ERR_HIP, "fp64 MFMA lane map differs from what the kernels assume");
+    double err32 = -1.0;
+    if (run_mfma_f32_selftest(c->stream, &err32) != 0) return fail(CBO_ERR_HIP, "f32 mfma selftest launch failed");
+    if (max_abs_err_out) *max_abs_err_out = err32 > err ? err32 : err;
+    if (err32 != 0.0) return fail(CBO_ERR_HIP, "fp32 MFMA lane map differs from what the kernels assume");
     return CBO_OK;
 }

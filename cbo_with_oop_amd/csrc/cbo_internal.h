@@ -83,6 +83,22 @@ void launch_rhs(hipStream_t s, const double *y, const double *pm, int64_t n, dou
 void launch_kstar(hipStream_t s, const PointSet &X, const PointSet &C, int64_t c_begin, int64_t m_pad,
                   const KernelHyper &h, double *V, int64_t ldv, int64_t n_pad);
 
+// ---- fp32 sweep (kernels_f32.hip; BASELINE.json configs[4]) -----------------------------------------------
+// The fit stays fp64; factor, diagonal inverses and z are down-converted once per fit into a layout whose 16-row
+// groups are row-permuted (physical row 4 (k & 3) + (k >> 2) = logical row k) and padded to n32 = round_up(n_pad, 256).
+constexpr int kPadN32 = 256;
+void launch_factor_to_f32(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt, float *Uf,
+                          int64_t ldu, float *invF, int64_t n32);
+// K(X, X*) in fp64 arithmetic, stored as fp32; the posterior mean's kernel part mu = K*^T alpha (GPy's own formula)
+// is formed on the way from the unrounded values: mu_part is (n32 / 64) * m_pad doubles of workspace
+void launch_kstar_f32(hipStream_t s, const PointSet &X, const PointSet &C, int64_t c_begin, int64_t m_pad,
+                      const KernelHyper &h, float *V, int64_t ldv, int64_t n32, const double *alpha, double *mu_part,
+                      double *mu);
+// V <- L^-1 V in fp32 (64-column strips), q[c] = sum V^2 accumulated in fp64
+void launch_trsm_strips_f32(hipStream_t s, const float *U, int64_t ldu, const float *invDt, float *V, int64_t ldv,
+                            int64_t n32, int64_t m_pad, double *q);
+int run_mfma_f32_selftest(hipStream_t s, double *max_err);
+
 // Recursive blocked Cholesky (upper) of A[0:n_pad, 0:n_pad] incl. forward solve of the rhs strip.
 // Sweep pipelined with the factorisation: as soon as a pair of 128-row panels of U is final, the strip kernel
 // solves those rows of V on `stream` (q, mu accumulate) and trsm_update_kernel folds them into the rows below,

@@ -100,9 +100,15 @@ struct KmatArgs {
     double variance, lengthscale, diag_add, jitter;
     int symmetric, zero_diag;
     int sym_tiles;                 // symmetric: tiles per side (grid = upper triangle, linearised)
+    float *out32;                  // OUT32: fp32 output (K* of the fp32 sweep), rows of every 16-row group permuted
+    const double *alpha;           // OUT32: woodbury vector; mu_part[row tile][column] = sum over the tile's 64 rows of
+    double *mu_part;               //        K*[i][c] alpha[i], formed from the fp64 values before they are rounded
+    int64_t ld_part;
 };
 
-template <int D>
+// OUT32: the same fp64 arithmetic, rounded to fp32 on store, into the row-permuted layout of kernels_f32.hip
+// (physical row 4 (k & 3) + (k >> 2) of a 16-row group holds logical row k).
+template <int D, bool OUT32 = false>
 __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a)
 {
     int tj = blockIdx.x, ti = blockIdx.y;
@@ -118,14 +124,21 @@ __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a)
     }
     __shared__ double sx[D][64], sy[D][64];
     __shared__ double sxq[64], syq[64], sxv[64], syv[64];
+    __shared__ double sal[OUT32 ? 64 : 1], smu[OUT32 ? 8 * 64 : 1];
     const int tid = threadIdx.x;
     const int64_t i0 = (int64_t)ti * 64, j0 = (int64_t)tj * 64;
+    if (OUT32 && tid >= 128 && tid < 192) {
+        const int64_t gi = i0 + (tid - 128);
+        sal[tid - 128] = (gi < a.n_rows) ? a.alpha[gi] : 0.0;
+    }
+    double macc[2] = {0.0, 0.0};
     if (tid < 64) {
         const int64_t gi = i0 + tid;
+        const bool in = gi < a.ldr;                    // fp32 sweep: rows are padded to 256, beyond the point set's ld
 #pragma unroll
-        for (int k = 0; k < D; ++k) sx[k][tid] = a.rx[(int64_t)k * a.ldr + gi];
-        sxq[tid] = a.rsq[gi];
-        sxv[tid] = a.rsv ? a.rsv[gi] : 0.0;
+        for (int k = 0; k < D; ++k) sx[k][tid] = in ? a.rx[(int64_t)k * a.ldr + gi] : 0.0;
+        sxq[tid] = in ? a.rsq[gi] : 0.0;
+        sxv[tid] = (in && a.rsv) ? a.rsv[gi] : 0.0;
     } else if (tid < 128) {
         const int t = tid - 64;
         const int64_t gj = a.col_begin + j0 + t;
@@ -180,14 +193,38 @@ __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a)
             }
             o[c] = v;
         }
-        *reinterpret_cast<d2 *>(&a.out[gi * a.ldo + j0 + 2 * tx]) = o;
+        if (OUT32) {
+            macc[0] = __fma_rn(o[0], sal[ii], macc[0]);
+            macc[1] = __fma_rn(o[1], sal[ii], macc[1]);
+            const int64_t pr = (gi & ~(int64_t)15) + 4 * (gi & 3) + ((gi >> 2) & 3);
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 of;
+            of[0] = (float)o[0];
+            of[1] = (float)o[1];
+            *reinterpret_cast<f2 *>(&a.out32[pr * a.ldo + j0 + 2 * tx]) = of;
+        } else {
+            *reinterpret_cast<d2 *>(&a.out[gi * a.ldo + j0 + 2 * tx]) = o;
+        }
+    }
+    if (OUT32) {
+        // GPy Posterior._raw_predict: mu = Kx^T woodbury_vector -- the tile's share of it, fixed summation order
+        smu[ty * 64 + 2 * tx] = macc[0];
+        smu[ty * 64 + 2 * tx + 1] = macc[1];
+        __syncthreads();
+        if (tid < 64) {
+            double t = 0.0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) t = __dadd_rn(t, smu[g * 64 + tid]);
+            a.mu_part[(int64_t)ti * a.ld_part + j0 + tid] = t;
+        }
     }
 }
 
 template <int D>
 static void launch_kmat_d(hipStream_t s, const KmatArgs &a, dim3 grid)
 {
-    hipLaunchKernelGGL(kmat_tile_kernel<D>, grid, dim3(256), 0, s, a);
+    if (a.out32) hipLaunchKernelGGL((kmat_tile_kernel<D, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((kmat_tile_kernel<D, false>), grid, dim3(256), 0, s, a);
 }
 
 static void launch_kmat(hipStream_t s, int d, const KmatArgs &a, dim3 grid)
@@ -213,7 +250,7 @@ void launch_kxx(hipStream_t s, const PointSet &X, const KernelHyper &h, double d
     a.n_rows = X.n; a.n_cols = X.n; a.col_begin = 0;
     a.out = A; a.ldo = lda;
     a.variance = h.variance; a.lengthscale = h.lengthscale; a.diag_add = diag_add; a.jitter = jitter;
-    a.symmetric = 1; a.zero_diag = h.zero_diag;
+    a.symmetric = 1; a.zero_diag = h.zero_diag; a.out32 = nullptr; a.alpha = nullptr; a.mu_part = nullptr; a.ld_part = 0;
     const int nt = (int)(n_pad / 64);
     a.sym_tiles = nt;
     launch_kmat(s, X.d, a, dim3((unsigned)(nt * (nt + 1) / 2), 1));
@@ -228,8 +265,37 @@ void launch_kstar(hipStream_t s, const PointSet &X, const PointSet &C, int64_t c
     a.n_rows = X.n; a.n_cols = C.ld; a.col_begin = c_begin;   // all padded columns are computable
     a.out = V; a.ldo = ldv;
     a.variance = h.variance; a.lengthscale = h.lengthscale; a.diag_add = 0.0; a.jitter = 0.0;
-    a.symmetric = 0; a.zero_diag = 0; a.sym_tiles = 0;
+    a.symmetric = 0; a.zero_diag = 0; a.sym_tiles = 0; a.out32 = nullptr; a.alpha = nullptr; a.mu_part = nullptr; a.ld_part = 0;
     launch_kmat(s, X.d, a, dim3((unsigned)(m_pad / 64), (unsigned)(n_pad / 64)));
+}
+
+// mu[c] = sum over the row tiles of mu_part[t][c] (fixed order)
+__global__ __launch_bounds__(256) void colsum_parts_kernel(const double *__restrict__ part, int64_t ld, int tiles,
+                                                           int64_t m, double *__restrict__ mu)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= m) return;
+    double t = 0.0;
+    for (int i = 0; i < tiles; ++i) t = __dadd_rn(t, part[(int64_t)i * ld + c]);
+    mu[c] = t;
+}
+
+// K(X, X*) rounded to fp32 for the fp32 sweep: [n32][ldv] floats, rows permuted (kernels_f32.hip), rows >= n zero.
+void launch_kstar_f32(hipStream_t s, const PointSet &X, const PointSet &C, int64_t c_begin, int64_t m_pad,
+                      const KernelHyper &h, float *V, int64_t ldv, int64_t n32, const double *alpha, double *mu_part,
+                      double *mu)
+{
+    KmatArgs a;
+    a.rx = X.xs; a.ldr = X.ld; a.rsq = X.sq; a.rsv = X.sv;
+    a.cx = C.xs; a.ldc = C.ld; a.csq = C.sq; a.csv = (X.sv != nullptr) ? C.sv : nullptr;
+    a.n_rows = X.n; a.n_cols = C.ld; a.col_begin = c_begin;
+    a.out = nullptr; a.ldo = ldv; a.out32 = V;
+    a.alpha = alpha; a.mu_part = mu_part; a.ld_part = m_pad;
+    a.variance = h.variance; a.lengthscale = h.lengthscale; a.diag_add = 0.0; a.jitter = 0.0;
+    a.symmetric = 0; a.zero_diag = 0; a.sym_tiles = 0;
+    launch_kmat(s, X.d, a, dim3((unsigned)(m_pad / 64), (unsigned)(n32 / 64)));
+    hipLaunchKernelGGL(colsum_parts_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, mu_part, m_pad,
+                       (int)(n32 / 64), m_pad, mu);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -31,7 +31,7 @@ typedef enum cbo_status {
     CBO_ERR_NOT_PD = -3,      /* jitchol exhausted its 5 retries (numpy.linalg.LinAlgError in GPy) */
     CBO_ERR_NONPOS_DIAG = -4, /* jitchol: "not pd: non-positive diagonal elements" */
     CBO_ERR_NOT_FITTED = -5,
-    CBO_ERR_UNSUPPORTED = -6, /* e.g. dtype f32 (planned) */
+    CBO_ERR_UNSUPPORTED = -6, /* a request this build cannot serve (e.g. a workspace cap too small for the call) */
     CBO_ERR_NO_DEVICE = -7,
     CBO_ERR_COMM = -8
 } cbo_status;
@@ -56,6 +56,7 @@ typedef struct cbo_timers {
     int64_t n_sweep;   /* number of sweeps / predicts timed                  */
     int64_t n_trsm_launches;
     double trsm_flops; /* algorithmic flops of the timed trsm launches: sum n_pad^2 * m_pad */
+    double ms_f32_convert; /* CBO_DTYPE_F32 models: factor / diagonal inverses / z down-converted after a fit */
 } cbo_timers;
 
 /* ---- context ---------------------------------------------------------------------------------- */
@@ -82,6 +83,12 @@ int cbo_region_end(cbo_ctx *ctx, double *ms_out);
  * already evaluated on X (NULL, NULL = non-causal kernel, zero mean).  zero_diag selects GPy's
  * X2=None distance shortcut (plain RBF) vs CausalRBF's explicit-X2 path (causal_kernels.py:53-55).
  * Uploads X, y, priors; does not fit. */
+/* dtype (BASELINE.json configs[4], "fp32 path with MFMA"): CBO_DTYPE_F64 -- everything fp64; CBO_DTYPE_F32 -- the
+ * FIT stays fp64 (Ky carries a 1e-8 jitter fp32 cannot represent) and every sweep / predict of the model runs its
+ * substitution V = L^-1 K* on the f32 MFMA (157 TFLOP/s dense against 78.6 for fp64) from a once-per-fit fp32 copy of
+ * the factor; K* is evaluated in fp64 and rounded to fp32, q = sum V^2 and mu = V^T z accumulate in fp64.  Accuracy is
+ * that of an fp32 triangular solve: about 6e-8 * sqrt(cond(Ky)) relative in V (tests/test_f32_gpu.py states what it
+ * meets on the coral ranges); cbo_gp_append and cbo_cands_keep_solution do not apply (the caller refits). */
 int cbo_gp_create(cbo_ctx *ctx, int dtype, int64_t n, int d, const double *X, const double *y,
                   const double *prior_mean_X, const double *prior_var_X, double variance,
                   const double *lengthscale /* 1 value, or d values if ard */, int ard,
@@ -161,6 +168,7 @@ int cbo_gp_get_posterior(cbo_gp *gp, double *L_out, double *alpha_out);
  * K(X,X) + diag into K_out (n*n row-major, symmetric) for tests of the assembly kernel. */
 int cbo_gp_assemble_kxx(cbo_gp *gp, double *K_out);
 int64_t cbo_gp_n(const cbo_gp *gp);
+int cbo_gp_dtype(const cbo_gp *gp);
 /* Outcome of the jitchol ladder of the last fit: retries used (0 = none) and jitter added. */
 int cbo_gp_jitter(const cbo_gp *gp, int *jitter_tries_out, double *jitter_out);
 
