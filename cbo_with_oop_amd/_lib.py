@@ -121,6 +121,15 @@ SIGNATURES = {
     "cbo_sem_target": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_int_p,
                                       c_double_p, c_double_p]),
     "cbo_selftest_mfma": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
+    "cbo_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "cbo_comm_init_rank": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, c_void_pp]),
+    "cbo_comm_init_all": (ctypes.c_int, [ctypes.c_int, c_void_pp, c_void_pp]),
+    "cbo_comm_destroy": (None, [ctypes.c_void_p]),
+    "cbo_comm_size": (ctypes.c_int, [ctypes.c_void_p, c_int_p, c_int_p]),
+    "cbo_comm_argmax": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_int64, c_double_p, c_int64_p]),
+    "cbo_comm_argmax_all": (ctypes.c_int, [ctypes.c_int, c_void_pp, c_double_p, c_int64_p, c_double_p, c_int64_p]),
+    "cbo_comm_max_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, c_double_p]),
+    "cbo_comm_barrier": (ctypes.c_int, [ctypes.c_void_p]),
 }
 
 _lib = None

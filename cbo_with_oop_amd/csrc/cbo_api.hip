@@ -1,10 +1,13 @@
 // C-ABI host side of libcbo_hip.so (declared in include/cbo_hip.h): handle management, the jitchol
 // retry ladder, candidate chunking, profiling events.  All arithmetic of the path runs in the HIP
 // kernels of kernels_*.hip; there is no CPU fallback here.
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -19,6 +22,30 @@ static int fail(int code, const std::string &msg)
 {
     g_err = msg;
     return code;
+}
+namespace cbo {
+int set_error(int code, const std::string &msg) { return fail(code, msg); }
+}
+
+// Every context that cbo_init handed out and cbo_shutdown has not seen yet.  A context owns CU-masked streams
+// (hipExtStreamCreateWithCUMask); when those are still alive while the HIP runtime runs its own exit handlers,
+// tools that hook finalisation (rocprofv3) crash inside __cxa_finalize.  The first cbo_init therefore registers an
+// atexit handler -- after the runtime's own, so it runs BEFORE them -- that shuts down whatever the caller left
+// open: a C or ctypes consumer that exits without cbo_shutdown is safe too.  cbo_shutdown ignores handles that are
+// not (or no longer) registered, which also makes a second call on the same handle harmless.
+static std::mutex g_live_mutex;
+static std::vector<cbo_ctx *> g_live;
+static void shutdown_all_at_exit()
+{
+    for (;;) {
+        cbo_ctx *c = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g_live_mutex);
+            if (g_live.empty()) break;
+            c = g_live.back();
+        }
+        cbo_shutdown(c);
+    }
 }
 
 #define HIP_TRY(expr)                                                                                   \
@@ -189,6 +216,8 @@ static void resolve_events(cbo_ctx *c)
 }
 
 // ---- context -------------------------------------------------------------------------------------
+static void destroy_ctx(cbo_ctx *c);
+
 extern "C" int cbo_abi_version(void) { return CBO_HIP_ABI_VERSION; }
 extern "C" const char *cbo_last_error(void) { return g_err.c_str(); }
 
@@ -262,7 +291,7 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
     if (e == hipSuccess) e = hipHostMalloc(&c->h_best_idx, sizeof(int64_t));
     if (e == hipSuccess) e = hipHostMalloc(&c->h_info, sizeof(int));
     if (e != hipSuccess) {
-        cbo_shutdown(c);
+        destroy_ctx(c);
         return fail(CBO_ERR_HIP, std::string("cbo_init: ") + hipGetErrorString(e));
     }
     const char *ws = std::getenv("CBO_HIP_WORKSPACE_MB");
@@ -280,13 +309,35 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
     if (tf) c->pipe_tail_frac = std::atof(tf);
     const char *kb = std::getenv("CBO_HIP_PIPE_KB");
     if (kb && std::atoi(kb) == 32) c->pipe_half_lds = false;
+    {
+        static std::once_flag once;
+        std::call_once(once, [] { std::atexit(shutdown_all_at_exit); });
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        g_live.push_back(c);
+    }
     *out = c;
     return CBO_OK;
+}
+
+namespace cbo {
+hipStream_t ctx_stream(cbo_ctx *c) { return c->stream; }
+int ctx_device(cbo_ctx *c) { return c->device; }
 }
 
 extern "C" void cbo_shutdown(cbo_ctx *c)
 {
     if (!c) return;
+    {
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        auto it = std::find(g_live.begin(), g_live.end(), c);
+        if (it == g_live.end()) return;              // already shut down (or never ours): the pointer is not touched
+        g_live.erase(it);
+    }
+    destroy_ctx(c);
+}
+
+static void destroy_ctx(cbo_ctx *c)
+{
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
@@ -313,7 +364,7 @@ extern "C" int cbo_synchronize(cbo_ctx *c)
 {
     if (!c) return fail(CBO_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipDeviceSynchronize());            // every stream of the device, the communicator's included
     return CBO_OK;
 }
 

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "cbo_hip.h"
@@ -48,6 +49,11 @@ constexpr int kRhsCols = 64;     // width of the right-hand-side strip appended 
 constexpr int kLdExtra = 16;     // extra doubles per row so consecutive rows fall in different channels
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// shared with cbo_comm.hip (the context is defined in cbo_api.hip)
+int set_error(int code, const std::string &msg);          // records the message for cbo_last_error(), returns code
+hipStream_t ctx_stream(cbo_ctx *c);
+int ctx_device(cbo_ctx *c);
 
 // GPy constants (GPy 1.10.0 exact_gaussian_inference.py / posterior.py); see oracle/gp_oracle.py.
 constexpr double kGpyDiagJitter = 1e-8;

@@ -1,19 +1,27 @@
-"""Candidate-grid sharding across the GPUs of one node.
+"""Candidate-grid sharding across the GPUs of one node -- no PyTorch.
 
-The acquisition sweep is independent per candidate once the posterior is fitted, so the grid is cut
-into contiguous blocks, one per rank (one process per GPU); every rank fits the same posterior from
-the same (X, y) (replicated, bit-identical, no data-path collective) and sweeps its block.  The only
-exchange is the arg-max: each rank contributes (best_val, best_global_idx) = 16 bytes, all-gathered
-through the launcher's process group -- with backend "nccl" that is RCCL over xGMI -- and every rank
-reduces the gathered pairs with the same tie rule (lowest global index wins; NaN maximal), so all
-ranks agree on the winner.  RCCL has no MAXLOC, hence gather + local reduce.
+The acquisition sweep is independent per candidate once the posterior is fitted, so the grid is cut into contiguous
+blocks, one per rank (one process per GPU); every rank fits the same posterior from the same (X, y) (replicated,
+bit-identical, no data-path collective) and sweeps its block.  The only exchange is the arg-max: each rank
+contributes (best_val, best_global_idx) = 16 bytes, all-gathered over RCCL (xGMI) by ``libcbo_hip.so`` itself
+(``cbo_comm_*`` of include/cbo_hip.h: ``librccl.so.1`` is dlopen'ed there) and reduced with the same tie rule on
+every rank (lowest global index wins; NaN maximal), so all ranks agree on the winner.  RCCL has no MAXLOC, hence
+gather + local reduce.
 
-torch.distributed is used for the rendezvous/collective only (plumbing); no torch types cross the
-C-ABI.
+Launch layout: the one ``torch.distributed.run`` / ``mpirun`` produce -- RANK, WORLD_SIZE, LOCAL_RANK in the
+environment.  The 128-byte RCCL id travels from rank 0 to the others through a file in the temporary directory
+(single node; keyed by MASTER_PORT, the launcher's pid and its run id) -- the launcher's own TCP store belongs to
+the launcher.
+
+Exploration sets are a second independent axis (src/CBO.py:249 loops over them): ``CBOAcquisitionPath`` places whole
+sets on ranks when there are at least as many sets as ranks, and candidate blocks otherwise.
 """
 from __future__ import annotations
 
 import ctypes
+import os
+import tempfile
+import time
 
 import numpy as np
 
@@ -41,73 +49,120 @@ def reduce_pairs(vals, idxs):
 
 
 NO_CANDIDATE = np.iinfo(np.int64).max     # index sent by a rank whose shard is empty
+ID_BYTES = 128
 
 
-_exchange_buffers = {}     # (device, world size) -> persistent tensors of the per-step exchange
+def _id_path():
+    tag = "_".join(str(os.environ.get(k, "x")) for k in ("MASTER_PORT", "TORCHELASTIC_RUN_ID"))
+    return os.path.join(tempfile.gettempdir(), f"cbo_comm_{tag}_{os.getppid()}.id")
 
 
-def _buffers(device, world):
-    """Persistent pinned/device tensors and, on a GPU, a side stream of torch's own: the exchange then allocates
-    nothing per step and never touches the legacy default stream (whose operations synchronise with every blocking
-    stream of the process, the library's CU-masked ones included)."""
-    import torch
-    key = (str(device), world)
-    buf = _exchange_buffers.get(key)
-    if buf is None:
-        on_gpu = device.type == "cuda"
-        buf = {
-            "host_in": torch.empty(2, dtype=torch.int64, pin_memory=on_gpu),
-            "host_out": torch.empty(2 * world, dtype=torch.int64, pin_memory=on_gpu),
-            "mine": torch.empty(2, dtype=torch.int64, device=device),
-            "out": torch.empty(2 * world, dtype=torch.int64, device=device),
-            "stream": torch.cuda.Stream(device=device) if on_gpu else None,
-        }
-        _exchange_buffers[key] = buf
-    return buf
+class Communicator:
+    """One rank of an RCCL communicator (``cbo_comm``).  ``from_env`` forms it from the launcher's environment;
+    ``single`` forms a one-rank communicator (exercises the collective on a one-GPU box)."""
+
+    def __init__(self, context, world, rank, id_bytes):
+        self._lib = _lib.load()
+        self._ctx = context
+        self.world, self.rank = int(world), int(rank)
+        buf = (ctypes.c_char * ID_BYTES).from_buffer_copy(id_bytes)
+        self._handle = ctypes.c_void_p()
+        _lib.check(self._lib.cbo_comm_init_rank(context.handle, self.world, self.rank, buf, ctypes.byref(self._handle)))
+
+    @staticmethod
+    def unique_id():
+        buf = (ctypes.c_char * ID_BYTES)()
+        _lib.check(_lib.load().cbo_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def single(cls, context):
+        return cls(context, 1, 0, cls.unique_id())
+
+    @classmethod
+    def from_env(cls, context=None, timeout_s=120.0):
+        """The communicator of this process under a one-process-per-GPU launcher, or None for a plain run
+        (no RANK / WORLD_SIZE in the environment)."""
+        if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
+            return None
+        world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+        ctx = context if context is not None else _lib.Context.get()
+        path = _id_path()
+        if rank == 0:
+            uid = cls.unique_id()
+            tmp = f"{path}.{os.getpid()}.tmp"
+            with open(tmp, "wb") as f:
+                f.write(uid)
+            os.replace(tmp, path)                       # atomic: a reader sees all 128 bytes or no file
+        else:
+            deadline = time.monotonic() + timeout_s
+            while not os.path.exists(path):
+                if time.monotonic() > deadline:
+                    raise _lib.CboHipError(_lib.CBO_ERR_COMM, f"rank {rank}: no communicator id at {path}")
+                time.sleep(0.01)
+            with open(path, "rb") as f:
+                uid = f.read()
+        comm = cls(ctx, world, rank, uid)
+        comm.barrier()                                   # every rank has read the id
+        if rank == 0:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        return comm
+
+    def argmax(self, best_val, best_idx):
+        bv, bi = ctypes.c_double(0.0), ctypes.c_int64(-1)
+        _lib.check(self._lib.cbo_comm_argmax(self._handle, float(best_val), int(best_idx), ctypes.byref(bv),
+                                             ctypes.byref(bi)))
+        return bv.value, bi.value
+
+    def max(self, value):
+        out = ctypes.c_double(0.0)
+        _lib.check(self._lib.cbo_comm_max_f64(self._handle, float(value), ctypes.byref(out)))
+        return out.value
+
+    def barrier(self):
+        _lib.check(self._lib.cbo_comm_barrier(self._handle))
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            if not self._ctx.closed:
+                self._lib.cbo_comm_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
-def exchange_argmax(best_val, best_idx, group=None, device=None):
-    """All-gather this rank's (best_val, best_global_idx) and reduce.  Returns (val, idx) identical on
-    every rank.  Without an initialised process group (plain single-GPU run) it is the identity; a group of
-    one rank still goes through the collective."""
-    import torch
-    import torch.distributed as dist
+_default = {}
 
-    if not (dist.is_available() and dist.is_initialized()):
+
+def default_communicator(context=None):
+    """The process-wide communicator formed from the environment on first use (None for a plain run)."""
+    if "comm" not in _default:
+        _default["comm"] = Communicator.from_env(context)
+    return _default["comm"]
+
+
+def exchange_argmax(best_val, best_idx, comm=None):
+    """All-gather this rank's (best_val, best_global_idx) and reduce.  Returns (val, idx), identical on every
+    rank.  Without a communicator (plain single-GPU run) it is the identity."""
+    if comm is None:
         return float(best_val), int(best_idx)
-    world = dist.get_world_size(group)
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" \
-            else torch.device("cpu")
-    device = torch.device(device)
-    buf = _buffers(device, world)
-    # one 16-byte record per rank: the value's bits and the index, both as int64 (one collective)
-    buf["host_in"][0] = np.float64(best_val).view(np.int64).item()
-    buf["host_in"][1] = int(best_idx)
-    if buf["stream"] is not None:
-        with torch.cuda.stream(buf["stream"]):
-            buf["mine"].copy_(buf["host_in"], non_blocking=True)
-            dist.all_gather_into_tensor(buf["out"], buf["mine"], group=group)
-            buf["host_out"].copy_(buf["out"], non_blocking=True)
-        buf["stream"].synchronize()
-    else:
-        buf["mine"].copy_(buf["host_in"])
-        dist.all_gather_into_tensor(buf["out"], buf["mine"], group=group)
-        buf["host_out"].copy_(buf["out"])
-    rec = buf["host_out"].numpy().reshape(world, 2)
-    vals = rec[:, 0].copy().view(np.float64)
-    idxs = rec[:, 1].copy()
-    keep = idxs != NO_CANDIDATE
-    return reduce_pairs(vals[keep], idxs[keep])
+    return comm.argmax(best_val, best_idx)
 
 
-def sharded_sweep(local_sweep, m_total, world_size, rank, group=None, device=None):
+def sharded_sweep(local_sweep, m_total, world_size, rank, exchange=exchange_argmax):
     """Run ``local_sweep(begin, end) -> (best_val, best_global_idx)`` on this rank's block and agree on
-    the global winner.  ``local_sweep`` is the HIP sweep in the product (bench.py, CBO path); tests
-    inject other callables to exercise the exchange on CPU ranks."""
+    the global winner through ``exchange(val, idx)``.  ``local_sweep`` is the HIP sweep in the product (bench.py,
+    CBO path); tests inject other callables (and a gloo exchange) to rehearse the logic on CPU ranks."""
     begin, end = shard_bounds(m_total, world_size, rank)
     if end > begin:
         val, idx = local_sweep(begin, end)
     else:
         val, idx = -np.inf, NO_CANDIDATE
-    return exchange_argmax(val, idx, group=group, device=device)
+    return exchange(val, idx)

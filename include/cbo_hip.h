@@ -65,6 +65,10 @@ const char *cbo_last_error(void);
 int cbo_device_count(int *count_out);
 /* Bind device `device_id`; fails with CBO_ERR_NO_DEVICE when no gfx950-class GPU is visible. */
 int cbo_init(int device_id, cbo_ctx **out);
+/* Releases everything the context owns.  Contexts still open when the process exits are shut down by an atexit
+ * handler the first cbo_init registers (it runs before the HIP runtime's own exit handlers: a context's CU-masked
+ * streams must not outlive the runtime -- tools that hook finalisation crash otherwise); a handle that was already
+ * shut down is ignored.  Models, candidate sets and communicators of a context must be destroyed before it. */
 void cbo_shutdown(cbo_ctx *ctx);
 int cbo_synchronize(cbo_ctx *ctx);
 int cbo_set_profiling(cbo_ctx *ctx, int enabled);
@@ -216,10 +220,37 @@ int cbo_acq_sweep_host(cbo_gp *gp, int64_t m, const double *Xs, const double *pr
 int cbo_argmax_sets(const double *ys, int s, int *idx_out);
 
 /* Reduce (best_val, best_idx) pairs gathered from all candidate shards (one per GPU) to the global
- * winner with the same tie rule; pure host arithmetic on 16 B per rank.  The gather itself is done by
- * the launcher's communicator (RCCL all-gather via torch.distributed). */
+ * winner with the same tie rule; pure host arithmetic on 16 B per rank (cbo_comm_argmax gathers and calls it). */
 int cbo_argmax_pairs(const double *vals, const int64_t *idxs, int n, double *best_val,
                      int64_t *best_idx);
+
+/* ---- arg-max exchange across GPUs ------------------------------------------------------
+ * The candidate grid shards over the GPUs of a node (contiguous blocks, index_offset of cbo_cands_create), the
+ * posterior is replicated, and the one exchange step is 16 bytes per rank: (best acquisition value, best GLOBAL
+ * candidate index), all-gathered over RCCL (xGMI) and reduced identically on every rank with the tie rule of
+ * cbo_argmax_pairs -- RCCL has no MAXLOC.  The reference is a single process (src/CBO.py:269-277 picks over sets);
+ * this is the cross-GPU counterpart of that pick.  librccl.so.1 is dlopen'ed on first use (CBO_HIP_RCCL_LIB
+ * overrides the name); no PyTorch involved.  Every RCCL failure returns CBO_ERR_COMM with RCCL's message.
+ *
+ * One process per GPU: rank 0 calls cbo_comm_unique_id (128 bytes), the launcher's side channel (a file, MPI_Bcast,
+ * a TCP store) hands the bytes to the other ranks, every rank calls cbo_comm_init_rank on its own context.
+ * One process driving G devices: cbo_comm_init_all fills out[0..n) (rank i on ctxs[i]); use cbo_comm_argmax_all,
+ * which issues the G collectives as one group. */
+typedef struct cbo_comm cbo_comm;
+#define CBO_COMM_ID_BYTES 128
+int cbo_comm_unique_id(void *id_out /* CBO_COMM_ID_BYTES */);
+int cbo_comm_init_rank(cbo_ctx *ctx, int world, int rank, const void *id /* CBO_COMM_ID_BYTES */, cbo_comm **out);
+int cbo_comm_init_all(int n, cbo_ctx *const *ctxs, cbo_comm **out /* n handles */);
+void cbo_comm_destroy(cbo_comm *comm);
+int cbo_comm_size(const cbo_comm *comm, int *world_out, int *rank_out);
+/* This rank's (val, global idx) in, the global winner out (identical on every rank).  A rank whose shard is empty
+ * passes idx = INT64_MAX.  Blocking (the exchange runs on the communicator's own stream). */
+int cbo_comm_argmax(cbo_comm *comm, double val, int64_t idx, double *best_val, int64_t *best_idx);
+int cbo_comm_argmax_all(int n, cbo_comm *const *comms, const double *vals, const int64_t *idxs, double *best_val,
+                        int64_t *best_idx);
+/* max over the ranks of one double (the slowest rank's time of a benchmark); doubles as a barrier */
+int cbo_comm_max_f64(cbo_comm *comm, double value, double *max_out);
+int cbo_comm_barrier(cbo_comm *comm);
 
 /* ---- Monte-Carlo interventional target -----------------------------------------
  * Replaces compute_interventions (src/utils_functions/graph_functions.py:48-77): the mean of the target node

@@ -1,4 +1,6 @@
 """CPU tests of the host-side mirror of the reference interface (no device calls)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -8,6 +10,7 @@ from cbo_with_oop_amd.graphs import GRAPHS, CompleteGraph, CoralGraph, ToyGraph,
 from cbo_with_oop_amd.sharding import reduce_pairs, shard_bounds
 from cbo_with_oop_amd.utils_functions.cost_functions import Cost, total_cost
 from cbo_with_oop_amd.utils_functions.utils import default_grid_shape, find_current_global, space_bounds
+from conftest import ROOT
 from oracle import gp_oracle as O
 
 
@@ -95,3 +98,17 @@ def test_one_row_growth_detection():
     assert not grew(np.hstack([x7, x7[:, :1]]), y7)               # another dimension
     model.stale = True
     assert not grew(x7, y7)                                       # nothing fitted to extend
+
+
+def test_missing_rccl_is_reported_as_comm_error():
+    """The arg-max exchange opens librccl with dlopen inside libcbo_hip.so: when it cannot, the C-ABI says
+    CBO_ERR_COMM (no GPU needed for that; a fresh process because the library is opened once per process)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from cbo_with_oop_amd import _lib\n"
+            "from cbo_with_oop_amd.sharding import Communicator\n"
+            "try:\n    Communicator.unique_id()\nexcept _lib.CboHipError as e:\n    print('code', e.code)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CBO_HIP_RCCL_LIB="/nonexistent/librccl.so"),
+                         capture_output=True, text=True, timeout=120)
+    assert "code -8" in out.stdout, (out.stdout, out.stderr[-500:])

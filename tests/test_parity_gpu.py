@@ -610,9 +610,19 @@ def test_prediction_gradients_and_refinement(hip):
     assert np.isclose(f1[0, 0], -fxo, rtol=1e-5) and np.allclose(x1[0], xo, atol=1e-4)
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def test_bench_exchange_over_rccl_single_rank(hip):
-    """bench.py under torch.distributed.run with one rank: the process group is RCCL (backend nccl) and the
-    winner goes through all_gather_into_tensor on the GPU; it must equal the winner of the plain run."""
+    """bench.py under the one-process-per-GPU launcher with one rank: the communicator is RCCL formed inside
+    libcbo_hip.so (no PyTorch in the bench process) and the winner goes through ncclAllGather on the GPU; it must
+    equal the winner of the plain run."""
     import json
     import subprocess
     import sys
@@ -620,19 +630,60 @@ def test_bench_exchange_over_rccl_single_rank(hip):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-sample", "0"]
+    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--post-steps", "0"]
     plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, env=env, capture_output=True,
                            text=True, timeout=300, cwd=ROOT)
     assert plain.returncode == 0, plain.stderr[-2000:]
     launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-                               "--master-addr", "127.0.0.1", "--master-port", "29541",
+                               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                                os.path.join(ROOT, "bench.py")] + common, env=env, capture_output=True, text=True,
                               timeout=300, cwd=ROOT)
     assert launched.returncode == 0, launched.stderr[-2000:]
     a = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
     b = json.loads([l for l in launched.stdout.splitlines() if l.startswith("{")][-1])
     assert a["winner"] == b["winner"]
-    assert b["n_gpus"] == 1 and b["roofline"]["frac"] > 0.3
+    assert b["n_gpus"] == 1 and "RCCL" in b["config"]["exchange"] and "RCCL" not in a["config"]["exchange"]
+
+
+def test_communicator_through_the_c_abi(hip):
+    """cbo_comm_* with one rank (all a one-GPU box can form): both ways of forming the communicator, the arg-max
+    exchange, the max reduction, and the empty-shard sentinel."""
+    import ctypes
+    from cbo_with_oop_amd import _lib
+    from cbo_with_oop_amd.sharding import NO_CANDIDATE, Communicator
+    ctx = _lib.Context.get()
+    comm = Communicator.single(ctx)
+    assert (comm.world, comm.rank) == (1, 0)
+    assert comm.argmax(0.25, 1234567890123) == (0.25, 1234567890123)
+    v, i = comm.argmax(float("nan"), 7)
+    assert np.isnan(v) and i == 7
+    assert comm.max(3.5) == 3.5
+    comm.barrier()
+    with pytest.raises(_lib.CboHipError) as e:
+        comm.argmax(-np.inf, NO_CANDIDATE)              # every shard empty: nothing to pick
+    assert e.value.code == _lib.CBO_ERR_INVALID
+    comm.close()
+    # one process driving the devices: ncclCommInitAll + grouped collectives
+    lib = _lib.load()
+    ctxs = (ctypes.c_void_p * 1)(ctx.handle)
+    comms = (ctypes.c_void_p * 1)()
+    _lib.check(lib.cbo_comm_init_all(1, ctxs, comms))
+    vals, idxs = (ctypes.c_double * 1)(1.5), (ctypes.c_int64 * 1)(42)
+    bv, bi = ctypes.c_double(), ctypes.c_int64()
+    _lib.check(lib.cbo_comm_argmax_all(1, comms, vals, idxs, ctypes.byref(bv), ctypes.byref(bi)))
+    assert (bv.value, bi.value) == (1.5, 42)
+    lib.cbo_comm_destroy(comms[0])
+    # a bad library name surfaces as CBO_ERR_COMM in a fresh process (the library is opened once per process)
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from cbo_with_oop_amd import _lib\n"
+            "from cbo_with_oop_amd.sharding import Communicator\n"
+            "try:\n    Communicator.unique_id()\nexcept _lib.CboHipError as e:\n    print('code', e.code)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CBO_HIP_RCCL_LIB="/nonexistent/librccl.so"),
+                         capture_output=True, text=True, timeout=120)
+    assert "code -8" in out.stdout, (out.stdout, out.stderr[-500:])          # CBO_ERR_COMM
 
 
 def forced_context(monkeypatch, **env):

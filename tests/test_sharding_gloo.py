@@ -1,7 +1,8 @@
-"""world_size-2 (and 3) `gloo` test of the multi-GPU path on CPU ranks: candidate sharding + the
-arg-max exchange of cbo_with_oop_amd/sharding.py.  The per-shard scores come from the oracle here
-(test stand-in for the HIP sweep, which needs a GPU); what is under test is the partition, the
-all-gather and the tie rule."""
+"""world_size-2 (and 3) `gloo` rehearsal of the multi-GPU path on CPU ranks: candidate sharding and the arg-max
+exchange logic of cbo_with_oop_amd/sharding.py.  The product's exchange is RCCL inside libcbo_hip.so (cbo_comm_*,
+needs GPUs: tests/test_parity_gpu.py drives it); here the all-gather is torch.distributed/gloo, defined in this test,
+and the per-shard scores come from the oracle (stand-in for the HIP sweep).  Under test: the partition, the empty-shard
+sentinel and the tie rule (the library's own cbo_argmax_pairs reduces the gathered records)."""
 import os
 import socket
 import sys
@@ -24,10 +25,22 @@ def _free_port():
 def _worker(rank, world, port, name, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
     import torch.distributed as dist
-    from cbo_with_oop_amd.sharding import shard_bounds, sharded_sweep
+    from cbo_with_oop_amd.sharding import NO_CANDIDATE, reduce_pairs, sharded_sweep
     from oracle import gp_oracle as O
     dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def gloo_exchange(val, idx):
+        # one 16-byte record per rank (value bits, index), gathered; reduced by the library's host reduction
+        mine = torch.tensor([np.float64(val).view(np.int64).item(), int(idx)], dtype=torch.int64)
+        out = torch.empty(2 * world, dtype=torch.int64)
+        dist.all_gather_into_tensor(out, mine)
+        rec = out.numpy().reshape(world, 2)
+        vals, idxs = rec[:, 0].copy().view(np.float64), rec[:, 1].copy()
+        keep = idxs != NO_CANDIDATE
+        return reduce_pairs(vals[keep], idxs[keep])
+
     f = load_fixture(name)
     post = O.fit(f["X"], f["y"], f["mX"], f["vX"], float(f["variance"]), f["lengthscale_arg"], float(f["noise_var"]))
 
@@ -39,7 +52,7 @@ def _worker(rank, world, port, name, out_dir):
                                                   float(f["cost"]))
         return val, begin + idx
 
-    val, idx = sharded_sweep(local, f["Xs"].shape[0], world, rank)
+    val, idx = sharded_sweep(local, f["Xs"].shape[0], world, rank, exchange=gloo_exchange)
     np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([val, idx]))
     dist.barrier()
     dist.destroy_process_group()
