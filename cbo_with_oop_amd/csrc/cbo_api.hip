@@ -253,7 +253,24 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
     int prio_low = 0, prio_high = 0;
     hipError_t e = hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_high);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, prio_high);
+    // The look-ahead stream of the factorisation carries the bulk trailing updates.  CBO_HIP_CHAIN_RESERVE = k keeps
+    // k CUs per XCD away from it (for the chain's one-workgroup diagonal kernel); measured neutral at N = 4096 and
+    // -4 % at N = 16384, so the default is 0 = an ordinary high-priority stream.
+    if (e == hipSuccess) {
+        int keep = 0;
+        const char *cr = std::getenv("CBO_HIP_CHAIN_RESERVE");
+        if (cr) keep = std::atoi(cr);
+        const int n_cu = prop.multiProcessorCount;
+        bool made = false;
+        if (keep > 0 && keep * 8 < n_cu) {
+            std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
+            for (int b = 0; b < n_cu; ++b)
+                if (b / 8 >= keep) mask[(size_t)b / 32] |= 1u << (b % 32);
+            made = hipExtStreamCreateWithCUMask(&c->side_stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+            if (!made) { (void)hipGetLastError(); c->side_stream = nullptr; }
+        }
+        if (!made) e = hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, prio_high);
+    }
     // The sweep streams leave a few CUs per XCD to the factorisation: its diagonal-block kernel needs a whole
     // CU's LDS and would otherwise wait behind a queue of half-LDS sweep workgroups that keep every CU partly
     // occupied.  CU-mask bit b is CU b/8 of XCD b%8 on this device (scripts/probes/cumask_probe.hip).

@@ -16,6 +16,7 @@
 //   3. syrk_kernel            A[r0+128:, r0+128:] -= P^T P  on the upper 128x128 tiles (fp64 MFMA),
 //                             rhs[r0+128:] -= P^T z_k
 // The SYRK carries the n^3/3 flops; steps 1-2 are the serial chain.
+#include <cstdlib>
 #include <vector>
 
 #include "cbo_internal.h"
@@ -246,6 +247,338 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t l
 }
 
 // ------------------------------------------------------------------------------------------------
+// Second form of the diagonal-block kernel: the same arithmetic per tile, decoupled waves.
+//
+// The block's chain is 8 tile factorisations of 16 dependent pivots each (wave 0); everything else -- the row panel
+// X = inv(L_d) S[o:o+16, o+16:] and the rank-16 update of the trailing tiles -- is throughput work.  In the first
+// form the four waves alternate between the two kinds of work with two barriers per tile, so the chain waits for
+// the row panel and the other waves wait for the chain.  Here wave 0 runs one step ahead and touches nothing the
+// other waves produce inside an interval:
+//   interval jb:  wave 0     X01 = inv(L_jb) S(jb, jb+1);  S(jb+1, jb+1) -= X01^T X01 (registers);  factor tile jb+1
+//                 waves 1-3  EACH forms the whole row panel X(jb, jb+1..8) in registers (no exchange between them),
+//                            then updates its share of the trailing tiles T(ti, tj) -= X_ti^T X_tj straight from
+//                            those registers (the f64 MFMA result map is both operand maps), and one of them writes
+//                            the finished factor rows to global memory
+//   ONE barrier per interval.  Solved rows never return to LDS (nobody reads them again), so no wave overwrites
+//   what another still reads; the diagonal-tile inverse is double-buffered (wave 0 writes tile jb+1's while the
+//   others read tile jb's).  The right-hand side rides along as column tile 8 (the 16 spare columns of the LDS row
+//   stride: column 128 = r, the rest zero), so z = L^-1 r needs no code of its own.
+struct Diag2Shared {
+    double S[128][kDiagLd];    // the block, upper triangle; columns 128..143: rhs tile (column 128) 
+    double Yt[2][16][16];      // inverse of the diagonal factor of tile jb in Yt[jb & 1]: Yt[k][i] = inv(L_d)[i][k]
+};
+
+// Register Cholesky of one 16x16 tile given in the MFMA accumulator layout (d[r] = D[kq + 4r][lc], anything below
+// the diagonal ignored); returns the factor in the same layout (zeros below the diagonal), writes the inverse to
+// LDS (transposed: the A-operand image of the row-panel product) and to global memory (what the strip TRSM reads).
+__device__ __forceinline__ d4 factor_tile_regs(d4 din, int lane, int pivot_row0, int *info, double (*Yt)[16],
+                                               double *__restrict__ invDt_tile)
+{
+    const int lc = lane & 15, kq = lane >> 4;
+    d4 d, e;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        d[r] = (kq + 4 * r <= lc) ? din[r] : 0.0;
+        e[r] = (kq + 4 * r == lc) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piv = 4 * b + j;
+            double pj = readlane_f64(d[b], 16 * j + piv);
+            if (!(pj > 0.0)) {
+                if (lane == 0) atomicCAS(info, 0, pivot_row0 + piv + 1);
+                pj = 1.0;
+            }
+            const double inv = rsqrt(pj);
+            const double dj = pj * inv;
+            const double scaled = (lc > piv) ? d[b] * inv : ((lc == piv) ? dj : 0.0);
+            if (kq == j) {
+                d[b] = scaled;
+                e[b] *= inv;
+            }
+            if (j < 3) {
+                const double ujc = __shfl(d[b], 16 * j + lc);
+                const double ejc = __shfl(e[b], 16 * j + lc);
+                const double ujr = __shfl(d[b], 16 * j + 4 * b + kq);
+                if (kq > j) {
+                    d[b] = fma(-ujr, ujc, d[b]);
+                    e[b] = fma(-ujr, ejc, e[b]);
+                }
+            }
+        }
+        if (b < 3) {
+            const d4 keep = d, keep_e = e;
+            const double na = -d[b];
+            d = MFMA_F64(na, d[b], d);
+            e = MFMA_F64(na, e[b], e);
+#pragma unroll
+            for (int r = 0; r <= b; ++r) { d[r] = keep[r]; e[r] = keep_e[r]; }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        Yt[lc][kq + 4 * r] = e[r];
+        invDt_tile[lc * 16 + kq + 4 * r] = e[r];
+    }
+    return d;
+}
+
+// The trailing tiles one of waves 1..3 owns: columns {8, 3, 2}, {7, 4, 1}, {6, 5} (12, 12 and 11 tiles, balanced for
+// every step since a column loses one tile per step), listed by row so that the tiles still due form a suffix.
+template <int W>
+struct DiagTiles;
+template <>
+struct DiagTiles<0> {
+    static constexpr int n = 12;
+    static constexpr int ti[12] = {1, 1, 1, 2, 2, 2, 3, 3, 4, 5, 6, 7};
+    static constexpr int tj[12] = {2, 3, 8, 2, 3, 8, 3, 8, 8, 8, 8, 8};
+};
+template <>
+struct DiagTiles<1> {
+    static constexpr int n = 12;
+    static constexpr int ti[12] = {1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 6, 7};
+    static constexpr int tj[12] = {1, 4, 7, 4, 7, 4, 7, 4, 7, 7, 7, 7};
+};
+template <>
+struct DiagTiles<2> {
+    static constexpr int n = 12;      // the last entry repeats a tile and is never written
+    static constexpr int ti[12] = {1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6};
+    static constexpr int tj[12] = {5, 6, 5, 6, 5, 6, 5, 6, 5, 6, 6, 6};
+};
+
+template <int W>
+__device__ __forceinline__ void diag_trailing(Diag2Shared &sh, const d4 (&x)[9], const d4 (&nx)[9], int jb, int lane)
+{
+    using L = DiagTiles<W>;
+    const int lc = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int g = 0; g < L::n; g += 4) {
+        // the group's last tile has the largest row index: nothing due in the group -> skip it (uniform)
+        if (L::ti[g + 3] <= jb) continue;
+        d4 acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[k][r] = sh.S[16 * L::ti[g + k] + kq + 4 * r][16 * L::tj[g + k] + lc];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = MFMA_F64(x[L::ti[g + k]][r], nx[L::tj[g + k]][r], acc[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ti = L::ti[g + k], tj = L::tj[g + k];
+            const bool dup = (W == 2 && g + k == 11);
+            if (!dup && ti > jb && !(ti == tj && ti == jb + 1)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sh.S[16 * ti + kq + 4 * r][16 * tj + lc] = acc[k][r];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void potrf_diag128_v2_kernel(double *A, int64_t lda, int r0, int rcol,
+                                                               double *__restrict__ invDt, int *info,
+                                                               double *__restrict__ zvec)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Diag2Shared &sh = *reinterpret_cast<Diag2Shared *>(smem_raw);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, kq = lane >> 4;
+
+    {
+        const unsigned s0 = lds_byte_address(&sh.S[0][0]);
+        const double *g = A + (int64_t)(r0 + wave * 32) * lda + r0 + lane * 2;
+#pragma unroll 8
+        for (int p = 0; p < 32; ++p)
+            glds16(g + (int64_t)p * lda, __builtin_amdgcn_readfirstlane(s0 + 8u * (unsigned)((wave * 32 + p) * kDiagLd)));
+    }
+    if (tid < 128) {
+        sh.S[tid][128] = A[(int64_t)(r0 + tid) * lda + rcol];
+#pragma unroll
+        for (int c = 129; c < kDiagLd; ++c) sh.S[tid][c] = 0.0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave == 0) {
+        d4 t0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t0[r] = sh.S[kq + 4 * r][lc];
+        const d4 u = factor_tile_regs(t0, lane, r0, info, sh.Yt[0], invDt + (int64_t)(r0 / 16) * 256);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A[(int64_t)(r0 + kq + 4 * r) * lda + r0 + lc] = u[r];
+    }
+    __syncthreads();
+
+    for (int jb = 0; jb < 8; ++jb) {
+        const int o = 16 * jb;
+        double af[4];                                       // A operand of the row-panel product: inv(L_jb)[lc][4 kk + kq]
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) af[kk] = sh.Yt[jb & 1][4 * kk + kq][lc];
+        if (wave == 0) {
+            if (jb < 7) {
+                d4 x = {0.0, 0.0, 0.0, 0.0}, acc;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) x = MFMA_F64(af[kk], sh.S[o + 4 * kk + kq][o + 16 + lc], x);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = sh.S[o + 16 + kq + 4 * r][o + 16 + lc];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = MFMA_F64(x[r], -x[r], acc);
+                const d4 u = factor_tile_regs(acc, lane, r0 + o + 16, info, sh.Yt[(jb + 1) & 1],
+                                              invDt + (int64_t)(r0 / 16 + jb + 1) * 256);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) A[(int64_t)(r0 + o + 16 + kq + 4 * r) * lda + r0 + o + 16 + lc] = u[r];
+            }
+        } else {
+            const int w = wave - 1;
+            // the whole row panel of this step, tiles 1 .. 8 (8 = right-hand side), in registers; tiles <= jb are
+            // finished rows whose results nobody uses (computed along when cheaper than branching around them).
+            // k-step outer, tile inner: eight independent accumulation chains keep the matrix pipe busy
+            d4 x[9], nx[9];
+            if (jb < 4) {
+                double bq[4][9];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int ct = 1; ct <= 8; ++ct) bq[kk][ct] = sh.S[o + 4 * kk + kq][16 * ct + lc];
+#pragma unroll
+                for (int ct = 1; ct <= 8; ++ct) x[ct] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int ct = 1; ct <= 8; ++ct) x[ct] = MFMA_F64(af[kk], bq[kk][ct], x[ct]);
+            } else {
+                double bq[4][9];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int ct = 5; ct <= 8; ++ct) bq[kk][ct] = sh.S[o + 4 * kk + kq][16 * ct + lc];
+#pragma unroll
+                for (int ct = 1; ct <= 8; ++ct) x[ct] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int ct = 5; ct <= 8; ++ct) x[ct] = MFMA_F64(af[kk], bq[kk][ct], x[ct]);
+            }
+#pragma unroll
+            for (int ct = 1; ct <= 8; ++ct) nx[ct] = -x[ct];
+            // rows o .. o+15 of the factor right of the diagonal tile, and z, leave for global memory
+            if (w == jb % 3) {
+#pragma unroll
+                for (int ct = 1; ct <= 7; ++ct) {
+                    if (ct > jb) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            A[(int64_t)(r0 + o + kq + 4 * r) * lda + r0 + 16 * ct + lc] = x[ct][r];
+                    }
+                }
+                if (lc == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = r0 + o + kq + 4 * r;
+                        A[(int64_t)row * lda + rcol] = x[8][r];
+                        if (zvec) zvec[row] = x[8][r];
+                    }
+                }
+            }
+            // trailing tiles T(ti, tj) -= X_ti^T X_tj, jb < ti <= 7, ti <= tj <= 8, except the next diagonal tile
+            // (wave 0's).  Ownership is by column (a compile-time list per wave), tiles go four at a time with their
+            // accumulation chains interleaved; a tile that is not due (ti <= jb) is computed on stale operands and
+            // simply not written back.
+            if (w == 0) diag_trailing<0>(sh, x, nx, jb, lane);
+            else if (w == 1) diag_trailing<1>(sh, x, nx, jb, lane);
+            else diag_trailing<2>(sh, x, nx, jb, lane);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row panel of the blocked factorisation, U[r0:r0+128, cols] = U_kk^-T A[r0:r0+128, cols]: the strip kernel's
+// arithmetic for ONE 128-row block (same 16x16 diagonal inverses, same tile order), without its three-deep staging
+// pipeline -- for 128 rows that pipeline is all prologue.  The whole diagonal block goes to LDS in one burst of
+// LDS-DMA, the strip's right-hand sides and the eight inverses go to registers, then the eight tile steps run
+// back to back: x_s = inv(L_ss) r_s (two half-sums), tile s+1 brought up to date first, and its own solve chain
+// interleaved with the rest of tile s's updates so that the matrix pipe never waits for a dependent result.
+// 64 columns per 256-thread workgroup, wave w owns 16 of them (no exchange between waves).
+struct PanelShared {
+    double U[128][kDiagLd];
+};
+
+__global__ __launch_bounds__(256) void panel_trsm_kernel(double *A, int64_t lda, int r0, int col0,
+                                                         const double *__restrict__ invDt)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    PanelShared &sh = *reinterpret_cast<PanelShared *>(smem_raw);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, kq = lane >> 4;
+    {
+        const unsigned s0 = lds_byte_address(&sh.U[0][0]);
+        const double *g = A + (int64_t)(r0 + wave * 32) * lda + r0 + lane * 2;
+#pragma unroll 8
+        for (int p = 0; p < 32; ++p)
+            glds16(g + (int64_t)p * lda, __builtin_amdgcn_readfirstlane(s0 + 8u * (unsigned)((wave * 32 + p) * kDiagLd)));
+    }
+    double *Ac = A + (int64_t)r0 * lda + col0 + (int64_t)blockIdx.x * kStrip + wave * 16 + lc;
+    d4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = Ac[(int64_t)(16 * t + kq + 4 * r) * lda];
+    double iv[8][4];
+    const double *inv = invDt + (int64_t)(r0 / 16) * 256 + kq * 16 + lc;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) iv[s][kk] = inv[s * 256 + 64 * kk];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const double *ub = &sh.U[kq][lc];                 // A operand of an update: U[16 s + 4 kk + kq][16 t + lc]
+    d4 x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
+    x = MFMA_F64(iv[0][0], acc[0][0], x);
+    x2 = MFMA_F64(iv[0][1], acc[0][1], x2);
+    x = MFMA_F64(iv[0][2], acc[0][2], x);
+    x2 = MFMA_F64(iv[0][3], acc[0][3], x2);
+    x += x2;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ac[(int64_t)(16 * s + kq + 4 * r) * lda] = x[r];
+        if (s == 7) break;
+        const d4 nx = -x;
+        // tile s+1 first (with tile s+2 in between: no MFMA waits on its predecessor) ...
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            acc[s + 1] = MFMA_F64(ub[(16 * s + 4 * kk) * kDiagLd + 16 * (s + 1)], nx[kk], acc[s + 1]);
+            if (s + 2 < 8) acc[s + 2] = MFMA_F64(ub[(16 * s + 4 * kk) * kDiagLd + 16 * (s + 2)], nx[kk], acc[s + 2]);
+        }
+        // ... then its solve chain, the remaining updates of tile s filling the gaps
+        d4 y1 = {0.0, 0.0, 0.0, 0.0}, y2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk & 1) y2 = MFMA_F64(iv[s + 1][kk], acc[s + 1][kk], y2);
+            else y1 = MFMA_F64(iv[s + 1][kk], acc[s + 1][kk], y1);
+#pragma unroll
+            for (int t = s + 3; t < 8; ++t) acc[t] = MFMA_F64(ub[(16 * s + 4 * kk) * kDiagLd + 16 * t], nx[kk], acc[t]);
+        }
+        x = y1 + y2;
+    }
+}
+
+void launch_panel_trsm(hipStream_t s, double *A, int64_t lda, int r0, int col0, int n_cols, const double *invDt)
+{
+    if (n_cols <= 0) return;
+    hipLaunchKernelGGL(panel_trsm_kernel, dim3((unsigned)(n_cols / kStrip)), dim3(256), sizeof(PanelShared), s, A, lda, r0,
+                       col0, invDt);
+}
+
+// ------------------------------------------------------------------------------------------------
 // SYRK: C[i][j] -= sum_k P[k][i] P[k][j] on the upper tiles of the trailing block, P = the panel rows
 // [r0, r0+n1).  TS x TS tile per workgroup, 2x2 waves, each wave (TS/2)^2 via 16x16x4 f64 MFMAs with
 // both operand fragments read straight from the panel rows (4 row segments of 128 B per load).
@@ -456,6 +789,21 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     // devices in one process are all covered)
     hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)sizeof(DiagShared));
+    hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag128_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)sizeof(Diag2Shared));
+    hipFuncSetAttribute(reinterpret_cast<const void *>(panel_trsm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)sizeof(PanelShared));
+    static const int panel_form = [] { const char *e = std::getenv("CBO_HIP_PANEL_FORM"); return e ? std::atoi(e) : 2; }();
+    static const int syrk_gemm_rows = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_ROWS"); return e ? std::atoi(e) : 6144; }();
+    static const int diag_form = [] { const char *e = std::getenv("CBO_HIP_DIAG_FORM"); return e ? std::atoi(e) : 2; }();
+    auto launch_diag = [&](int rr) {
+        if (diag_form == 1)
+            hipLaunchKernelGGL(potrf_diag128_kernel, dim3(1), dim3(256), sizeof(DiagShared), s, A, lda, rr, (int)n_pad, invDt,
+                               info_dev, 0, pipe ? pipe->zvec : nullptr);
+        else
+            hipLaunchKernelGGL(potrf_diag128_v2_kernel, dim3(1), dim3(256), sizeof(Diag2Shared), s, A, lda, rr, (int)n_pad,
+                               invDt, info_dev, pipe ? pipe->zvec : nullptr);
+    };
     hipMemsetAsync(info_dev, 0, sizeof(int), s);
     const int rcol = (int)n_pad;
 #ifdef CBO_DIAG_KNOBS
@@ -485,10 +833,11 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     int pending = -1;                      // event index of the bulk update still in flight
     for (int k = 0; k < np; k += 2) {
         const int r0 = 128 * k;
-        hipLaunchKernelGGL(potrf_diag128_kernel, dim3(1), dim3(256), sizeof(DiagShared), s, A, lda, r0, rcol, invDt,
-                           info_dev, dbg, zvec);
+        launch_diag(r0);
         const int n2 = (int)n_pad - r0 - 128;
         if (n2 <= 0) { sweep_rows(r0, 128); break; }
+        if (panel_form == 2 && !pipe) launch_panel_trsm(s, A, lda, r0, r0 + 128, n2, invDt);   // (beside a pipelined sweep: the half-LDS strip kernel)
+        else
         launch_trsm_strips(s, A + (int64_t)r0 * lda + r0, lda, invDt + (int64_t)(r0 / 16) * 256,
                            A + (int64_t)r0 * lda + r0 + 128, lda, 128, n2, nullptr, nullptr, nullptr, false, half_lds);
         // rows of the pair's second panel: K = 128 update with the first panel (after the previous bulk
@@ -496,10 +845,11 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         if (pending >= 0) { hipStreamWaitEvent(s, events[pending], 0); pending = -1; }
         launch_syrk(s, A, lda, r0, 128, n2, rcol, 0, 2);
         const int r1 = r0 + 128;
-        hipLaunchKernelGGL(potrf_diag128_kernel, dim3(1), dim3(256), sizeof(DiagShared), s, A, lda, r1, rcol, invDt,
-                           info_dev, dbg, zvec);
+        launch_diag(r1);
         const int n3 = (int)n_pad - r1 - 128;
         if (n3 <= 0) { sweep_rows(r0, 256); break; }
+        if (panel_form == 2 && !pipe) launch_panel_trsm(s, A, lda, r1, r1 + 128, n3, invDt);
+        else
         launch_trsm_strips(s, A + (int64_t)r1 * lda + r1, lda, invDt + (int64_t)(r1 / 16) * 256,
                            A + (int64_t)r1 * lda + r1 + 128, lda, 128, n3, nullptr, nullptr, nullptr, false, half_lds);
         sweep_rows(r0, 256);
@@ -508,7 +858,15 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         if (n3 > 128) {                                       // ... the rest on the side stream
             hipEventRecord(events[2 * k], s);
             hipStreamWaitEvent(side, events[2 * k], 0);
-            launch_syrk(side, A, lda, r0, 256, n3, rcol, 2, n3 / 64);
+            // the bulk of the trailing update.  Large trailing blocks go through the LDS-staged GEMM form of the
+            // sweep's update kernel (C -= P^T P on 64-column strips x 256-row chunks, upper part only, the rhs strip
+            // as one more strip): the 64x64-tile SYRK reads its operands as fragment-shaped loads from L2 and tops
+            // out near half the fp64 MFMA rate, which is what bounds the factorisation at 16384 points
+            if (n3 - 128 >= syrk_gemm_rows)
+                launch_gemm_update(side, A, lda, A, lda, A, lda, r0, 256, r0 + 256 + 128, (int)n_pad, n_pad + kRhsCols, 2,
+                                   true, true);
+            else
+                launch_syrk(side, A, lda, r0, 256, n3, rcol, 2, n3 / 64);
             hipEventRecord(events[2 * k + 1], side);
             pending = 2 * k + 1;
         }
