@@ -10,7 +10,8 @@ import numpy as np
 from .GaussianProcessFactory import GaussianProcessFactory as GPFactory
 from .graphs import meshgrid_candidates
 from .utils_functions.causal_acquisition_functions import CandidateGrid
-from .utils_functions.utils import default_grid_shape, find_current_global, find_next_y_point, space_bounds
+from .utils_functions.utils import (default_grid_shape, find_current_global, find_next_y_point, find_next_y_points,  # noqa: F401
+                                    space_bounds)
 
 
 class CBOAcquisitionPath:
@@ -33,6 +34,7 @@ class CBOAcquisitionPath:
         self.models = []
         self.last_intervention = None
         self._grids = {}          # per set: (grid shape, prior closures, device-resident candidate grid)
+        self._call_cache = {}     # handle arrays and batch costs of the multi-set sweep, valid while the objects are
         # keep L^-1 K* of every set's grid on the device: a trial then costs the set intervened on one forward
         # solve and one new row (append-only step) instead of a refit and a full sweep
         self.keep_solutions = bool(keep_solutions)
@@ -77,14 +79,10 @@ class CBOAcquisitionPath:
         return cached[1]
 
     def compute_best_acquisition_values(self, current_best):
-        """CBO.py:237-260."""
-        xs, ys = [], []
-        for s in range(len(self.exploration_set)):
-            y, x = find_next_y_point(self.space_list[s], self.models[s], current_best, self.exploration_set[s],
-                                     self.costs, task=self.task, candidates=self.candidate_grid(s))
-            ys.append(y)
-            xs.append(x)
-        return xs, ys
+        """CBO.py:237-260: the loop over the exploration sets, as ONE device call (``cbo_acq_sweep_sets``)."""
+        grids = [self.candidate_grid(s) for s in range(self.es_size)]
+        return find_next_y_points(self.models, current_best, self.exploration_set, self.costs, self.task, grids,
+                                  cache=self._call_cache)
 
     def current_best_solution(self, current_best_y):
         """CBO.py:262-267 (the monitor's ``current_best_y`` dict is passed in)."""

@@ -114,6 +114,12 @@ class HipGaussianProcess:
 
     stale = False      # data uploaded, posterior not yet refitted (set_data(..., fit=False))
 
+    @property
+    def small(self):
+        """At most 128 observations on the fp64 path: the multi-set sweep (``cbo_acq_sweep_sets``) factors and sweeps
+        such a model inside one launch, from its resident data, whether it is fitted or not."""
+        return self.dtype == "f64" and self.X.shape[0] <= 128
+
     def _note_jitter(self, tries, jitter):
         self.stale = False
         self.jitter_tries, self.jitter = tries, jitter
@@ -168,7 +174,9 @@ class HipGaussianProcess:
         ``fit=False`` uploads only and leaves the refit to the next use: an acquisition sweep then runs the
         refit and the sweep overlapped (``cbo_gp_fit_sweep``); any other consumer (predict, log_likelihood, ...)
         fits first.  A not-positive-definite error then surfaces at that use instead of here."""
-        if self._grew_by_one_row(X, Y) and self.append(np.asarray(X)[-1], np.asarray(Y).reshape(-1)[-1]):
+        # (a model of at most 128 observations is refactored inside every multi-set sweep anyway: no append there)
+        if not (self.dtype == "f64" and np.shape(X)[0] <= 128 and not fit) and self._grew_by_one_row(X, Y) \
+                and self.append(np.asarray(X)[-1], np.asarray(Y).reshape(-1)[-1]):
             return                                   # the factor grew by one column instead of being rebuilt
         self._set_arrays(X, Y)
         pm, pv = self._prior(self.X)

@@ -110,6 +110,8 @@ SIGNATURES = {
     "cbo_gp_fit_sweep": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_int,
                                         ctypes.c_double, ctypes.c_double, c_double_p, c_double_p, c_double_p,
                                         c_double_p, c_int64_p, c_int_p, c_double_p]),
+    "cbo_acq_sweep_sets": (ctypes.c_int, [ctypes.c_int, c_void_pp, c_void_pp, c_double_p, ctypes.c_int, ctypes.c_double,
+                                          c_double_p, c_double_p, c_int64_p]),
     "cbo_acq_sweep_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_double_p, c_double_p, c_double_p,
                                           ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                           c_double_p, c_double_p, c_int64_p]),

@@ -55,6 +55,8 @@ static void shutdown_all_at_exit()
             return fail(CBO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
     } while (0)
 
+constexpr size_t kStageBytes = 64 << 10;
+
 enum Phase { PH_KXX = 0, PH_CHOL, PH_ALPHA, PH_KSTAR, PH_TRSM, PH_ACQ, PH_CONVERT, PH_COUNT };
 
 struct EventPair {
@@ -77,6 +79,7 @@ struct cbo_ctx {
     double pipe_tail_frac = -1.0;    // CBO_HIP_PIPE_TAIL: rows (fraction) left to the closing left-looking launch; < 0 = automatic
     int n_cu = 256;
     bool sweep_cache = true;         // CBO_HIP_SWEEP_CACHE=0: never reuse a candidate set's q, mu between sweeps
+    bool small_sets = true;          // CBO_HIP_SMALL_SETS=0: cbo_acq_sweep_sets always takes the general path
     int sweep_mode = -1;             // CBO_HIP_SWEEP: 0 = always left-looking, 1 = always right-looking, else automatic
     int overlap_mode = -1;           // CBO_HIP_OVERLAP: 0 = cbo_gp_fit_sweep never overlaps, 1 = always, else automatic
     bool profiling = false;
@@ -89,11 +92,20 @@ struct cbo_ctx {
     double *W = nullptr; size_t W_bytes = 0;          // -Ky^-1 for the likelihood gradients
     double *gpart = nullptr; size_t gpart_elems = 0;
     double *mupart = nullptr; size_t mupart_elems = 0;   // fp32 sweep: per-row-tile partial sums of K*^T alpha
+    // multi-set sweep of small models (cbo_acq_sweep_sets): descriptors, per-workgroup scratch, partial and final winners
+    cbo_small_set *sets_host = nullptr; int sets_cap = 0;       // pinned, read by the kernel directly
+    cbo_small_result *small_out = nullptr;                      // pinned, written by the kernel directly
+    double *small_scratch = nullptr; size_t small_scratch_elems = 0;
+    double *small_part_val = nullptr; int64_t *small_part_idx = nullptr; size_t small_part_elems = 0;
+    int *small_info = nullptr;                                  // device, sets_cap status words (zero between calls)
     double *q = nullptr, *mu = nullptr, *mean = nullptr, *var = nullptr, *acq = nullptr; size_t vec_elems = 0;
     double *part_val = nullptr; int64_t *part_idx = nullptr;
     double *best_val = nullptr; int64_t *best_idx = nullptr;   // device
     double *h_best_val = nullptr; int64_t *h_best_idx = nullptr; // pinned host
     int *h_info = nullptr;
+    // small uploads (cbo_gp_upload_data / cbo_gp_set_data of a few KB, every trial of the reference's loop): one
+    // pinned staging buffer the preparation kernel reads directly; `stage_done` guards its reuse
+    double *stage = nullptr; hipEvent_t stage_done = nullptr; bool stage_pending = false;
     size_t max_ws_bytes = (size_t)32 << 30;   // V workspace cap: 288 GB of HBM per GPU, one chunk whenever possible
     char name[128] = {0};
 };
@@ -307,6 +319,8 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
     if (e == hipSuccess) e = hipHostMalloc(&c->h_best_val, sizeof(double));
     if (e == hipSuccess) e = hipHostMalloc(&c->h_best_idx, sizeof(int64_t));
     if (e == hipSuccess) e = hipHostMalloc(&c->h_info, sizeof(int));
+    if (e == hipSuccess) e = hipHostMalloc(&c->stage, kStageBytes);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->stage_done, hipEventDisableTiming);
     if (e != hipSuccess) {
         destroy_ctx(c);
         return fail(CBO_ERR_HIP, std::string("cbo_init: ") + hipGetErrorString(e));
@@ -320,6 +334,8 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
     if (sm) c->sweep_mode = std::atoi(sm);
     const char *sc = std::getenv("CBO_HIP_SWEEP_CACHE");
     if (sc && std::atoi(sc) == 0) c->sweep_cache = false;
+    const char *ss = std::getenv("CBO_HIP_SMALL_SETS");
+    if (ss && std::atoi(ss) == 0) c->small_sets = false;
     const char *om = std::getenv("CBO_HIP_OVERLAP");
     if (om) c->overlap_mode = std::atoi(om);
     const char *tf = std::getenv("CBO_HIP_PIPE_TAIL");
@@ -360,9 +376,12 @@ static void destroy_ctx(cbo_ctx *c)
     for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->pool) hipEventDestroy(e);
     hipFree(c->W); hipFree(c->gpart); hipFree(c->mupart);
+    hipHostFree(c->sets_host); hipHostFree(c->small_out); hipFree(c->small_scratch); hipFree(c->small_part_val);
+    hipFree(c->small_part_idx); hipFree(c->small_info);
     hipFree(c->V); hipFree(c->q); hipFree(c->mu); hipFree(c->mean); hipFree(c->var); hipFree(c->acq);
     hipFree(c->part_val); hipFree(c->part_idx); hipFree(c->best_val); hipFree(c->best_idx);
-    hipHostFree(c->h_best_val); hipHostFree(c->h_best_idx); hipHostFree(c->h_info);
+    hipHostFree(c->h_best_val); hipHostFree(c->h_best_idx); hipHostFree(c->h_info); hipHostFree(c->stage);
+    if (c->stage_done) hipEventDestroy(c->stage_done);
     for (auto e : c->chol_events) hipEventDestroy(e);
     for (auto e : c->pipe_events) hipEventDestroy(e);
     if (c->region_a) hipEventDestroy(c->region_a);
@@ -492,6 +511,27 @@ static int upload_gp_data(cbo_gp *g, int64_t n, const double *X, const double *y
     g->n = n;
     g->X.n = n; g->X.ld = n_pad; g->X.d = g->d;
     g->fitted = false;
+    const size_t stage_need = sizeof(double) * (size_t)(n * g->d + n + (pv ? 2 * n : 0));
+    if (stage_need <= kStageBytes) {
+        // small upload: host arrays -> pinned staging -> ONE kernel that reads the staging buffer itself.  The
+        // caller's buffers are free as soon as they are copied here; nothing to wait for on the stream.
+        if (c->stage_pending) { HIP_TRY(hipEventSynchronize(c->stage_done)); c->stage_pending = false; }
+        double *st = c->stage;
+        std::memcpy(st, X, sizeof(double) * n * g->d);
+        std::memcpy(st + n * g->d, y, sizeof(double) * n);
+        g->h_pv.clear();
+        if (pv) {
+            std::memcpy(st + n * g->d + n, pm, sizeof(double) * n);
+            std::memcpy(st + n * g->d + 2 * n, pv, sizeof(double) * n);
+            g->h_pv.assign(pv, pv + n);
+        }
+        launch_prep_points_staged(c->stream, st, n, g->d, g->h.ard ? g->ls_dev : nullptr, pv != nullptr, g->raw, g->y,
+                                  g->X.pm, g->X.pv, g->X.xs, n_pad, g->X.sq, g->X.sv);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->stage_done, c->stream));
+        c->stage_pending = true;
+        return CBO_OK;
+    }
     HIP_TRY(hipMemcpyAsync(g->raw, X, sizeof(double) * n * g->d, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(g->y, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     g->h_pv.clear();
@@ -1315,6 +1355,116 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
     if (jitter_out) *jitter_out = jitter;
     if (Vws != c->V) { k->v_stamp = g->fit_stamp; k->v_rows = g->n; }
     return finish_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
+}
+
+// ---- every exploration set of a trial in one call ------------------------------------------------------------------
+// CBO.compute_best_acquisition_values (/root/reference/src/CBO.py:237-260) loops find_next_y_point over the S
+// exploration sets.  Sets whose model has at most 128 observations -- every model the reference itself builds
+// (10 + <= 40 points, src/ArgumentParser.py:18,25) -- are swept by ONE launch that factors and sweeps inside LDS
+// (kernels_chol.hip, small_sets_kernel): no per-set launch chain, no per-set synchronisation, one copy back.  Such a
+// model need not be fitted: the launch works from its resident data (cbo_gp_upload_data is enough) and leaves its
+// fitted state alone.  A set whose factorisation meets a non-positive pivot there (jitchol's business), a larger
+// model, or an fp32 model takes the general path: cbo_gp_fit_sweep when the model is not fitted, cbo_acq_sweep
+// otherwise.
+static int ensure_small_buffers(cbo_ctx *c, int n_sets, int blocks)
+{
+    if (n_sets > c->sets_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipHostFree(c->sets_host); hipHostFree(c->small_out); hipFree(c->small_info);
+        c->sets_host = nullptr; c->small_out = nullptr; c->small_info = nullptr;
+        c->sets_cap = 0;
+        const int cap = n_sets < 32 ? 32 : n_sets;
+        HIP_TRY(hipHostMalloc(&c->sets_host, sizeof(cbo_small_set) * cap));
+        HIP_TRY(hipHostMalloc(&c->small_out, sizeof(cbo_small_result) * cap));
+        HIP_TRY(hipMalloc(&c->small_info, sizeof(int) * cap));
+        HIP_TRY(hipMemset(c->small_info, 0, sizeof(int) * cap));
+        c->sets_cap = cap;
+    }
+    const size_t scratch = small_sets_scratch_doubles(n_sets, blocks), parts = (size_t)n_sets * (size_t)blocks;
+    if (scratch > c->small_scratch_elems) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->small_scratch);
+        c->small_scratch = nullptr; c->small_scratch_elems = 0;
+        HIP_TRY(hipMalloc(&c->small_scratch, sizeof(double) * scratch));
+        c->small_scratch_elems = scratch;
+    }
+    if (parts > c->small_part_elems) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->small_part_val); hipFree(c->small_part_idx);
+        c->small_part_val = nullptr; c->small_part_idx = nullptr; c->small_part_elems = 0;
+        HIP_TRY(hipMalloc(&c->small_part_val, sizeof(double) * parts));
+        HIP_TRY(hipMalloc(&c->small_part_idx, sizeof(int64_t) * parts));
+        c->small_part_elems = parts;
+    }
+    return CBO_OK;
+}
+
+extern "C" int cbo_acq_sweep_sets(int n_sets, cbo_gp *const *gps, cbo_cands *const *cands, const double *y_best, int task,
+                                  double ei_jitter, const double *costs, double *best_vals, int64_t *best_idxs)
+{
+    if (n_sets <= 0 || !gps || !cands || !y_best || !costs || !best_vals || !best_idxs)
+        return fail(CBO_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n_sets; ++i) {
+        int rc = check_sweep_args(gps[i], cands[i], task);
+        if (rc != CBO_OK) return rc;
+        if (gps[i]->ctx != gps[0]->ctx) return fail(CBO_ERR_INVALID, "all sets must live on one context");
+        if (gps[i]->n <= 0 || gps[i]->n_pad <= 0) return fail(CBO_ERR_INVALID, "a gp holds no data");
+    }
+    cbo_ctx *c = gps[0]->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<int> small;
+    int blocks = 1;
+    for (int i = 0; i < n_sets; ++i) {
+        if (gps[i]->dtype == CBO_DTYPE_F64 && gps[i]->n_pad == kPadN && c->small_sets) {
+            small.push_back(i);
+            const int b = (int)((cands[i]->m + 63) / 64);
+            if (b > blocks) blocks = b;
+        }
+    }
+    std::vector<char> done((size_t)n_sets, 0);
+    if (!small.empty() && blocks <= 65535) {
+        int rc = ensure_small_buffers(c, (int)small.size(), blocks);
+        if (rc != CBO_OK) return rc;
+        for (size_t j = 0; j < small.size(); ++j) {
+            cbo_gp *g = gps[small[j]];
+            cbo_cands *k = cands[small[j]];
+            rc = prepare_cands(g, k);
+            if (rc != CBO_OK) return rc;
+            const bool causal = g->X.sv != nullptr;
+            cbo_small_set &st = c->sets_host[j];
+            st.xs = g->X.xs; st.sq = g->X.sq; st.sv = g->X.sv; st.pm = causal ? g->X.pm : nullptr; st.y = g->y;
+            st.cxs = k->P.xs; st.csq = k->P.sq; st.csv = causal ? k->P.sv : nullptr;
+            st.cpm = causal ? k->pm : nullptr; st.cpv = causal ? k->pv : nullptr;
+            st.ld = g->X.ld; st.cld = k->P.ld; st.m = k->m; st.index_offset = k->index_offset;
+            st.n = (int)g->n; st.d = g->d; st.zero_diag = g->h.zero_diag; st.task = task;
+            st.variance = g->h.variance; st.lengthscale = g->h.lengthscale; st.noise_var = g->noise_var;
+            st.diag_add = g->noise_var + kGpyDiagJitter; st.y_best = y_best[small[j]]; st.ei_jitter = ei_jitter;
+            st.cost = costs[small[j]];
+        }
+        const int ns = (int)small.size();
+        launch_small_sets(c->stream, c->sets_host, ns, blocks, c->small_scratch, c->small_part_val, c->small_part_idx,
+                          c->small_info, c->small_out);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int j = 0; j < ns; ++j) {
+            if (c->small_out[j].info != 0) continue;        // not positive definite as assembled: the jitchol ladder below
+            best_vals[small[(size_t)j]] = c->small_out[j].best_val;
+            best_idxs[small[(size_t)j]] = c->small_out[j].best_idx;
+            done[(size_t)small[(size_t)j]] = 1;
+        }
+    }
+    for (int i = 0; i < n_sets; ++i) {
+        if (done[(size_t)i]) continue;
+        int rc;
+        if (!gps[i]->fitted)
+            rc = cbo_gp_fit_sweep(gps[i], cands[i], y_best[i], task, ei_jitter, costs[i], nullptr, nullptr, nullptr,
+                                  &best_vals[i], &best_idxs[i], nullptr, nullptr);
+        else
+            rc = cbo_acq_sweep(gps[i], cands[i], y_best[i], task, ei_jitter, costs[i], nullptr, nullptr, nullptr,
+                               &best_vals[i], &best_idxs[i]);
+        if (rc != CBO_OK) return rc;
+    }
+    return CBO_OK;
 }
 
 extern "C" int cbo_acq_sweep_host(cbo_gp *g, int64_t m, const double *Xs, const double *pm, const double *pv,

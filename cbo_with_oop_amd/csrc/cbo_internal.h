@@ -81,6 +81,10 @@ struct KernelHyper {
 void launch_prep_points(hipStream_t s, const double *raw_aos, int64_t n, int d, const double *ls_dev /*d or null*/,
                         const double *pv_raw /*n or null*/, double *xs, int64_t ld, double *sq, double *sv);
 
+void launch_prep_points_staged(hipStream_t s, const double *stage, int64_t n, int d, const double *ls_dev, bool has_prior,
+                               double *raw, double *y, double *pm, double *pv, double *xs, int64_t ld, double *sq,
+                               double *sv);
+
 // K(X,X) + diag into the upper 64x64 tiles of A (identity on the padding), and the rhs strip.
 void launch_kxx(hipStream_t s, const PointSet &X, const KernelHyper &h, double diag_add, double jitter,
                 double *A, int64_t lda, int64_t n_pad);
@@ -160,6 +164,27 @@ void launch_trsm_update(hipStream_t s, const double *U, int64_t ldu, double *V, 
 void launch_gemm_update(hipStream_t s, const double *U, int64_t ldu, const double *V, int64_t ldv, double *C,
                         int64_t ldc, int k0, int klen, int i0_begin, int i0_end, int64_t m_pad, int chunk_blocks,
                         bool half_lds, bool upper_only);
+
+// One (model, candidate set) pair of a multi-set sweep of small models (kernels_chol.hip, small_sets_kernel): every
+// pointer is device memory; filled on the host per call and uploaded as an array.
+struct cbo_small_set {
+    const double *xs, *sq, *sv, *pm, *y;               // model: SoA points (ld), |x|^2, sqrt(v) or null, m(X) or null, targets
+    const double *cxs, *csq, *csv, *cpm, *cpv;         // candidates (scaled SoA, ld = cld), prior closures at them or null
+    int64_t ld, cld, m, index_offset;
+    int n, d, zero_diag, task;
+    double variance, lengthscale, noise_var, diag_add, y_best, ei_jitter, cost;
+};
+struct cbo_small_result {
+    double best_val;
+    int64_t best_idx;
+    int info, pad;                                     // first non-positive pivot (1-based) or 0
+};
+size_t small_sets_scratch_doubles(int n_sets, int blocks_per_set);
+// sets / out may be pinned host memory (device-mapped): the kernels then read the descriptors and write the results
+// across the host link themselves and the call needs no copy operation; info (device, n_sets ints) must be zero on
+// entry and is zero again afterwards
+void launch_small_sets(hipStream_t s, const cbo_small_set *sets, int n_sets, int blocks_per_set, double *scratch,
+                       double *part_val, int64_t *part_idx, int *info, cbo_small_result *out);
 
 struct AcqParams {
     double variance, noise_var, y_best, ei_jitter, cost;

@@ -10,47 +10,11 @@
 //   numpy.argmax)                             /root/reference/src/utils_functions/causal_optimizer.py:52-55
 // HBM-bound and tiny next to the TRSM: 2-4 doubles in, up to 3 out per candidate.  The arg-max is a
 // wavefront shuffle reduction, one partial per workgroup, then one 256-thread finishing block.
-#include "cbo_internal.h"
+#include "cbo_device.h"
 
 #pragma clang fp contract(off)
 
 namespace cbo {
-
-// scipy.special.ndtr (cephes ndtr.c): 0.5 erfc(-x/sqrt2) split at |x/sqrt2| < sqrt(1/2).
-__device__ __forceinline__ double ndtr(double a)
-{
-    const double SQRTH = 7.07106781186547524401E-1;
-    if (isnan(a)) return a;
-    const double x = a * SQRTH;
-    const double zabs = fabs(x);
-    double y;
-    if (zabs < SQRTH) {
-        y = 0.5 + 0.5 * erf(x);
-    } else {
-        y = 0.5 * erfc(zabs);
-        if (x > 0) y = 1.0 - y;
-    }
-    return y;
-}
-
-__device__ __forceinline__ bool better(double va, int64_t ia, double vb, int64_t ib)
-{
-    // true when (va, ia) beats (vb, ib): larger value, NaN maximal, lowest index on ties
-    const bool na = isnan(va), nb = isnan(vb);
-    if (na != nb) return na;
-    if (na || va == vb) return ia < ib;
-    return va > vb;
-}
-
-__device__ __forceinline__ void wave_argmax(double &v, int64_t &i)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_down(v, off);
-        const int64_t oi = __shfl_down(i, off);
-        if (better(ov, oi, v, i)) { v = ov; i = oi; }
-    }
-}
 
 __device__ __forceinline__ void block_argmax(double v, int64_t i, double *out_v, int64_t *out_i)
 {
@@ -82,23 +46,12 @@ __global__ __launch_bounds__(256) void acq_kernel(const double *__restrict__ q, 
     double bv = -INFINITY;
     int64_t bi = kNoIndex;
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < m; c += (int64_t)gridDim.x * blockDim.x) {
-        const double kss = pv ? (p.variance + pv[c]) : p.variance;     // Kdiag
-        double var = kss - q[c];
-        var = (var < kGpyVarClip) ? kGpyVarClip : var;                  // np.clip(var, 1e-15, inf); NaN stays NaN
-        if (p.include_noise) var = var + p.noise_var;                   // Gaussian likelihood predictive_values
-        double mean = mu[c];
-        if (pm) mean = mean + pm[c];                                    // GP._raw_predict: mu += mean_function.f(Xnew)
+        double mean, var;
+        posterior_of(q[c], mu[c], pm ? pm[c] : 0.0, pv ? pv[c] : 0.0, pv != nullptr, p, mean, var);
         if (mean_out) mean_out[c] = mean;
         if (var_out) var_out[c] = var;
         if (p.want_ei) {
-            const double s = sqrt(var);
-            const double mj = mean + p.ei_jitter;
-            const double u = (p.y_best - mj) / s;
-            const double pdf = exp(-(u * u) / 2.0) / 2.5066282746310002;   // scipy _norm_pdf: exp(-x**2/2)/sqrt(2 pi)
-            const double cdf = ndtr(u);
-            double imp = s * (u * cdf + pdf);
-            if (p.task != CBO_TASK_MIN) imp = -imp;
-            const double acq = imp / p.cost;
+            const double acq = acquisition_of(mean, var, p);
             if (acq_out) acq_out[c] = acq;
             const int64_t gi = c + index_offset;
             if (better(acq, gi, bv, bi)) { bv = acq; bi = gi; }

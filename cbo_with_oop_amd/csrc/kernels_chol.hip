@@ -19,7 +19,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "cbo_internal.h"
+#include "cbo_device.h"
 
 namespace cbo {
 
@@ -378,31 +378,17 @@ __device__ __forceinline__ void diag_trailing(Diag2Shared &sh, const d4 (&x)[9],
     }
 }
 
-__global__ __launch_bounds__(256) void potrf_diag128_v2_kernel(double *A, int64_t lda, int r0, int rcol,
-                                                               double *__restrict__ invDt, int *info,
-                                                               double *__restrict__ zvec)
+// The factorisation of a block that is already in LDS (S: upper triangle + rhs tile; the caller has synchronised).
+// `tiles` = 16-row tiles to factor (8 = the whole block; fewer when the rest is identity padding, which the caller
+// then writes out itself).  Factor rows, diagonal inverses and z go to global memory (A, invDt, zvec).
+__device__ __forceinline__ void diag128_factor_in_lds(Diag2Shared &sh, double *A, int64_t lda, int r0, int rcol,
+                                                      double *__restrict__ invDt, int *info,
+                                                      double *__restrict__ zvec, int tiles)
 {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    Diag2Shared &sh = *reinterpret_cast<Diag2Shared *>(smem_raw);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lc = lane & 15, kq = lane >> 4;
-
-    {
-        const unsigned s0 = lds_byte_address(&sh.S[0][0]);
-        const double *g = A + (int64_t)(r0 + wave * 32) * lda + r0 + lane * 2;
-#pragma unroll 8
-        for (int p = 0; p < 32; ++p)
-            glds16(g + (int64_t)p * lda, __builtin_amdgcn_readfirstlane(s0 + 8u * (unsigned)((wave * 32 + p) * kDiagLd)));
-    }
-    if (tid < 128) {
-        sh.S[tid][128] = A[(int64_t)(r0 + tid) * lda + rcol];
-#pragma unroll
-        for (int c = 129; c < kDiagLd; ++c) sh.S[tid][c] = 0.0;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
     if (wave == 0) {
         d4 t0;
 #pragma unroll
@@ -413,13 +399,13 @@ __global__ __launch_bounds__(256) void potrf_diag128_v2_kernel(double *A, int64_
     }
     __syncthreads();
 
-    for (int jb = 0; jb < 8; ++jb) {
+    for (int jb = 0; jb < tiles; ++jb) {
         const int o = 16 * jb;
         double af[4];                                       // A operand of the row-panel product: inv(L_jb)[lc][4 kk + kq]
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) af[kk] = sh.Yt[jb & 1][4 * kk + kq][lc];
         if (wave == 0) {
-            if (jb < 7) {
+            if (jb + 1 < tiles) {
                 d4 x = {0.0, 0.0, 0.0, 0.0}, acc;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) x = MFMA_F64(af[kk], sh.S[o + 4 * kk + kq][o + 16 + lc], x);
@@ -496,6 +482,32 @@ __global__ __launch_bounds__(256) void potrf_diag128_v2_kernel(double *A, int64_
     }
 }
 
+__global__ __launch_bounds__(256) void potrf_diag128_v2_kernel(double *A, int64_t lda, int r0, int rcol,
+                                                               double *__restrict__ invDt, int *info,
+                                                               double *__restrict__ zvec)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Diag2Shared &sh = *reinterpret_cast<Diag2Shared *>(smem_raw);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        const unsigned s0 = lds_byte_address(&sh.S[0][0]);
+        const double *g = A + (int64_t)(r0 + wave * 32) * lda + r0 + lane * 2;
+#pragma unroll 8
+        for (int p = 0; p < 32; ++p)
+            glds16(g + (int64_t)p * lda, __builtin_amdgcn_readfirstlane(s0 + 8u * (unsigned)((wave * 32 + p) * kDiagLd)));
+    }
+    if (tid < 128) {
+        sh.S[tid][128] = A[(int64_t)(r0 + tid) * lda + rcol];
+#pragma unroll
+        for (int c = 129; c < kDiagLd; ++c) sh.S[tid][c] = 0.0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    diag128_factor_in_lds(sh, A, lda, r0, rcol, invDt, info, zvec, 8);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Row panel of the blocked factorisation, U[r0:r0+128, cols] = U_kk^-T A[r0:r0+128, cols]: the strip kernel's
 // arithmetic for ONE 128-row block (same 16x16 diagonal inverses, same tile order), without its three-deep staging
@@ -507,6 +519,43 @@ __global__ __launch_bounds__(256) void potrf_diag128_v2_kernel(double *A, int64_
 struct PanelShared {
     double U[128][kDiagLd];
 };
+
+// The eight (or `tiles`) tile steps of a 128-row block solve for one wave's 16 columns: acc[t] = right-hand sides of
+// tile t in the MFMA result layout, iv = the diagonal inverses as A operands, ub = &U[kq][lc] of the block in LDS;
+// emit(s, x) receives tile s of the solution.  x_s = inv(L_ss) r_s (two half-sums), tile s+1 brought up to date first,
+// its solve chain interleaved with the rest of tile s's updates.
+template <typename Emit>
+__device__ __forceinline__ void panel_solve_tiles(const double *ub, d4 (&acc)[8], const double (&iv)[8][4], int tiles,
+                                                  Emit emit)
+{
+    d4 x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
+    x = MFMA_F64(iv[0][0], acc[0][0], x);
+    x2 = MFMA_F64(iv[0][1], acc[0][1], x2);
+    x = MFMA_F64(iv[0][2], acc[0][2], x);
+    x2 = MFMA_F64(iv[0][3], acc[0][3], x2);
+    x += x2;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        emit(s, x);
+        if (s == 7 || s + 1 >= tiles) break;
+        const d4 nx = -x;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            acc[s + 1] = MFMA_F64(ub[(16 * s + 4 * kk) * kDiagLd + 16 * (s + 1)], nx[kk], acc[s + 1]);
+            if (s + 2 < 8) acc[s + 2] = MFMA_F64(ub[(16 * s + 4 * kk) * kDiagLd + 16 * (s + 2)], nx[kk], acc[s + 2]);
+        }
+        d4 y1 = {0.0, 0.0, 0.0, 0.0}, y2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk & 1) y2 = MFMA_F64(iv[s + 1][kk], acc[s + 1][kk], y2);
+            else y1 = MFMA_F64(iv[s + 1][kk], acc[s + 1][kk], y1);
+#pragma unroll
+            for (int t = s + 3; t < 8; ++t) acc[t] = MFMA_F64(ub[(16 * s + 4 * kk) * kDiagLd + 16 * t], nx[kk], acc[t]);
+        }
+        x = y1 + y2;
+    }
+}
+
 
 __global__ __launch_bounds__(256) void panel_trsm_kernel(double *A, int64_t lda, int r0, int col0,
                                                          const double *__restrict__ invDt)
@@ -539,36 +588,10 @@ __global__ __launch_bounds__(256) void panel_trsm_kernel(double *A, int64_t lda,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const double *ub = &sh.U[kq][lc];                 // A operand of an update: U[16 s + 4 kk + kq][16 t + lc]
-    d4 x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
-    x = MFMA_F64(iv[0][0], acc[0][0], x);
-    x2 = MFMA_F64(iv[0][1], acc[0][1], x2);
-    x = MFMA_F64(iv[0][2], acc[0][2], x);
-    x2 = MFMA_F64(iv[0][3], acc[0][3], x2);
-    x += x2;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    panel_solve_tiles(&sh.U[kq][lc], acc, iv, 8, [&](int s, const d4 &x) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) Ac[(int64_t)(16 * s + kq + 4 * r) * lda] = x[r];
-        if (s == 7) break;
-        const d4 nx = -x;
-        // tile s+1 first (with tile s+2 in between: no MFMA waits on its predecessor) ...
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            acc[s + 1] = MFMA_F64(ub[(16 * s + 4 * kk) * kDiagLd + 16 * (s + 1)], nx[kk], acc[s + 1]);
-            if (s + 2 < 8) acc[s + 2] = MFMA_F64(ub[(16 * s + 4 * kk) * kDiagLd + 16 * (s + 2)], nx[kk], acc[s + 2]);
-        }
-        // ... then its solve chain, the remaining updates of tile s filling the gaps
-        d4 y1 = {0.0, 0.0, 0.0, 0.0}, y2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if (kk & 1) y2 = MFMA_F64(iv[s + 1][kk], acc[s + 1][kk], y2);
-            else y1 = MFMA_F64(iv[s + 1][kk], acc[s + 1][kk], y1);
-#pragma unroll
-            for (int t = s + 3; t < 8; ++t) acc[t] = MFMA_F64(ub[(16 * s + 4 * kk) * kDiagLd + 16 * t], nx[kk], acc[t]);
-        }
-        x = y1 + y2;
-    }
+    });
 }
 
 void launch_panel_trsm(hipStream_t s, double *A, int64_t lda, int r0, int col0, int n_cols, const double *invDt)
@@ -576,6 +599,249 @@ void launch_panel_trsm(hipStream_t s, double *A, int64_t lda, int r0, int col0, 
     if (n_cols <= 0) return;
     hipLaunchKernelGGL(panel_trsm_kernel, dim3((unsigned)(n_cols / kStrip)), dim3(256), sizeof(PanelShared), s, A, lda, r0,
                        col0, invDt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small models, many sets, ONE launch (the reference's own operating point: N = 10..50 observations per exploration
+// set, S = 2..25 sets, /root/reference/src/ArgumentParser.py:18,25, src/CBO.py:237-260).  At that size every kernel of
+// the general path is launch latency: K(X,X), eight chain launches, K*, the strip solve, the epilogue, a stream
+// synchronisation -- per set.  Here one workgroup does all of it for (one set, 64 candidates) inside LDS and
+// registers, with the SAME device functions as the general path (kernel_value, the decoupled-wave block
+// factorisation, the tile solve, the EI epilogue), so the numbers are the general path's numbers:
+//   K(X,X) + diag  ->  LDS block (identity beyond n)       rhs r = y - m(X)  ->  column tile 8
+//   factorisation of the ceil(n/16) tiles that are not padding  (factor rows, inverses, z to a per-workgroup scratch)
+//   K(X, X*) of the workgroup's 64 candidates straight into the MFMA result registers
+//   V = L^-1 K*,  q = sum V^2,  mu = V^T z,  variance, mean, EI / cost, arg-max over the 64 candidates
+// A second, tiny launch reduces the per-workgroup winners of every set.  Every workgroup of a set repeats the
+// set's factorisation (no inter-workgroup dependency; it is a few microseconds).
+struct SmallShared {
+    Diag2Shared blk;           // Ky / factor workspace, later the factor itself for the solve
+    double xs[CBO_MAX_DIM][128];
+    double sq[128], sv[128];
+};
+static_assert(sizeof(SmallShared) <= 163840, "one workgroup per CU");
+
+constexpr int kSmallLd = kDiagLd;                              // scratch factor rows: [128][144], z in column 128
+constexpr int kSmallScratch = 128 * kSmallLd + 8 * 256;        // doubles per workgroup: factor rows + inverses
+
+template <int D>
+__device__ __forceinline__ void small_assemble(SmallShared &sh, const cbo_small_set &st, int tiles)
+{
+    const int tid = threadIdx.x;
+    const int i = tid >> 4, j = tid & 15;
+    const double inv_l2 = 1.0 / (st.lengthscale * st.lengthscale);
+    const bool causal = st.sv != nullptr;
+    for (int ti = 0; ti < tiles; ++ti)
+        for (int tj = ti; tj < tiles; ++tj) {
+            const int gi = 16 * ti + i, gj = 16 * tj + j;
+            double v;
+            if (gi < st.n && gj < st.n) {
+                double xi[D], xj[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) { xi[k] = sh.xs[k][gi]; xj[k] = sh.xs[k][gj]; }
+                v = kernel_value<D>(xi, xj, sh.sq[gi], sh.sq[gj], st.variance, inv_l2, st.zero_diag && gi == gj);
+                if (causal) v = __dadd_rn(v, __dmul_rn(sh.sv[gi], sh.sv[gj]));
+                if (gi == gj) v = __dadd_rn(v, st.diag_add);           // Ky = K + (noise + 1e-8) I
+            } else {
+                v = (gi == gj) ? 1.0 : 0.0;                            // identity padding
+            }
+            sh.blk.S[gi][gj] = v;
+        }
+}
+
+template <int D>
+__device__ __forceinline__ double small_kstar(const SmallShared &sh, const cbo_small_set &st, int row, const double *xc,
+                                              double csq, double csv, double inv_l2)
+{
+    if (row >= st.n) return 0.0;
+    double xi[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) xi[k] = sh.xs[k][row];
+    double v = kernel_value<D>(xi, xc, sh.sq[row], csq, st.variance, inv_l2, false);
+    if (st.sv != nullptr) v = __dadd_rn(v, __dmul_rn(sh.sv[row], csv));
+    return v;
+}
+
+template <int D>
+__device__ __forceinline__ void small_kstar_tiles(const SmallShared &sh, const cbo_small_set &st, int tiles,
+                                                  const double *xc, double csq, double csv, double inv_l2, int kq,
+                                                  d4 (&acc)[8])
+{
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[t][r] = (t < tiles) ? small_kstar<D>(sh, st, 16 * t + kq + 4 * r, xc, csq, csv, inv_l2) : 0.0;
+}
+
+__global__ __launch_bounds__(256) void small_sets_kernel(const cbo_small_set *__restrict__ sets, double *scratch,
+                                                         int blocks_per_set, double *__restrict__ part_val,
+                                                         int64_t *__restrict__ part_idx, int *__restrict__ info)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    SmallShared &sh = *reinterpret_cast<SmallShared *>(smem_raw);
+    const int set = blockIdx.y, blk = blockIdx.x;
+    const cbo_small_set st = sets[set];
+    const int slot = set * blocks_per_set + blk;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, kq = lane >> 4;
+    if ((int64_t)blk * 64 >= st.m) {                              // no candidates left for this workgroup
+        if (tid == 0) { part_val[slot] = -INFINITY; part_idx[slot] = INT64_MAX; }
+        return;
+    }
+    const int tiles = (st.n + 15) / 16;
+    double *my = scratch + (int64_t)slot * kSmallScratch;
+    double *Us = my, *invs = my + 128 * kSmallLd;
+
+    // ---- the model's points and K(X,X) + diag, rhs, zero fill of what the factorisation reads beyond the tiles
+    if (tid < 128) {
+        const bool in = tid < st.n;
+        for (int k = 0; k < st.d; ++k) sh.xs[k][tid] = in ? st.xs[(int64_t)k * st.ld + tid] : 0.0;
+        sh.sq[tid] = in ? st.sq[tid] : 0.0;
+        sh.sv[tid] = (in && st.sv) ? st.sv[tid] : 0.0;
+    }
+    __syncthreads();
+    switch (st.d) {
+        case 1: small_assemble<1>(sh, st, tiles); break;
+        case 2: small_assemble<2>(sh, st, tiles); break;
+        case 3: small_assemble<3>(sh, st, tiles); break;
+        case 4: small_assemble<4>(sh, st, tiles); break;
+        case 5: small_assemble<5>(sh, st, tiles); break;
+        case 6: small_assemble<6>(sh, st, tiles); break;
+        case 7: small_assemble<7>(sh, st, tiles); break;
+        default: small_assemble<8>(sh, st, tiles); break;
+    }
+    {
+        const int rows = 16 * tiles;
+        for (int idx = tid; idx < rows * (kDiagLd - rows); idx += 256) {
+            const int r = idx / (kDiagLd - rows), c = rows + idx % (kDiagLd - rows);
+            double v = 0.0;
+            if (c == 128 && r < st.n) v = st.pm ? __dadd_rn(st.y[r], -st.pm[r]) : st.y[r];   // r = y - m(X)
+            sh.blk.S[r][c] = v;
+        }
+    }
+    __syncthreads();
+    diag128_factor_in_lds(sh.blk, Us, kSmallLd, 0, 128, invs, &info[set], nullptr, tiles);
+    // (ends with a barrier.)  Every wave's stores of factor rows / inverses / z are complete before anyone re-reads them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- the factor back into LDS (rows of the factored tiles; the solve reads nothing else), inverses and z to registers
+    {
+        const unsigned s0 = lds_byte_address(&sh.blk.S[0][0]);
+        const int rows = 16 * tiles;
+        for (int p = wave; p < rows; p += 4)
+            glds16(Us + (int64_t)p * kSmallLd + lane * 2, __builtin_amdgcn_readfirstlane(s0 + 8u * (unsigned)(p * kDiagLd)));
+    }
+    double iv[8][4], zr[8][4];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            iv[s][kk] = (s < tiles) ? invs[s * 256 + (4 * kk + kq) * 16 + lc] : 0.0;
+            zr[s][kk] = (s < tiles) ? Us[(int64_t)(16 * s + kq + 4 * kk) * kSmallLd + 128] : 0.0;
+        }
+    // ---- K(X, X*) of this wave's 16 candidates, straight into the result layout
+    const int64_t c = (int64_t)blk * 64 + wave * 16 + lc;
+    const int64_t cc = (c < st.m) ? c : st.m - 1;                  // clamped: lanes beyond the set compute, nobody looks
+    double xc[CBO_MAX_DIM];
+#pragma unroll
+    for (int k = 0; k < CBO_MAX_DIM; ++k) xc[k] = (k < st.d) ? st.cxs[(int64_t)k * st.cld + cc] : 0.0;
+    const double csq = st.csq[cc], csv = st.csv ? st.csv[cc] : 0.0;
+    const double inv_l2 = 1.0 / (st.lengthscale * st.lengthscale);
+    d4 acc[8];
+    switch (st.d) {
+        case 1: small_kstar_tiles<1>(sh, st, tiles, xc, csq, csv, inv_l2, kq, acc); break;
+        case 2: small_kstar_tiles<2>(sh, st, tiles, xc, csq, csv, inv_l2, kq, acc); break;
+        case 3: small_kstar_tiles<3>(sh, st, tiles, xc, csq, csv, inv_l2, kq, acc); break;
+        case 4: small_kstar_tiles<4>(sh, st, tiles, xc, csq, csv, inv_l2, kq, acc); break;
+        case 5: small_kstar_tiles<5>(sh, st, tiles, xc, csq, csv, inv_l2, kq, acc); break;
+        case 6: small_kstar_tiles<6>(sh, st, tiles, xc, csq, csv, inv_l2, kq, acc); break;
+        case 7: small_kstar_tiles<7>(sh, st, tiles, xc, csq, csv, inv_l2, kq, acc); break;
+        default: small_kstar_tiles<8>(sh, st, tiles, xc, csq, csv, inv_l2, kq, acc); break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- V = L^-1 K*, q = sum V^2, mu = V^T z (lane partials, then over the four lane groups: the strip kernel's order)
+    double qacc = 0.0, macc = 0.0;
+    panel_solve_tiles(&sh.blk.S[kq][lc], acc, iv, tiles, [&](int s, const d4 &x) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            qacc = fma(x[r], x[r], qacc);
+            macc = fma(x[r], zr[s][r], macc);
+        }
+    });
+    qacc += __shfl_xor(qacc, 16);
+    qacc += __shfl_xor(qacc, 32);
+    macc += __shfl_xor(macc, 16);
+    macc += __shfl_xor(macc, 32);
+
+    // ---- epilogue and the workgroup's arg-max
+    AcqParams p;
+    p.variance = st.variance; p.noise_var = st.noise_var; p.y_best = st.y_best; p.ei_jitter = st.ei_jitter;
+    p.cost = st.cost; p.task = st.task; p.include_noise = 1; p.want_ei = 1;
+    double bv = -INFINITY;
+    int64_t bi = INT64_MAX;
+    if (kq == 0 && c < st.m) {
+        double mean, var;
+        posterior_of(qacc, macc, st.cpm ? st.cpm[c] : 0.0, st.cpv ? st.cpv[c] : 0.0, st.sv != nullptr, p, mean, var);
+        bv = acquisition_of(mean, var, p);
+        bi = c + st.index_offset;
+    }
+    wave_argmax(bv, bi);
+    double *red_v = &sh.sq[0];                         // free by now
+    int64_t *red_i = reinterpret_cast<int64_t *>(&sh.sv[0]);
+    __syncthreads();
+    if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (better(red_v[w], red_i[w], bv, bi)) { bv = red_v[w]; bi = red_i[w]; }
+        part_val[slot] = bv;
+        part_idx[slot] = bi;
+    }
+}
+
+// per set: reduce the workgroups' winners, hand the result record to the host (pinned, device-mapped memory: no copy
+// operation on the stream), and re-arm the set's status word for the next call
+__global__ void small_sets_final_kernel(const double *__restrict__ part_val, const int64_t *__restrict__ part_idx,
+                                        int blocks_per_set, int *__restrict__ info, cbo_small_result *__restrict__ out)
+{
+    const int set = blockIdx.x;
+    double bv = -INFINITY;
+    int64_t bi = INT64_MAX;
+    for (int b = threadIdx.x; b < blocks_per_set; b += 64)
+        if (better(part_val[set * blocks_per_set + b], part_idx[set * blocks_per_set + b], bv, bi)) {
+            bv = part_val[set * blocks_per_set + b];
+            bi = part_idx[set * blocks_per_set + b];
+        }
+    wave_argmax(bv, bi);
+    if (threadIdx.x == 0) {
+        out[set].best_val = bv;
+        out[set].best_idx = bi;
+        out[set].info = info[set];
+        info[set] = 0;
+    }
+}
+
+size_t small_sets_scratch_doubles(int n_sets, int blocks_per_set) { return (size_t)n_sets * blocks_per_set * kSmallScratch; }
+
+void launch_small_sets(hipStream_t s, const cbo_small_set *sets, int n_sets, int blocks_per_set, double *scratch,
+                       double *part_val, int64_t *part_idx, int *info, cbo_small_result *out)
+{
+    static bool once = [] {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(small_sets_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(SmallShared));
+        return true;
+    }();
+    (void)once;
+    hipLaunchKernelGGL(small_sets_kernel, dim3((unsigned)blocks_per_set, (unsigned)n_sets), dim3(256), sizeof(SmallShared), s,
+                       sets, scratch, blocks_per_set, part_val, part_idx, info);
+    hipLaunchKernelGGL(small_sets_final_kernel, dim3((unsigned)n_sets), dim3(64), 0, s, part_val, part_idx, blocks_per_set,
+                       info, out);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@
 // staged in LDS, 16-byte coalesced stores (each wave writes 2 rows x 512 B per instruction).
 // Measured (scripts/kxx_roofline.py): 16384 points, d=3 -> 1.08 GB of upper tiles in 0.22 ms = 4.9 TB/s
 // (61 % of the 8 TB/s HBM peak); at 4096 points the 34 us launch is ramp/tail dominated (2.0 TB/s).
-#include "cbo_internal.h"
+#include "cbo_device.h"
 
 #pragma clang fp contract(off)
 
@@ -61,6 +61,66 @@ __global__ __launch_bounds__(256) void prep_points_kernel(const double *__restri
     if (sv) sv[i] = (i < n && pv) ? sqrt(pv[i]) : 0.0;
 }
 
+// The same preparation for a small point set whose host arrays sit in ONE pinned (device-mapped) staging buffer
+// [X (n,d) | y (n) | prior mean (n) | prior variance (n)]: the kernel reads them across the host link itself and
+// also fills the resident device copies (raw AoS, y, prior) -- one launch, no copy operation, nothing to wait for.
+__global__ __launch_bounds__(256) void prep_points_staged_kernel(const double *__restrict__ stage, int64_t n, int d,
+                                                                 const double *__restrict__ ls, int has_prior,
+                                                                 double *__restrict__ raw, double *__restrict__ y,
+                                                                 double *__restrict__ pm, double *__restrict__ pv,
+                                                                 double *__restrict__ xs, int64_t ld,
+                                                                 double *__restrict__ sq, double *__restrict__ sv)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ld) return;
+    double x[CBO_MAX_DIM];
+#pragma unroll
+    for (int k = 0; k < CBO_MAX_DIM; ++k) x[k] = 0.0;
+    double pvi = 0.0;
+    if (i < n) {
+#pragma unroll
+        for (int k = 0; k < CBO_MAX_DIM; ++k)
+            if (k < d) {
+                double v = stage[i * d + k];
+                raw[i * d + k] = v;
+                if (ls) v = v / ls[k];
+                x[k] = v;
+            }
+        y[i] = stage[n * d + i];
+        if (has_prior) {
+            pm[i] = stage[n * d + n + i];
+            pvi = stage[n * d + 2 * n + i];
+            pv[i] = pvi;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CBO_MAX_DIM; ++k)
+        if (k < d) xs[(int64_t)k * ld + i] = x[k];
+    double s;
+    if (d == 8) {
+        double r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = __dmul_rn(x[k], x[k]);
+        s = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])),
+                      __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
+    } else {
+        s = 0.0;
+#pragma unroll
+        for (int k = 0; k < CBO_MAX_DIM; ++k)
+            if (k < d) s = __dadd_rn(s, __dmul_rn(x[k], x[k]));
+    }
+    sq[i] = s;
+    if (sv) sv[i] = (i < n && has_prior) ? sqrt(pvi) : 0.0;
+}
+
+void launch_prep_points_staged(hipStream_t s, const double *stage, int64_t n, int d, const double *ls_dev, bool has_prior,
+                               double *raw, double *y, double *pm, double *pv, double *xs, int64_t ld, double *sq,
+                               double *sv)
+{
+    hipLaunchKernelGGL(prep_points_staged_kernel, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, stage, n, d, ls_dev,
+                       has_prior ? 1 : 0, raw, y, pm, pv, xs, ld, sq, sv);
+}
+
 void launch_prep_points(hipStream_t s, const double *raw_aos, int64_t n, int d, const double *ls_dev,
                         const double *pv_raw, double *xs, int64_t ld, double *sq, double *sv)
 {
@@ -70,27 +130,7 @@ void launch_prep_points(hipStream_t s, const double *raw_aos, int64_t n, int d, 
                        sq, sv);
 }
 
-// ------------------------------------------------------------------------------------------------
-// One kernel-matrix element, GPy operation order.
-template <int D>
-__device__ __forceinline__ double kernel_value(const double *xi, const double *xj, double sqi, double sqj,
-                                               double variance, double inv_l2, bool force_zero)
-{
-    // np.dot(X, X2.T): BLAS accumulates a_k*b_k with FMAs from a zero accumulator.
-    double dot = __dmul_rn(xi[0], xj[0]);
-#pragma unroll
-    for (int k = 1; k < D; ++k) dot = __fma_rn(xi[k], xj[k], dot);
-    double r2 = __dadd_rn(__dmul_rn(-2.0, dot), __dadd_rn(sqi, sqj));
-    if (force_zero) r2 = 0.0;
-    r2 = (r2 < 0.0) ? 0.0 : r2;                       // np.clip(r2, 0, inf) (NaN stays NaN)
-    // GPy goes r = sqrt(r2) / lengthscale, then r*r.  The round trip through the square root costs ~40 fp64
-    // instructions per element and changes r^2 by at most a couple of ulp (far below the 1e-16-level
-    // differences between exp() implementations), so the squared scaled distance is formed directly;
-    // inv_l2 = 1 / lengthscale^2 is exactly 1 for the reference's lengthscale = 1 (and for ARD, whose inputs
-    // are pre-scaled).
-    return __dmul_rn(variance, exp(__dmul_rn(-0.5, __dmul_rn(r2, inv_l2))));
-}
-
+// (one kernel-matrix element: kernel_value<D> of cbo_device.h)
 struct KmatArgs {
     const double *rx; int64_t ldr; const double *rsq; const double *rsv;   // row points (observations)
     const double *cx; int64_t ldc; const double *csq; const double *csv;   // column points

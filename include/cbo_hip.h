@@ -210,6 +210,17 @@ int cbo_gp_fit_sweep(cbo_gp *gp, cbo_cands *cands, double y_best, int task, doub
                      double *acq_out, double *mean_out, double *var_out, double *best_val,
                      int64_t *best_idx, int *tries_out, double *jitter_out);
 
+/* Every exploration set of a trial in one call: CBO.compute_best_acquisition_values (src/CBO.py:237-260) loops
+ * find_next_y_point over the S sets (S = 2 toy, 6 complete, 25 coral).  Pair i is (gps[i], cands[i]) with its own
+ * incumbent y_best[i] and batch cost costs[i]; best_vals / best_idxs receive S winners.  Sets whose model has at most
+ * 128 observations (every model the reference builds: 10 + <= 40 points) are factored AND swept by one launch inside
+ * LDS -- no per-set launch chain, no per-set synchronisation, one copy back; such a model need not be fitted
+ * (cbo_gp_upload_data suffices) and its fitted state is left alone.  Larger models, fp32 models and sets whose
+ * factorisation needs jitchol's jitter take the general path (cbo_gp_fit_sweep if unfitted, else cbo_acq_sweep).
+ * Same numbers as the per-set calls (same device functions, same summation orders).  All pairs on one context. */
+int cbo_acq_sweep_sets(int n_sets, cbo_gp *const *gps, cbo_cands *const *cands, const double *y_best, int task,
+                       double ei_jitter, const double *costs, double *best_vals, int64_t *best_idxs);
+
 /* Host-buffer convenience form of the same call (uploads Xs first). */
 int cbo_acq_sweep_host(cbo_gp *gp, int64_t m, const double *Xs, const double *prior_mean_s,
                        const double *prior_var_s, double y_best, int task, double ei_jitter,

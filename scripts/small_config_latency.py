@@ -27,7 +27,18 @@ def cpu_pass():
     posts[1] = O.fit(xs[1], ys[1])
     vals = [O.acquisition_sweep(posts[s], grids[s], best, cost=1.0)[1] for s in range(2)]
     return O.select_next_intervention([np.array([[v]]) for v in vals])
-for name, fn in (("gpu path", gpu_pass), ("cpu oracle", cpu_pass)):
+from cbo_with_oop_amd.utils_functions.utils import find_next_y_point
+def gpu_pass_per_set():
+    """the same pass with one device call (and one synchronisation) per set: round 1's path"""
+    path.update_gaussian_process_of_last_intervention()
+    ysn = [find_next_y_point(path.space_list[s], path.models[s], best, es[s], path.costs, task="min",
+                             candidates=path.candidate_grid(s))[0] for s in range(2)]
+    return path.select_next_intervention(ysn)
+def device_only():
+    """just the multi-set device call (no upload of the intervened set, no host bookkeeping)"""
+    return path.compute_best_acquisition_values(best)[1][0][0, 0]
+for name, fn in (("gpu path (one launch for all sets)", gpu_pass), ("gpu path, per-set calls", gpu_pass_per_set),
+                 ("  of which cbo_acq_sweep_sets + host glue", device_only), ("cpu oracle", cpu_pass)):
     for _ in range(5): fn()
     t0 = time.perf_counter(); n = 50
     for _ in range(n): r = fn()
@@ -39,3 +50,16 @@ if "--profile" in sys.argv:
     for _ in range(200): gpu_pass()
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+# the C-ABI call alone (no Python glue): cbo_acq_sweep_sets on the two sets
+import ctypes
+from cbo_with_oop_amd import _lib
+lib = _lib.load()
+grids_dev = [path.candidate_grid(s) for s in range(2)]
+gps = (ctypes.c_void_p * 2)(*[m._handle for m in path.models])
+cds = (ctypes.c_void_p * 2)(*[g._handle for g in grids_dev])
+yb, cs, vals, idxs = np.full(2, best), np.ones(2), np.empty(2), np.empty(2, dtype=np.int64)
+args = (2, gps, cds, _lib.dptr(yb), 0, 0.0, _lib.dptr(cs), _lib.dptr(vals), idxs.ctypes.data_as(_lib.c_int64_p))
+for _ in range(5): _lib.check(lib.cbo_acq_sweep_sets(*args))
+t0 = time.perf_counter()
+for _ in range(200): lib.cbo_acq_sweep_sets(*args)
+print(f"  cbo_acq_sweep_sets alone (2 sets x 200 candidates, 50 observations each): {(time.perf_counter() - t0) / 200 * 1e6:.1f} us per call")

@@ -1071,3 +1071,121 @@ def test_append_only_trial_step_matches_full_refit(hip, n0, d, causal):
     inc.set_data(X, y)
     c = CausalExpectedImprovement(best, "min", inc).sweep(grid, cost=2.0, want_acq=True)
     np.testing.assert_allclose(c["acq"][big], b["acq"][big], rtol=1e-9)
+
+
+# ------------------------------------------------------------------------- every set of a trial in one launch
+def _per_set_reference(hip, models, grids, y_best, task, costs):
+    """The general path, set by set (cbo_acq_sweep after a fit)."""
+    from cbo_with_oop_amd import CausalExpectedImprovement
+    out = []
+    for m, g, c in zip(models, grids, costs):
+        m.ensure_fitted()
+        r = CausalExpectedImprovement(y_best, task, m).sweep(g, cost=c)
+        out.append((r["best_val"], r["best_idx"]))
+    return out
+
+
+def _sweep_sets(models, grids, y_best, task, costs):
+    import ctypes
+    from cbo_with_oop_amd import _lib
+    s = len(models)
+    gps = (ctypes.c_void_p * s)(*[m._handle for m in models])
+    cds = (ctypes.c_void_p * s)(*[g._handle for g in grids])
+    yb, cs = np.full(s, float(y_best)), np.asarray(costs, dtype=np.float64)
+    vals, idxs = np.empty(s), np.empty(s, dtype=np.int64)
+    _lib.check(_lib.load().cbo_acq_sweep_sets(s, gps, cds, _lib.dptr(yb), _lib.TASK_CODE[task], 0.0, _lib.dptr(cs),
+                                              _lib.dptr(vals), idxs.ctypes.data_as(_lib.c_int64_p)))
+    return list(zip(vals.tolist(), idxs.tolist()))
+
+
+def test_sweep_sets_small_models_equal_the_per_set_path(hip):
+    """cbo_acq_sweep_sets on the reference's own model sizes (10..50 observations, src/ArgumentParser.py:18,25): one
+    launch for all sets, UNFITTED models included, must give the per-set general path's winners -- same device
+    functions, same summation orders, so the same bits."""
+    from cbo_with_oop_amd import CandidateGrid
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    from cbo_with_oop_amd.graphs import CompleteGraph, ToyGraph, meshgrid_candidates
+    fx, fz, fc = load_fixture("toy_init_X"), load_fixture("toy_init_Z"), load_fixture("toy_c1_Z50")
+    rng = np.random.default_rng(5)
+    models, grids, costs = [], [], []
+    for f in (fx, fz, fc):
+        models.append(HipGaussianProcess(f["X"], f["y"], fit=False))           # never fitted before the launch
+        grids.append(CandidateGrid(f["Xs"], models[-1]))
+        costs.append(float(f["cost"]))
+    # complete-graph sets: d = 1 and d = 2, 17 and 100 points, an index offset and a ragged candidate count
+    for names, n, shape in ((("B",), 17, (333,)), (("B", "D"), 100, (25, 21)), (("D", "E"), 128, (40, 40))):
+        box = CompleteGraph.bounds(list(names))
+        lo, hi = np.array([b[0] for b in box], float), np.array([b[1] for b in box], float)
+        X = rng.uniform(lo, hi, (n, len(box)))
+        y = np.sin(X).sum(1, keepdims=True) + 0.1 * rng.standard_normal((n, 1))
+        models.append(HipGaussianProcess(X, y, fit=False))
+        grids.append(CandidateGrid(meshgrid_candidates(box, shape), models[-1], index_offset=1000 * len(models)))
+        costs.append(float(len(names)))
+    y_best = -0.7
+    for task in ("min", "max"):
+        got = _sweep_sets(models, grids, y_best, task, costs)
+        assert all(m.stale for m in models)                                    # the launch left the models alone
+        ref_models = [HipGaussianProcess(m.X, m.Y) for m in models]
+        ref_grids = [CandidateGrid(g.points, rm, index_offset=g.index_offset) for g, rm in zip(grids, ref_models)]
+        want = _per_set_reference(hip, ref_models, ref_grids, y_best, task, costs)
+        assert got == want, (task, got, want)
+    # against the oracle on the toy fixtures (the fixtures' own incumbent and task)
+    for f, m, g in zip((fx, fz, fc), models, grids):
+        (val, idx), = _sweep_sets([m], [g], float(f["y_best"]), f["task"], [float(f["cost"])])
+        assert idx == int(f["best_idx"]), f["note"]
+
+
+def test_sweep_sets_mixed_sizes_causal_and_jitter(hip):
+    """One call over: a causal small model, a small model whose K needs jitchol's jitter (duplicate rows: the general
+    path takes over for that set), a model beyond 128 observations, an fp32 model."""
+    import warnings
+    from cbo_with_oop_amd import CandidateGrid
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    fcausal, fj, fbig = load_fixture("causal_d2"), load_fixture("jitter_ladder"), load_fixture("complete_bo_d3")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        mc = make_model(hip, fcausal)
+        mj = HipGaussianProcess(fj["X"], fj["y"], noise_var=float(fj["noise_var"]), fit=False)
+        rng = np.random.default_rng(3)
+        Xb = rng.uniform(-3, 3, (300, 3))
+        yb = np.cos(Xb).sum(1, keepdims=True)
+        mb = HipGaussianProcess(Xb, yb, fit=False)
+        m32 = HipGaussianProcess(Xb[:200], yb[:200], noise_var=1e-2, dtype="f32")
+        models = [mc, mj, mb, m32]
+        grids = [CandidateGrid(fcausal["Xs"], mc), CandidateGrid(fj["Xs"], mj), CandidateGrid(fbig["Xs"], mb),
+                 CandidateGrid(fbig["Xs"], m32)]
+        costs = [2.0, 1.0, 3.0, 3.0]
+        got = _sweep_sets(models, grids, 0.1, "min", costs)
+        refs = [make_model(hip, fcausal), make_model(hip, fj), HipGaussianProcess(Xb, yb),
+                HipGaussianProcess(Xb[:200], yb[:200], noise_var=1e-2, dtype="f32")]
+        want = _per_set_reference(hip, refs, [CandidateGrid(g.points, r) for g, r in zip(grids, refs)], 0.1, "min", costs)
+    assert got == want, (got, want)
+    assert refs[1].jitter_tries >= 1                                           # that set did need the ladder
+
+
+def test_sweep_sets_switch_and_path_integration(hip, monkeypatch):
+    """CBO_HIP_SMALL_SETS=0 sends everything through the general path (same answers), and CBOAcquisitionPath's
+    compute_best_acquisition_values is the multi-set call."""
+    from cbo_with_oop_amd import CBOAcquisitionPath, GaussianProcessType
+    from cbo_with_oop_amd.graphs import ToyGraph
+    rng = np.random.default_rng(0)
+    es = ToyGraph.get_exploration_set("MIS")
+    xs = [rng.uniform(-5, 5, (50, 1)), rng.uniform(-5, 20, (50, 1))]
+    ys = [ToyGraph.target_do_x(xs[0]), ToyGraph.target_do_z(xs[1])]
+
+    def run():
+        path = CBOAcquisitionPath(GaussianProcessType.NON_CAUSAL_GP, es, ToyGraph.get_cost_structure(1), "min", xs, ys,
+                                  [ToyGraph.bounds(s) for s in es], grid_shapes=[[200], [200]])
+        path.update_all_gaussian_processes()
+        best = min(float(ys[0].min()), float(ys[1].min()))
+        path.last_intervention = 1
+        path.update_gaussian_process_of_last_intervention()
+        pts, vals = path.compute_best_acquisition_values(best)
+        choice = path.select_next_intervention(vals)
+        return [p.tolist() for p in pts], [v.tolist() for v in vals], choice
+
+    from cbo_with_oop_amd import _lib
+    one_launch = run()
+    ctx = forced_context(monkeypatch, CBO_HIP_SMALL_SETS=0)
+    monkeypatch.setattr(_lib.Context, "get", classmethod(lambda cls, device_id=None: ctx))
+    assert run() == one_launch
