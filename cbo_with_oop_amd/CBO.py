@@ -14,12 +14,19 @@ from .utils_functions.utils import (default_grid_shape, find_current_global, fin
                                     space_bounds)
 
 
+class _FixedCosts:
+    """Batch costs decided by the caller (the whole grid's, when a rank only holds a block of it)."""
+
+    def __init__(self, by_set, order):
+        self.values = [by_set[s] for s in order]
+
+
 class CBOAcquisitionPath:
     """Holds exactly the state those methods read on the reference's ``CBO`` object: ``gp_type``,
     ``exploration_set``, ``costs``, ``task``, per-set data, spaces, prior closures and models."""
 
     def __init__(self, gp_type, exploration_set, costs, task, data_x, data_y, space_list, mean_functions=None,
-                 var_functions=None, grid_shapes=None, keep_solutions=True):
+                 var_functions=None, grid_shapes=None, keep_solutions=True, comm="env"):
         self.gp_type = gp_type
         self.exploration_set = exploration_set
         self.es_size = len(exploration_set)
@@ -35,6 +42,11 @@ class CBOAcquisitionPath:
         self.last_intervention = None
         self._grids = {}          # per set: (grid shape, prior closures, device-resident candidate grid)
         self._call_cache = {}     # handle arrays and batch costs of the multi-set sweep, valid while the objects are
+        # Several GPUs (one process per GPU): ``comm`` is a sharding.Communicator (or anything with world / rank /
+        # argmax), "env" = the launcher's (RANK / WORLD_SIZE), None = single process.  Whole exploration sets go to
+        # ranks when there are at least as many sets as ranks (S = 25 coral sets on 8 GPUs: every GPU sweeps full
+        # grids of three sets), candidate blocks of every set otherwise; either way one 16-byte exchange per set.
+        self._comm = comm
         # keep L^-1 K* of every set's grid on the device: a trial then costs the set intervened on one forward
         # solve and one new row (append-only step) instead of a refit and a full sweep
         self.keep_solutions = bool(keep_solutions)
@@ -62,27 +74,86 @@ class CBOAcquisitionPath:
         self.models[s] = GPFactory.create(self.gp_type, self.data_x[s], self.data_y[s],
                                           [self.mean_functions[s], self.var_functions[s]], emukit_wrapper=True, fit=fit)
 
+    @property
+    def comm(self):
+        if isinstance(self._comm, str):                      # "env": formed on first use (touches the GPU)
+            from .sharding import default_communicator
+            self._comm = default_communicator()
+        return self._comm
+
+    def placement(self):
+        """("single" | "sets" | "candidates", world, rank)."""
+        comm = self.comm
+        if comm is None or comm.world == 1:
+            return "single", 1, 0
+        return ("sets" if self.es_size >= comm.world else "candidates"), comm.world, comm.rank
+
+    def grid_points(self, s):
+        bounds = space_bounds(self.space_list[s])
+        shape = tuple(self.grid_shapes[s] or default_grid_shape(len(bounds)))
+        return shape, meshgrid_candidates(bounds, shape)
+
     def candidate_grid(self, s):
         """The regular grid over the set's box, resident on the device across trials (the reference draws fresh
         random anchors each trial; the grid of BASELINE.json's sweep is fixed).  Rebuilt when the grid shape, the
-        model object or the prior closures change."""
-        bounds = space_bounds(self.space_list[s])
-        shape = tuple(self.grid_shapes[s] or default_grid_shape(len(bounds)))
-        key = (shape, id(self.models[s]), id(self.mean_functions[s]), id(self.var_functions[s]))
+        model object or the prior closures change.  Under candidate placement it is this rank's contiguous block of
+        the grid (``index_offset`` = the block's first row); ``full_points`` keeps the whole grid for the look-up of
+        the winner."""
+        mode, world, rank = self.placement()
+        shape, pts = self.grid_points(s)
+        key = (shape, id(self.models[s]), id(self.mean_functions[s]), id(self.var_functions[s]), mode, world, rank)
         cached = self._grids.get(s)
         if cached is None or cached[0] != key:
             if cached is not None:
                 cached[1].close()
-            cached = (key, CandidateGrid(meshgrid_candidates(bounds, shape), self.models[s],
-                                         keep_solution=self.keep_solutions))
+            if mode == "candidates":
+                from .sharding import shard_bounds
+                begin, end = shard_bounds(pts.shape[0], world, rank)
+                grid = CandidateGrid(pts[begin:max(end, begin + 1)] if end > begin else pts[:1], self.models[s],
+                                     index_offset=begin, keep_solution=self.keep_solutions)
+                grid.empty_shard = end <= begin
+            else:
+                grid = CandidateGrid(pts, self.models[s], keep_solution=self.keep_solutions)
+                grid.empty_shard = False
+            grid.full_points = pts
+            cached = (key, grid)
             self._grids[s] = cached
         return cached[1]
 
     def compute_best_acquisition_values(self, current_best):
-        """CBO.py:237-260: the loop over the exploration sets, as ONE device call (``cbo_acq_sweep_sets``)."""
-        grids = [self.candidate_grid(s) for s in range(self.es_size)]
-        return find_next_y_points(self.models, current_best, self.exploration_set, self.costs, self.task, grids,
-                                  cache=self._call_cache)
+        """CBO.py:237-260: the loop over the exploration sets, as ONE device call (``cbo_acq_sweep_sets``); across
+        several GPUs, this rank's share of it and one arg-max exchange per set."""
+        mode, world, rank = self.placement()
+        if mode == "single":
+            grids = [self.candidate_grid(s) for s in range(self.es_size)]
+            return find_next_y_points(self.models, current_best, self.exploration_set, self.costs, self.task, grids,
+                                      cache=self._call_cache)
+        from .sharding import NO_CANDIDATE
+        from .utils_functions.cost_functions import Cost
+        mine = [s for s in range(self.es_size) if mode == "candidates" or s % world == rank]
+        mine = [s for s in mine if not (mode == "candidates" and self.candidate_grid(s).empty_shard)]
+        local = {}
+        if mine:
+            grids = [self.candidate_grid(s) for s in mine]
+            # batch costs are those of the WHOLE grid (a variable cost sums |x| over the batch column)
+            full_cost = {s: float(Cost(self.costs, self.exploration_set[s]).evaluate(self.candidate_grid(s).full_points))
+                         for s in mine}
+            _, ys = find_next_y_points([self.models[s] for s in mine], current_best,
+                                       [self.exploration_set[s] for s in mine], _FixedCosts(full_cost, mine), self.task,
+                                       grids, cache=self._call_cache, raw=True)
+            local = {s: ys[i] for i, s in enumerate(mine)}
+        xs, out = [], []
+        for s in range(self.es_size):
+            val, idx = local.get(s, (-np.inf, NO_CANDIDATE))
+            val, idx = self.comm.argmax(val, idx)                       # identical on every rank
+            pts = self.grid_points(s)[1]
+            x_new = pts[idx][None, :].copy()
+            cost = Cost(self.costs, self.exploration_set[s])
+            batch, point = float(cost.evaluate(pts)), float(cost.evaluate(x_new))
+            # utils.py:36 re-evaluates EI / cost at x_new alone: the same EI over the point's own cost
+            out.append(np.array([[val if point == batch else val * batch / point]]))
+            xs.append(x_new)
+        return xs, out
 
     def current_best_solution(self, current_best_y):
         """CBO.py:262-267 (the monitor's ``current_best_y`` dict is passed in)."""

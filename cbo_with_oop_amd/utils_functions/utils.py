@@ -98,22 +98,25 @@ def find_next_y_point(space, model, current_global_best, evaluated_set, costs_fu
     return y, x_new
 
 
-def find_next_y_points(models, current_global_best, evaluated_sets, costs_functions, task, grids, cache=None):
+def find_next_y_points(models, current_global_best, evaluated_sets, costs_functions, task, grids, cache=None, raw=False):
     """``find_next_y_point`` for every exploration set of a trial in ONE device call (``cbo_acq_sweep_sets``): the loop
     of src/CBO.py:249-257.  ``grids[s]`` is the CandidateGrid of set s.  Models with at most 128 observations -- all
     the reference builds -- are factored and swept inside one launch and need not be fitted; the others go through
     the general path inside the same call.  ``cache`` (a dict the caller keeps between trials) holds what does not
     change while models, grids and cost functions stay the same objects: the handle arrays and the batch costs.
-    Returns (xs, ys): lists of (1,d) points and (1,1) acquisition values."""
+    Returns (xs, ys): lists of (1,d) points and (1,1) acquisition values.  ``raw=True`` (the multi-GPU caller): the
+    batch costs are given (``costs_functions.values``, those of the whole grid) and ys are (value, global index)
+    pairs for the arg-max exchange, xs is None."""
     import ctypes
     from .. import _lib
     s = len(models)
     key = (id(costs_functions), tuple(id(m) for m in models), tuple(id(g) for g in grids))
     st = cache.get("sweep_sets") if cache is not None else None
-    if st is None or st["key"] != key:
-        costs = [Cost(costs_functions, evaluated_sets[i]) for i in range(s)]
+    if st is None or st["key"] != key or raw:
+        costs = None if raw else [Cost(costs_functions, evaluated_sets[i]) for i in range(s)]
         st = {"key": key, "costs": costs,
-              "batch_cost": np.array([float(costs[i].evaluate(grids[i].points)) for i in range(s)], dtype=np.float64),
+              "batch_cost": np.array(costs_functions.values if raw else
+                                     [float(costs[i].evaluate(grids[i].points)) for i in range(s)], dtype=np.float64),
               "gps": (ctypes.c_void_p * s)(*[m._handle for m in models]),
               "cds": (ctypes.c_void_p * s)(*[g._handle for g in grids]),
               "y_best": np.empty(s), "vals": np.empty(s), "idxs": np.empty(s, dtype=np.int64)}
@@ -124,10 +127,13 @@ def find_next_y_points(models, current_global_best, evaluated_sets, costs_functi
     _lib.check(_lib.load().cbo_acq_sweep_sets(s, st["gps"], st["cds"], _lib.dptr(st["y_best"]), _lib.TASK_CODE[task], 0.0,
                                               _lib.dptr(batch_cost), _lib.dptr(vals),
                                               idxs.ctypes.data_as(_lib.c_int64_p)))
-    xs, ys = [], []
     for i in range(s):
         if not models[i].small:                  # the general path fitted it on the way (deferred refit)
             models[i].stale = False
+    if raw:
+        return None, [(float(vals[i]), int(idxs[i])) for i in range(s)]
+    xs, ys = [], []
+    for i in range(s):
         x_new = grids[i].points[idxs[i] - grids[i].index_offset][None, :].copy()
         # utils.py:36 re-evaluates the acquisition at x_new alone; only variable costs change the value
         point_cost = float(costs[i].evaluate(x_new))

@@ -1189,3 +1189,63 @@ def test_sweep_sets_switch_and_path_integration(hip, monkeypatch):
     ctx = forced_context(monkeypatch, CBO_HIP_SMALL_SETS=0)
     monkeypatch.setattr(_lib.Context, "get", classmethod(lambda cls, device_id=None: ctx))
     assert run() == one_launch
+
+
+class _RecordingComm:
+    """Stand-in for sharding.Communicator in a single process: phase "record" keeps what this rank would contribute to
+    each exchange; phase "replay" answers each exchange with the reduction over all ranks' recorded contributions."""
+
+    def __init__(self, world, rank, records=None):
+        self.world, self.rank, self.records, self.mine, self.calls = world, rank, records, [], 0
+
+    def argmax(self, val, idx):
+        from cbo_with_oop_amd.sharding import NO_CANDIDATE, reduce_pairs
+        self.mine.append((val, idx))
+        if self.records is None:
+            return (val, idx) if idx != NO_CANDIDATE else (0.0, 0)
+        pairs = [r[self.calls] for r in self.records]
+        self.calls += 1
+        pairs = [p for p in pairs if p[1] != NO_CANDIDATE]
+        return reduce_pairs([p[0] for p in pairs], [p[1] for p in pairs])
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_path_placement_over_ranks_equals_single_process(hip, world):
+    """CBOAcquisitionPath under a communicator: sets placed on ranks (6 complete-graph sets over 2 or 3 ranks) or
+    candidate blocks of every set (8 ranks > 6 sets, some blocks ragged), one exchange per set -- every rank must end
+    up with the single-process answer.  The ranks run one after the other in this process; the exchange is replayed
+    from their recorded contributions (the real one is cbo_comm_argmax, test_communicator_through_the_c_abi)."""
+    from cbo_with_oop_amd import CBOAcquisitionPath, GaussianProcessType
+    from cbo_with_oop_amd.graphs import CompleteGraph
+    rng = np.random.default_rng(11)
+    es = CompleteGraph.get_exploration_set("MIS")
+    xs, ys = [], []
+    for s in es:
+        box = CompleteGraph.bounds(s)
+        lo, hi = np.array([b[0] for b in box], float), np.array([b[1] for b in box], float)
+        X = rng.uniform(lo, hi, (30 + 7 * len(xs), len(box)))
+        xs.append(X)
+        ys.append(np.sin(X).sum(1, keepdims=True) + 0.05 * rng.standard_normal((X.shape[0], 1)))
+    shapes = [[37] if len(s) == 1 else [9, 7] for s in es]
+    costs = CompleteGraph.get_cost_structure(3)                     # variable costs: the batch cost is the whole grid's
+    best = min(float(y.min()) for y in ys)
+
+    def run(comm):
+        path = CBOAcquisitionPath(GaussianProcessType.NON_CAUSAL_GP, es, costs, "min", xs, ys,
+                                  [CompleteGraph.bounds(s) for s in es], grid_shapes=shapes, comm=comm)
+        path.update_all_gaussian_processes()
+        pts, vals = path.compute_best_acquisition_values(best)
+        return [p.tolist() for p in pts], [float(v[0, 0]) for v in vals], path.placement()[0]
+
+    single_pts, single_vals, mode = run(None)
+    assert mode == "single"
+    recorders = [_RecordingComm(world, r) for r in range(world)]
+    for c in recorders:
+        run(c)
+    records = [c.mine for c in recorders]
+    assert all(len(r) == len(es) for r in records)
+    for r in range(world):
+        pts, vals, mode = run(_RecordingComm(world, r, records))
+        assert mode == ("sets" if len(es) >= world else "candidates")
+        assert pts == single_pts
+        assert np.allclose(vals, single_vals, rtol=1e-13, atol=0)
