@@ -406,13 +406,23 @@ __device__ __forceinline__ void diag128_factor_in_lds(Diag2Shared &sh, double *A
         for (int kk = 0; kk < 4; ++kk) af[kk] = sh.Yt[jb & 1][4 * kk + kq][lc];
         if (wave == 0) {
             if (jb + 1 < tiles) {
-                d4 x = {0.0, 0.0, 0.0, 0.0}, acc;
+                // two half-sums each: a chain of dependent f64 MFMAs runs at about half the issue rate
+                d4 x = {0.0, 0.0, 0.0, 0.0}, xb = {0.0, 0.0, 0.0, 0.0}, acc, accb = {0.0, 0.0, 0.0, 0.0};
+                double bq[4];
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) x = MFMA_F64(af[kk], sh.S[o + 4 * kk + kq][o + 16 + lc], x);
+                for (int kk = 0; kk < 4; ++kk) bq[kk] = sh.S[o + 4 * kk + kq][o + 16 + lc];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[r] = sh.S[o + 16 + kq + 4 * r][o + 16 + lc];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc = MFMA_F64(x[r], -x[r], acc);
+                x = MFMA_F64(af[0], bq[0], x);
+                xb = MFMA_F64(af[1], bq[1], xb);
+                x = MFMA_F64(af[2], bq[2], x);
+                xb = MFMA_F64(af[3], bq[3], xb);
+                x += xb;
+                acc = MFMA_F64(x[0], -x[0], acc);
+                accb = MFMA_F64(x[1], -x[1], accb);
+                acc = MFMA_F64(x[2], -x[2], acc);
+                accb = MFMA_F64(x[3], -x[3], accb);
+                acc += accb;
                 const d4 u = factor_tile_regs(acc, lane, r0 + o + 16, info, sh.Yt[(jb + 1) & 1],
                                               invDt + (int64_t)(r0 / 16 + jb + 1) * 256);
 #pragma unroll
@@ -495,8 +505,11 @@ __global__ __launch_bounds__(256) void potrf_diag128_v2_kernel(double *A, int64_
         const unsigned s0 = lds_byte_address(&sh.S[0][0]);
         const double *g = A + (int64_t)(r0 + wave * 32) * lda + r0 + lane * 2;
 #pragma unroll 8
-        for (int p = 0; p < 32; ++p)
-            glds16(g + (int64_t)p * lda, __builtin_amdgcn_readfirstlane(s0 + 8u * (unsigned)((wave * 32 + p) * kDiagLd)));
+        for (int p = 0; p < 32; ++p) {
+            // only the upper triangle (by 16-column tiles) is read: lanes left of the row's diagonal tile load nothing
+            if (lane >= 8 * ((wave * 32 + p) >> 4))
+                glds16(g + (int64_t)p * lda, __builtin_amdgcn_readfirstlane(s0 + 8u * (unsigned)((wave * 32 + p) * kDiagLd)));
+        }
     }
     if (tid < 128) {
         sh.S[tid][128] = A[(int64_t)(r0 + tid) * lda + rcol];
@@ -570,8 +583,10 @@ __global__ __launch_bounds__(256) void panel_trsm_kernel(double *A, int64_t lda,
         const unsigned s0 = lds_byte_address(&sh.U[0][0]);
         const double *g = A + (int64_t)(r0 + wave * 32) * lda + r0 + lane * 2;
 #pragma unroll 8
-        for (int p = 0; p < 32; ++p)
-            glds16(g + (int64_t)p * lda, __builtin_amdgcn_readfirstlane(s0 + 8u * (unsigned)((wave * 32 + p) * kDiagLd)));
+        for (int p = 0; p < 32; ++p) {
+            if (lane >= 8 * ((wave * 32 + p) >> 4))          // upper triangle only (by 16-column tiles)
+                glds16(g + (int64_t)p * lda, __builtin_amdgcn_readfirstlane(s0 + 8u * (unsigned)((wave * 32 + p) * kDiagLd)));
+        }
     }
     double *Ac = A + (int64_t)r0 * lda + col0 + (int64_t)blockIdx.x * kStrip + wave * 16 + lc;
     d4 acc[8];
@@ -953,6 +968,98 @@ __global__ __launch_bounds__(256) void syrk_kernel(double *A, int64_t lda, int r
         }
 }
 
+// The trailing update of the NEXT panel's 128 rows only -- the one piece of the update that sits on the chain (the
+// next diagonal block and row panel wait for it).  It is bound by the matrix pipe of single waves: a 64x64 tile per
+// workgroup means 2x2 MFMA tiles x K/4 steps = 256 dependent-free but serial MFMAs per wave at K = 256 (7.8 us).
+// Here a workgroup takes 32 rows x 64 columns (wave w: both 16-row tiles x its 16 columns), which halves the MFMAs
+// per wave and doubles the workgroups (256 at N = 4096: every CU busy).  blockIdx.x == nt: the rhs column.
+__global__ __launch_bounds__(256) void syrk_rows_kernel(double *A, int64_t lda, int r0, int n1, int c0, int nt, int rcol)
+{
+    const int tj = blockIdx.x, ti = blockIdx.y;                  // 64-column tile, 32-row tile (4 of them)
+    const int tid = threadIdx.x;
+    const double *P = A + (int64_t)r0 * lda;
+    if (tj == nt) {
+        __shared__ double part[256];
+        const int i = tid & 31, g = tid >> 5;
+        const int64_t gi = c0 + (int64_t)ti * 32 + i;
+        double s = 0.0;
+        for (int k0 = g; k0 < n1; k0 += 16 * 8) {
+            double pv[16], zv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = k0 + u * 8;
+                const bool ok = k < n1;
+                pv[u] = ok ? P[(int64_t)k * lda + gi] : 0.0;
+                zv[u] = ok ? P[(int64_t)k * lda + rcol] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s = fma(pv[u], zv[u], s);
+        }
+        part[tid] = s;
+        __syncthreads();
+        if (g == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int gg = 0; gg < 8; ++gg) tot += part[gg * 32 + i];
+            A[gi * lda + rcol] -= tot;
+        }
+        return;
+    }
+    const int64_t ib = c0 + (int64_t)ti * 32;                    // first row of the tile (= a column of the panel)
+    const int64_t jb0 = c0 + (int64_t)tj * 64;
+    if (jb0 + 63 < ib) return;                                   // entirely below the diagonal
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lc = lane & 15, kq = lane >> 4;
+    const int64_t jb = jb0 + wave * 16;
+    d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+    const double *Pa = P + (int64_t)kq * lda + ib + lc;          // A[i = lc][k = kq] = P[k][ib + i]  (+16: second row tile)
+    const double *Pb = P + (int64_t)kq * lda + jb + lc;          // B[k = kq][j = lc] = P[k][jb + j]
+    constexpr int CH = 8;                                        // k-steps per software-pipeline chunk
+    double a0[2][CH], a1[2][CH], b[2][CH];
+    auto load_chunk = [&](int k0, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < CH; ++ks) {
+            a0[buf][ks] = Pa[(int64_t)(k0 + 4 * ks) * lda];
+            a1[buf][ks] = Pa[(int64_t)(k0 + 4 * ks) * lda + 16];
+            b[buf][ks] = Pb[(int64_t)(k0 + 4 * ks) * lda];
+        }
+    };
+    load_chunk(0, 0);
+    double cv[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cv[m][r] = A[(ib + 16 * m + kq + 4 * r) * lda + jb + lc];
+    // n1 is 128 or 256: a multiple of 2 chunks of 32 rows
+    for (int k0 = 0; k0 < n1; k0 += 8 * CH) {
+        load_chunk(k0 + 4 * CH, 1);
+#pragma unroll
+        for (int ks = 0; ks < CH; ++ks) {
+            acc[0] = MFMA_F64(a0[0][ks], b[0][ks], acc[0]);
+            acc[1] = MFMA_F64(a1[0][ks], b[0][ks], acc[1]);
+        }
+        if (k0 + 8 * CH < n1) load_chunk(k0 + 8 * CH, 0);
+#pragma unroll
+        for (int ks = 0; ks < CH; ++ks) {
+            acc[0] = MFMA_F64(a0[1][ks], b[1][ks], acc[0]);
+            acc[1] = MFMA_F64(a1[1][ks], b[1][ks], acc[1]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A[(ib + 16 * m + kq + 4 * r) * lda + jb + lc] = cv[m][r] - acc[m][r];
+}
+
+// the next panel's 128 rows against the n1 panel rows [r0, r0 + n1): columns from c0 = r0 + n1 on, n2 of them
+static void launch_syrk_rows(hipStream_t s, double *A, int64_t lda, int r0, int n1, int n2, int rcol)
+{
+    const int c0 = r0 + n1;
+    const int nt = n2 / 64;
+    if (nt <= 0) return;
+    hipLaunchKernelGGL(syrk_rows_kernel, dim3(nt + 1, 4), dim3(256), 0, s, A, lda, r0, n1, c0, nt, rcol);
+}
+
 // tile rows [ti_begin, ti_end) of the trailing update (64-row tiles counted from the first trailing row)
 static void launch_syrk(hipStream_t s, double *A, int64_t lda, int r0, int n1, int n2, int rcol, int ti_begin,
                         int ti_end)
@@ -1061,6 +1168,9 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
                         (int)sizeof(PanelShared));
     static const int panel_form = [] { const char *e = std::getenv("CBO_HIP_PANEL_FORM"); return e ? std::atoi(e) : 2; }();
     static const int syrk_gemm_rows = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_ROWS"); return e ? std::atoi(e) : 6144; }();
+    static const int syrk_gemm_chunk = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_CHUNK"); return e ? std::atoi(e) : 2; }();
+    static const bool syrk_gemm_half = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_KB"); return !(e && std::atoi(e) == 32); }();
+    static const int syrk_rows_form = [] { const char *e = std::getenv("CBO_HIP_SYRK_ROWS_FORM"); return e ? std::atoi(e) : 2; }();
     static const int diag_form = [] { const char *e = std::getenv("CBO_HIP_DIAG_FORM"); return e ? std::atoi(e) : 2; }();
     auto launch_diag = [&](int rr) {
         if (diag_form == 1)
@@ -1109,7 +1219,8 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         // rows of the pair's second panel: K = 128 update with the first panel (after the previous bulk
         // update, which touches the same rows)
         if (pending >= 0) { hipStreamWaitEvent(s, events[pending], 0); pending = -1; }
-        launch_syrk(s, A, lda, r0, 128, n2, rcol, 0, 2);
+        if (syrk_rows_form == 2) launch_syrk_rows(s, A, lda, r0, 128, n2, rcol);
+        else launch_syrk(s, A, lda, r0, 128, n2, rcol, 0, 2);
         const int r1 = r0 + 128;
         launch_diag(r1);
         const int n3 = (int)n_pad - r1 - 128;
@@ -1120,7 +1231,8 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
                            A + (int64_t)r1 * lda + r1 + 128, lda, 128, n3, nullptr, nullptr, nullptr, false, half_lds);
         sweep_rows(r0, 256);
         // both panels against everything below them: next pair's first panel rows on this stream, ...
-        launch_syrk(s, A, lda, r0, 256, n3, rcol, 0, 2);
+        if (syrk_rows_form == 2) launch_syrk_rows(s, A, lda, r0, 256, n3, rcol);
+        else launch_syrk(s, A, lda, r0, 256, n3, rcol, 0, 2);
         if (n3 > 128) {                                       // ... the rest on the side stream
             hipEventRecord(events[2 * k], s);
             hipStreamWaitEvent(side, events[2 * k], 0);
@@ -1129,8 +1241,8 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
             // as one more strip): the 64x64-tile SYRK reads its operands as fragment-shaped loads from L2 and tops
             // out near half the fp64 MFMA rate, which is what bounds the factorisation at 16384 points
             if (n3 - 128 >= syrk_gemm_rows)
-                launch_gemm_update(side, A, lda, A, lda, A, lda, r0, 256, r0 + 256 + 128, (int)n_pad, n_pad + kRhsCols, 2,
-                                   true, true);
+                launch_gemm_update(side, A, lda, A, lda, A, lda, r0, 256, r0 + 256 + 128, (int)n_pad, n_pad + kRhsCols,
+                                   syrk_gemm_chunk, syrk_gemm_half, true);
             else
                 launch_syrk(side, A, lda, r0, 256, n3, rcol, 2, n3 / 64);
             hipEventRecord(events[2 * k + 1], side);
