@@ -103,6 +103,11 @@ struct cbo_ctx {
     double *best_val = nullptr; int64_t *best_idx = nullptr;   // device
     double *h_best_val = nullptr; int64_t *h_best_idx = nullptr; // pinned host
     int *h_info = nullptr;
+    // host-buffer entry points (cbo_gp_predict, _grouped, _gradients, cbo_acq_sweep_host) reuse ONE grow-only candidate
+    // set instead of creating and destroying one per call; gradient / export scratch likewise
+    cbo_cands *scratch_k = nullptr;
+    double *grads = nullptr; size_t grads_elems = 0;
+    double *export_buf = nullptr; size_t export_elems = 0;
     // small uploads (cbo_gp_upload_data / cbo_gp_set_data of a few KB, every trial of the reference's loop): one
     // pinned staging buffer the preparation kernel reads directly; `stage_done` guards its reuse
     double *stage = nullptr; hipEvent_t stage_done = nullptr; bool stage_pending = false;
@@ -136,6 +141,10 @@ struct cbo_gp {
     double append_d = 0.0, append_zn = 0.0;
     double *lvec = nullptr;          // [n_pad] the new column of U, contiguous
     cbo_cands *probe = nullptr;      // the appended point as a one-candidate set (scaled coordinates, prior)
+    // backward substitution through the forward kernel (prediction gradients of whole grids): the reversed factor and
+    // its diagonal-tile inverses, built on first use after a fit; 1 / lengthscale per dimension (ARD)
+    double *T = nullptr, *invT = nullptr, *inv_ls_dev = nullptr;
+    uint64_t t_stamp = 0;
     // CBO_DTYPE_F32: fp32 copies of the factor for the sweep (kernels_f32.hip), refreshed by every successful fit
     int dtype = CBO_DTYPE_F64;
     int64_t n32 = 0, ldu32 = 0;
@@ -147,8 +156,10 @@ struct cbo_cands {
     cbo_ctx *ctx = nullptr;
     int64_t m = 0, m_pad = 0;
     int d = 0;
+    int64_t cap_m_pad = 0; int cap_d = 0; bool cap_prior = false;      // what the buffers below can hold (grow-only)
     double *raw = nullptr;           // AoS (m,d) as uploaded
     double *pm = nullptr, *pv = nullptr;
+    bool has_prior = false;          // pm / pv carry this set's prior closures (the buffers may outlive that)
     int64_t index_offset = 0;
     // scaled view for the GP it was last prepared for
     PointSet P;
@@ -372,6 +383,8 @@ extern "C" void cbo_shutdown(cbo_ctx *c)
 static void destroy_ctx(cbo_ctx *c)
 {
     hipSetDevice(c->device);
+    if (c->scratch_k) { cbo_cands_destroy(c->scratch_k); c->scratch_k = nullptr; }
+    hipFree(c->grads); hipFree(c->export_buf);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->pool) hipEventDestroy(e);
@@ -466,8 +479,9 @@ static void free_gp_data(cbo_gp *g)
 {
     hipFree(g->X.xs); hipFree(g->X.sq); hipFree(g->X.sv); hipFree(g->X.pm); hipFree(g->X.pv);
     hipFree(g->raw); hipFree(g->y); hipFree(g->A); hipFree(g->invDt); hipFree(g->alpha); hipFree(g->z); hipFree(g->lvec);
-    hipFree(g->Uf); hipFree(g->invF);
+    hipFree(g->Uf); hipFree(g->invF); hipFree(g->T); hipFree(g->invT);
     g->Uf = g->invF = nullptr; g->f32_stamp = 0;
+    g->T = g->invT = nullptr; g->t_stamp = 0;
     g->X = PointSet{};
     g->raw = g->y = g->A = g->invDt = g->alpha = g->z = g->lvec = nullptr;
     g->parent_stamp = 0;
@@ -588,7 +602,7 @@ extern "C" void cbo_gp_destroy(cbo_gp *g)
     hipStreamSynchronize(g->ctx->stream);
     free_gp_data(g);
     hipFree(g->info);
-    hipFree(g->ls_dev);
+    hipFree(g->ls_dev); hipFree(g->inv_ls_dev);
     delete g;
 }
 
@@ -714,6 +728,18 @@ extern "C" int cbo_gp_upload_data(cbo_gp *g, int64_t n, const double *X, const d
     return upload_gp_data(g, n, X, y, pm, pv);      // leaves the model unfitted
 }
 
+static int ensure_export(cbo_ctx *c, size_t elems)
+{
+    if (elems > c->export_elems) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->export_buf);
+        c->export_buf = nullptr; c->export_elems = 0;
+        HIP_TRY(hipMalloc(&c->export_buf, sizeof(double) * elems));
+        c->export_elems = elems;
+    }
+    return CBO_OK;
+}
+
 extern "C" int cbo_gp_get_posterior(cbo_gp *g, double *L_out, double *alpha_out)
 {
     if (!g) return fail(CBO_ERR_INVALID, "gp is NULL");
@@ -721,13 +747,11 @@ extern "C" int cbo_gp_get_posterior(cbo_gp *g, double *L_out, double *alpha_out)
     cbo_ctx *c = g->ctx;
     HIP_TRY(hipSetDevice(c->device));
     if (L_out) {
-        double *tmp = nullptr;
-        HIP_TRY(hipMalloc(&tmp, sizeof(double) * g->n * g->n));
-        launch_export_lower(c->stream, g->A, g->lda, g->n, tmp);
-        hipError_t e = hipMemcpyAsync(L_out, tmp, sizeof(double) * g->n * g->n, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        hipFree(tmp);
-        HIP_TRY(e);
+        int rc = ensure_export(c, (size_t)g->n * (size_t)g->n);
+        if (rc != CBO_OK) return rc;
+        launch_export_lower(c->stream, g->A, g->lda, g->n, c->export_buf);
+        HIP_TRY(hipMemcpyAsync(L_out, c->export_buf, sizeof(double) * g->n * g->n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
     }
     if (alpha_out) {
         const int rc = ensure_alpha(g);
@@ -744,48 +768,103 @@ extern "C" int cbo_gp_assemble_kxx(cbo_gp *g, double *K_out)
     if (g->n <= 0 || g->n_pad <= 0) return fail(CBO_ERR_INVALID, "gp holds no data (a previous upload failed)");
     cbo_ctx *c = g->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    double *Atmp = nullptr, *tmp = nullptr;
-    HIP_TRY(hipMalloc(&Atmp, sizeof(double) * g->n_pad * g->lda));
-    if (hipMalloc(&tmp, sizeof(double) * g->n * g->n) != hipSuccess) { hipFree(Atmp); return fail(CBO_ERR_HIP, "hipMalloc"); }
+    // scratch: [n_pad x lda] assembly + [n x n] symmetric export, from the context's grow-only export buffer
+    const size_t a_elems = (size_t)g->n_pad * (size_t)g->lda;
+    int rc = ensure_export(c, a_elems + (size_t)g->n * (size_t)g->n);
+    if (rc != CBO_OK) return rc;
+    double *Atmp = c->export_buf, *tmp = c->export_buf + a_elems;
     launch_kxx(c->stream, g->X, g->h, g->noise_var + kGpyDiagJitter, 0.0, Atmp, g->lda, g->n_pad);
     launch_export_sym(c->stream, Atmp, g->lda, g->n, tmp);
-    hipError_t e = hipMemcpyAsync(K_out, tmp, sizeof(double) * g->n * g->n, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(Atmp);
-    hipFree(tmp);
-    HIP_TRY(e);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(K_out, tmp, sizeof(double) * g->n * g->n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return CBO_OK;
 }
 
 // ---- candidates ----------------------------------------------------------------------------------
-extern "C" int cbo_cands_create(cbo_ctx *c, int64_t m, int d, const double *Xs, const double *pm, const double *pv,
-                                int64_t index_offset, cbo_cands **out)
+// buffers for m points of dimension d (with prior closures if `prior`): grow-only, nothing happens when they fit
+static int cands_reserve(cbo_cands *k, int64_t m, int d, bool prior)
 {
-    if (!c || !out || !Xs) return fail(CBO_ERR_INVALID, "NULL argument");
+    cbo_ctx *c = k->ctx;
+    const int64_t m_pad = round_up(m, kStrip);
+    if (m_pad > k->cap_m_pad || d > k->cap_d || (prior && !k->cap_prior)) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const int64_t cap = m_pad > k->cap_m_pad ? m_pad : k->cap_m_pad;
+        const int cd = d > k->cap_d ? d : k->cap_d;
+        const bool cp = prior || k->cap_prior;
+        hipFree(k->raw); hipFree(k->P.xs); hipFree(k->P.sq); hipFree(k->P.sv); hipFree(k->pm); hipFree(k->pv);
+        hipFree(k->q); hipFree(k->mu);
+        k->raw = k->P.xs = k->P.sq = k->P.sv = k->pm = k->pv = k->q = k->mu = nullptr;
+        k->cap_m_pad = 0; k->cap_d = 0; k->cap_prior = false; k->fit_stamp = 0;
+        hipError_t e = hipMalloc(&k->raw, sizeof(double) * cap * cd);
+        if (e == hipSuccess) e = hipMalloc(&k->P.xs, sizeof(double) * cd * cap);
+        if (e == hipSuccess) e = hipMalloc(&k->P.sq, sizeof(double) * cap);
+        if (e == hipSuccess && cp) e = hipMalloc(&k->P.sv, sizeof(double) * cap);
+        if (e == hipSuccess && cp) e = hipMalloc(&k->pm, sizeof(double) * cap);
+        if (e == hipSuccess && cp) e = hipMalloc(&k->pv, sizeof(double) * cap);
+        if (e != hipSuccess) return fail(CBO_ERR_HIP, std::string("candidate buffers: ") + hipGetErrorString(e));
+        k->cap_m_pad = cap; k->cap_d = cd; k->cap_prior = cp;
+    }
+    return CBO_OK;
+}
+
+// (re)fill a candidate set from host arrays; every cache keyed on its old contents is dropped
+static int cands_fill(cbo_cands *k, int64_t m, int d, const double *Xs, const double *pm, const double *pv,
+                      int64_t index_offset)
+{
+    cbo_ctx *c = k->ctx;
+    int rc = cands_reserve(k, m, d, pv != nullptr);
+    if (rc != CBO_OK) return rc;
+    k->m = m; k->d = d; k->index_offset = index_offset;
+    k->m_pad = round_up(m, kStrip);
+    k->P.n = m; k->P.ld = k->m_pad; k->P.d = d;
+    k->has_prior = pv != nullptr;
+    k->prepared_for = nullptr; k->prepared_ls.clear();
+    k->fit_stamp = 0; k->v_stamp = 0;
+    hipError_t e = hipMemcpyAsync(k->raw, Xs, sizeof(double) * m * d, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && pv) e = hipMemcpyAsync(k->pm, pm, sizeof(double) * m, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && pv) e = hipMemcpyAsync(k->pv, pv, sizeof(double) * m, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);           // the host buffers are the caller's
+    if (e != hipSuccess) return fail(CBO_ERR_HIP, std::string("candidate upload: ") + hipGetErrorString(e));
+    return CBO_OK;
+}
+
+static int check_cands_args(cbo_ctx *c, int64_t m, int d, const double *Xs, const double *pm, const double *pv)
+{
+    if (!c || !Xs) return fail(CBO_ERR_INVALID, "NULL argument");
     if (m <= 0) return fail(CBO_ERR_INVALID, "m must be positive");
     if (d < 1 || d > CBO_MAX_DIM) return fail(CBO_ERR_INVALID, "d must be in [1, CBO_MAX_DIM]");
     if ((pm == nullptr) != (pv == nullptr))
         return fail(CBO_ERR_INVALID, "prior mean and prior variance must be given together");
+    return CBO_OK;
+}
+
+extern "C" int cbo_cands_create(cbo_ctx *c, int64_t m, int d, const double *Xs, const double *pm, const double *pv,
+                                int64_t index_offset, cbo_cands **out)
+{
+    if (!out) return fail(CBO_ERR_INVALID, "NULL argument");
+    int rc = check_cands_args(c, m, d, Xs, pm, pv);
+    if (rc != CBO_OK) return rc;
     HIP_TRY(hipSetDevice(c->device));
     cbo_cands *k = new cbo_cands();
-    k->ctx = c; k->m = m; k->d = d; k->index_offset = index_offset;
-    k->m_pad = round_up(m, kStrip);
-    hipError_t e = hipMalloc(&k->raw, sizeof(double) * m * d);
-    if (e == hipSuccess) e = hipMalloc(&k->P.xs, sizeof(double) * d * k->m_pad);
-    if (e == hipSuccess) e = hipMalloc(&k->P.sq, sizeof(double) * k->m_pad);
-    if (e == hipSuccess && pv) e = hipMalloc(&k->P.sv, sizeof(double) * k->m_pad);
-    if (e == hipSuccess && pv) e = hipMalloc(&k->pm, sizeof(double) * k->m_pad);
-    if (e == hipSuccess && pv) e = hipMalloc(&k->pv, sizeof(double) * k->m_pad);
-    if (e == hipSuccess) e = hipMemcpyAsync(k->raw, Xs, sizeof(double) * m * d, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess && pv) e = hipMemcpyAsync(k->pm, pm, sizeof(double) * m, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess && pv) e = hipMemcpyAsync(k->pv, pv, sizeof(double) * m, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) {
-        cbo_cands_destroy(k);
-        return fail(CBO_ERR_HIP, std::string("cbo_cands_create: ") + hipGetErrorString(e));
-    }
-    k->P.n = m; k->P.ld = k->m_pad; k->P.d = d;
+    k->ctx = c;
+    rc = cands_fill(k, m, d, Xs, pm, pv, index_offset);
+    if (rc != CBO_OK) { cbo_cands_destroy(k); return rc; }
     *out = k;
+    return CBO_OK;
+}
+
+// the context's reusable candidate set for the host-buffer entry points (no allocation once it has grown)
+static int scratch_cands(cbo_ctx *c, int64_t m, int d, const double *Xs, const double *pm, const double *pv,
+                         cbo_cands **out)
+{
+    int rc = check_cands_args(c, m, d, Xs, pm, pv);
+    if (rc != CBO_OK) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->scratch_k) { c->scratch_k = new cbo_cands(); c->scratch_k->ctx = c; }
+    rc = cands_fill(c->scratch_k, m, d, Xs, pm, pv, 0);
+    if (rc != CBO_OK) return rc;
+    *out = c->scratch_k;
     return CBO_OK;
 }
 
@@ -837,8 +916,8 @@ static int prepare_cands(cbo_gp *g, cbo_cands *k)
 {
     cbo_ctx *c = g->ctx;
     if (k->prepared_for == g && k->prepared_ls == g->ls) return CBO_OK;
-    launch_prep_points(c->stream, k->raw, k->m, k->d, g->h.ard ? g->ls_dev : nullptr, k->pv, k->P.xs, k->m_pad,
-                       k->P.sq, k->P.sv);
+    launch_prep_points(c->stream, k->raw, k->m, k->d, g->h.ard ? g->ls_dev : nullptr, k->has_prior ? k->pv : nullptr,
+                       k->P.xs, k->m_pad, k->P.sq, k->has_prior ? k->P.sv : nullptr);
     HIP_TRY(hipGetLastError());
     k->prepared_for = g;
     k->prepared_ls = g->ls;
@@ -951,7 +1030,7 @@ static int enqueue_right_looking(cbo_gp *g, double *V, int64_t ldv, int64_t cols
 static int own_solution_buffer(cbo_gp *g, cbo_cands *k, double **V, int64_t *ldv)
 {
     cbo_ctx *c = g->ctx;
-    if (!k->V || k->v_rows_cap != g->n_pad) {
+    if (!k->V || k->v_rows_cap != g->n_pad || k->v_ld != k->m_pad + kLdExtra) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         hipFree(k->V); hipFree(k->partial);
         k->V = nullptr; k->partial = nullptr; k->v_stamp = 0;
@@ -1059,7 +1138,7 @@ static int check_sweep_args(const cbo_gp *g, const cbo_cands *k, int task)
     if (!g || !k) return fail(CBO_ERR_INVALID, "NULL argument");
     if (g->ctx != k->ctx) return fail(CBO_ERR_INVALID, "gp and candidates live on different contexts");
     if (g->d != k->d) return fail(CBO_ERR_INVALID, "gp and candidates have different dimensions");
-    if ((g->X.sv != nullptr) && (k->pv == nullptr))
+    if ((g->X.sv != nullptr) && !k->has_prior)
         return fail(CBO_ERR_INVALID, "causal gp needs candidate prior mean/variance");
     if (task != CBO_TASK_MIN && task != CBO_TASK_MAX) return fail(CBO_ERR_INVALID, "task must be 0 (min) or 1 (max)");
     return CBO_OK;
@@ -1075,8 +1154,8 @@ static int finish_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task, double
     const bool cached = k->fit_stamp != 0 && k->fit_stamp == g->fit_stamp;
     if (!cached && c->sweep_cache) {
         if (!k->q) {
-            HIP_TRY(hipMalloc(&k->q, sizeof(double) * k->m_pad));
-            HIP_TRY(hipMalloc(&k->mu, sizeof(double) * k->m_pad));
+            HIP_TRY(hipMalloc(&k->q, sizeof(double) * k->cap_m_pad));
+            HIP_TRY(hipMalloc(&k->mu, sizeof(double) * k->cap_m_pad));
         }
         HIP_TRY(hipMemcpyAsync(k->q, c->q, sizeof(double) * k->m_pad, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(k->mu, c->mu, sizeof(double) * k->m_pad, hipMemcpyDeviceToDevice, c->stream));
@@ -1187,15 +1266,13 @@ extern "C" int cbo_gp_append(cbo_gp *g, const double *x_new, double y_new, doubl
     launch_gather_column(c->stream, c->V, ldv, g->n_pad, g->alpha + g->n_pad);      // work vector (alpha's scratch half)
     launch_forward_vec(c->stream, g->A, g->lda, g->n_pad, g->invDt, g->alpha + g->n_pad, g->lvec);
     HIP_TRY(hipGetLastError());
-    std::vector<double> hl((size_t)g->n), hz((size_t)g->n);
-    HIP_TRY(hipMemcpyAsync(hl.data(), g->lvec, sizeof(double) * g->n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(hz.data(), g->z, sizeof(double) * g->n, hipMemcpyDeviceToHost, c->stream));
+    // l^T z and l^T l by one device reduction (16 bytes come back)
+    launch_dot2(c->stream, g->lvec, g->z, g->n, c->part_val);
+    HIP_TRY(hipGetLastError());
+    double hd[2];
+    HIP_TRY(hipMemcpyAsync(hd, c->part_val, sizeof(hd), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    double h2[2] = {0.0, 0.0};
-    for (int64_t i = 0; i < g->n; ++i) {
-        h2[0] = std::fma(hl[(size_t)i], hl[(size_t)i], h2[0]);
-        h2[1] = std::fma(hl[(size_t)i], hz[(size_t)i], h2[1]);
-    }
+    const double h2[2] = {hd[1], hd[0]};                    // {l^T l, l^T z}
     g->alpha_ready = false;                                 // its scratch half was used
     const double kappa = g->h.variance + (causal ? prior_var_new : 0.0) + (g->noise_var + kGpyDiagJitter);
     const double d2 = kappa - h2[0];
@@ -1473,11 +1550,34 @@ extern "C" int cbo_acq_sweep_host(cbo_gp *g, int64_t m, const double *Xs, const 
 {
     if (!g) return fail(CBO_ERR_INVALID, "gp is NULL");
     cbo_cands *k = nullptr;
-    int rc = cbo_cands_create(g->ctx, m, g->d, Xs, pm, pv, 0, &k);
+    int rc = scratch_cands(g->ctx, m, g->d, Xs, pm, pv, &k);
     if (rc != CBO_OK) return rc;
-    rc = cbo_acq_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, nullptr, nullptr, best_val, best_idx);
-    cbo_cands_destroy(k);
-    return rc;
+    return cbo_acq_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, nullptr, nullptr, best_val, best_idx);
+}
+
+// posterior mean / variance of m host points into the context's mean / var vectors (device), via the scratch set
+static int posterior_of_host_points(cbo_gp *g, int64_t m, const double *Xs, const double *pm, const double *pv,
+                                    int include_noise, cbo_cands **k_out)
+{
+    const bool causal = g->X.sv != nullptr;
+    if (causal && (!pm || !pv)) return fail(CBO_ERR_INVALID, "causal gp needs candidate prior mean/variance");
+    cbo_ctx *c = g->ctx;
+    cbo_cands *k = nullptr;
+    int rc = scratch_cands(c, m, g->d, Xs, causal ? pm : nullptr, causal ? pv : nullptr, &k);
+    if (rc != CBO_OK) return rc;
+    rc = enqueue_posterior(g, k);
+    if (rc != CBO_OK) return rc;
+    AcqParams p;
+    p.variance = g->h.variance; p.noise_var = g->noise_var; p.y_best = 0.0; p.ei_jitter = 0.0; p.cost = 1.0;
+    p.task = CBO_TASK_MIN; p.include_noise = include_noise ? 1 : 0; p.want_ei = 0;
+    {
+        PhaseScope ps(c, PH_ACQ);
+        launch_acq(c->stream, c->q, c->mu, causal ? k->pm : nullptr, causal ? k->pv : nullptr, m, p, c->mean, c->var,
+                   nullptr, c->part_val, c->part_idx, 0, acq_blocks_for(m));
+    }
+    HIP_TRY(hipGetLastError());
+    *k_out = k;
+    return CBO_OK;
 }
 
 extern "C" int cbo_gp_predict(cbo_gp *g, int64_t m, const double *Xs, const double *pm, const double *pv,
@@ -1485,31 +1585,15 @@ extern "C" int cbo_gp_predict(cbo_gp *g, int64_t m, const double *Xs, const doub
 {
     if (!g || !mean_out || !var_out) return fail(CBO_ERR_INVALID, "NULL argument");
     if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
-    const bool causal = g->X.sv != nullptr;
-    if (causal && (!pm || !pv)) return fail(CBO_ERR_INVALID, "causal gp needs candidate prior mean/variance");
     cbo_ctx *c = g->ctx;
     cbo_cands *k = nullptr;
-    int rc = cbo_cands_create(c, m, g->d, Xs, causal ? pm : nullptr, causal ? pv : nullptr, 0, &k);
+    int rc = posterior_of_host_points(g, m, Xs, pm, pv, include_noise, &k);
     if (rc != CBO_OK) return rc;
-    rc = enqueue_posterior(g, k);
-    if (rc == CBO_OK) {
-        AcqParams p;
-        p.variance = g->h.variance; p.noise_var = g->noise_var; p.y_best = 0.0; p.ei_jitter = 0.0; p.cost = 1.0;
-        p.task = CBO_TASK_MIN; p.include_noise = include_noise ? 1 : 0; p.want_ei = 0;
-        {
-            PhaseScope ps(c, PH_ACQ);
-            launch_acq(c->stream, c->q, c->mu, k->pm, k->pv, m, p, c->mean, c->var, nullptr, c->part_val, c->part_idx,
-                       0, acq_blocks_for(m));
-        }
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(mean_out, c->mean, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(var_out, c->var, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) rc = fail(CBO_ERR_HIP, std::string("cbo_gp_predict: ") + hipGetErrorString(e));
-        if (c->profiling) c->timers.n_sweep += 1;
-    }
-    cbo_cands_destroy(k);
-    return rc;
+    HIP_TRY(hipMemcpyAsync(mean_out, c->mean, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(var_out, c->var, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->profiling) c->timers.n_sweep += 1;
+    return CBO_OK;
 }
 
 extern "C" int cbo_gp_set_hyper(cbo_gp *g, double variance, const double *lengthscale, double noise_var)
@@ -1603,14 +1687,14 @@ extern "C" int cbo_gp_lml_gradients(cbo_gp *g, double *lml_out, double *dvarianc
     launch_lml_grad(c->stream, g->X, g->h, g->alpha, c->W, ldw, n_pad, c->gpart, c->part_val);
     launch_lml_terms(c->stream, g->A, g->lda, n_pad, g->z, c->part_val + 16);
     HIP_TRY(hipGetLastError());
-    double hs[18];
-    std::vector<double> hq((size_t)g->n), ha((size_t)g->n);
+    // tr(Ky^-1) = sum q and alpha^T alpha by device reductions: part_val[20..23]
+    launch_dot2(c->stream, g->alpha, g->alpha, g->n, c->part_val + 20);
+    launch_sum(c->stream, c->q, g->n, c->part_val + 22);
+    HIP_TRY(hipGetLastError());
+    double hs[24];
     HIP_TRY(hipMemcpyAsync(hs, c->part_val, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(hq.data(), c->q, sizeof(double) * g->n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(ha.data(), g->alpha, sizeof(double) * g->n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    double tr_w = 0.0, aa = 0.0;
-    for (int64_t i = 0; i < g->n; ++i) { tr_w += hq[(size_t)i]; aa += ha[(size_t)i] * ha[(size_t)i]; }
+    const double tr_w = hs[22], aa = hs[20];
     *dvariance_out = 0.5 * hs[0] / g->h.variance;
     if (g->h.ard) {
         for (int k = 0; k < g->d; ++k) dlengthscale_out[k] = 0.5 * hs[1 + k] / g->ls[(size_t)k];
@@ -1624,52 +1708,89 @@ extern "C" int cbo_gp_lml_gradients(cbo_gp *g, double *lml_out, double *dvarianc
     return CBO_OK;
 }
 
+// the reversed factor of the backward substitution (kernels_kmat.hip), once per fit
+static int ensure_reversed_factor(cbo_gp *g)
+{
+    cbo_ctx *c = g->ctx;
+    if (!g->T) {
+        HIP_TRY(hipMalloc(&g->T, sizeof(double) * (size_t)g->n_pad * (size_t)g->lda));
+        HIP_TRY(hipMalloc(&g->invT, sizeof(double) * (size_t)(g->n_pad / 16) * 256));
+        g->t_stamp = 0;
+    }
+    if (g->t_stamp != g->fit_stamp) {
+        launch_reversed_factor(c->stream, g->A, g->lda, g->n_pad, g->invDt, g->T, g->lda, g->invT);
+        HIP_TRY(hipGetLastError());
+        g->t_stamp = g->fit_stamp;
+    }
+    return CBO_OK;
+}
+
+// Gradients of the posterior at a batch of points, any size: per workspace chunk, V = L^-1 K* by the forward sweep,
+// W = L^-T V by the SAME strip kernel on the reversed system (the factor read backwards is lower triangular again),
+// then one pass that forms both gradients from alpha and W.  Nothing is allocated once the workspaces have grown.
 extern "C" int cbo_gp_predict_gradients(cbo_gp *g, int64_t m, const double *Xs, const double *pv_s, double *dmean_out,
                                         double *dvar_out)
 {
     if (!g || !Xs || !dmean_out || !dvar_out) return fail(CBO_ERR_INVALID, "NULL argument");
-    if (m <= 0 || m > 4096) return fail(CBO_ERR_INVALID, "m must be in [1, 4096] (one backward solve per point)");
+    if (m <= 0) return fail(CBO_ERR_INVALID, "m must be positive");
     if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
     cbo_ctx *c = g->ctx;
     HIP_TRY(hipSetDevice(c->device));
     const bool causal = g->X.sv != nullptr;
     if (causal && !pv_s) return fail(CBO_ERR_INVALID, "causal gp needs the prior variance at the prediction points");
-    // the prior mean does not enter the gradients (GPy ignores the mean function there); zeros stand in
-    std::vector<double> zeros;
-    if (causal) zeros.assign((size_t)m, 0.0);
+    // the prior mean does not enter the gradients (GPy ignores the mean function there): the variances stand in
     cbo_cands *k = nullptr;
-    int rc = cbo_cands_create(c, m, g->d, Xs, causal ? zeros.data() : nullptr, causal ? pv_s : nullptr, 0, &k);
+    int rc = scratch_cands(c, m, g->d, Xs, causal ? pv_s : nullptr, causal ? pv_s : nullptr, &k);
     if (rc != CBO_OK) return rc;
-    double *W = nullptr, *work = nullptr, *grads = nullptr, *inv_ls = nullptr;
-    auto cleanup = [&]() { hipFree(W); hipFree(work); hipFree(grads); hipFree(inv_ls); cbo_cands_destroy(k); };
-    rc = ensure_alpha(g);
-    if (rc == CBO_OK) rc = enqueue_posterior(g, k, true);      // V = L^-1 K* (fp64 workspace)
+    rc = prepare_cands(g, k);
+    if (rc == CBO_OK) rc = ensure_alpha(g);
+    if (rc == CBO_OK) rc = ensure_reversed_factor(g);
+    if (rc != CBO_OK) return rc;
+    // two workspaces of the same shape: V (forward) and W (backward); halve the budget so that both fit it
     int64_t chunk = 0, ldv = 0;
-    if (rc == CBO_OK) rc = ensure_workspaces(c, g->n_pad, k->m_pad, &chunk, &ldv);
-    if (rc == CBO_OK && chunk < k->m_pad) rc = fail(CBO_ERR_INVALID, "too many points for one workspace chunk");
-    if (rc != CBO_OK) { cleanup(); return rc; }
-    hipError_t e = hipMalloc(&W, sizeof(double) * (size_t)m * g->n_pad);
-    if (e == hipSuccess) e = hipMalloc(&work, sizeof(double) * g->n_pad);
-    if (e == hipSuccess) e = hipMalloc(&grads, sizeof(double) * 2 * (size_t)m * g->d);
-    if (e == hipSuccess && g->h.ard) {
-        std::vector<double> il(g->d);
-        for (int i = 0; i < g->d; ++i) il[i] = 1.0 / g->ls[i];
-        e = hipMalloc(&inv_ls, sizeof(double) * g->d);
-        if (e == hipSuccess) e = hipMemcpyAsync(inv_ls, il.data(), sizeof(double) * g->d, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    const size_t saved_cap = c->max_ws_bytes;
+    c->max_ws_bytes = saved_cap / 2;
+    rc = ensure_workspaces(c, g->n_pad, k->m_pad, &chunk, &ldv);
+    c->max_ws_bytes = saved_cap;
+    if (rc != CBO_OK) return rc;
+    const size_t w_bytes = sizeof(double) * (size_t)g->n_pad * (size_t)ldv;
+    const size_t grad_elems = 2 * (size_t)k->m_pad * (size_t)g->d;
+    if (w_bytes > c->W_bytes || grad_elems > c->grads_elems || (g->h.ard && !g->inv_ls_dev)) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (w_bytes > c->W_bytes) {
+            hipFree(c->W);
+            c->W = nullptr; c->W_bytes = 0;
+            HIP_TRY(hipMalloc(&c->W, w_bytes));
+            c->W_bytes = w_bytes;
+        }
+        if (grad_elems > c->grads_elems) {
+            hipFree(c->grads);
+            c->grads = nullptr; c->grads_elems = 0;
+            HIP_TRY(hipMalloc(&c->grads, sizeof(double) * grad_elems));
+            c->grads_elems = grad_elems;
+        }
+        if (g->h.ard && !g->inv_ls_dev) HIP_TRY(hipMalloc(&g->inv_ls_dev, sizeof(double) * CBO_MAX_DIM));
     }
-    if (e == hipSuccess) {
-        // w_c = L^-T (L^-1 k*_c) = Ky^-1 k*_c, one backward solve per point
-        for (int64_t col = 0; col < m; ++col)
-            launch_backsolve_vec(c->stream, g->A, g->lda, g->n_pad, g->invDt, c->V + col, ldv, work, W + col * g->n_pad);
-        launch_pred_gradients(c->stream, g->X, k->P, m, g->h, inv_ls, g->alpha, W, g->n_pad, grads, grads + m * g->d);
-        e = hipGetLastError();
+    if (g->h.ard) {
+        double il[CBO_MAX_DIM] = {0};
+        for (int i = 0; i < g->d; ++i) il[i] = 1.0 / g->ls[(size_t)i];
+        HIP_TRY(hipMemcpyAsync(g->inv_ls_dev, il, sizeof(double) * g->d, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));               // `il` lives in this frame
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(dmean_out, grads, sizeof(double) * m * g->d, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dvar_out, grads + m * g->d, sizeof(double) * m * g->d, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    cleanup();
-    if (e != hipSuccess) return fail(CBO_ERR_HIP, std::string("cbo_gp_predict_gradients: ") + hipGetErrorString(e));
+    double *dmean = c->grads, *dvar = c->grads + (size_t)k->m_pad * g->d;
+    for (int64_t c0 = 0; c0 < k->m_pad; c0 += chunk) {
+        const int64_t cols = (k->m_pad - c0 < chunk) ? (k->m_pad - c0) : chunk;
+        launch_kstar(c->stream, g->X, k->P, c0, cols, g->h, c->V, ldv, g->n_pad);
+        launch_trsm_strips(c->stream, g->A, g->lda, g->invDt, c->V, ldv, g->n_pad, cols, nullptr, nullptr, nullptr);
+        launch_reverse_rows(c->stream, c->V, ldv, g->n_pad, cols, c->W, ldv);
+        launch_trsm_strips(c->stream, g->T, g->lda, g->invT, c->W, ldv, g->n_pad, cols, nullptr, nullptr, nullptr);
+        launch_pred_gradients(c->stream, g->X, g->n_pad, k->P, c0, cols, m, g->h, g->inv_ls_dev, g->alpha, c->W, ldv,
+                              dmean, dvar);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(dmean_out, dmean, sizeof(double) * m * g->d, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(dvar_out, dvar, sizeof(double) * m * g->d, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return CBO_OK;
 }
 
@@ -1679,31 +1800,19 @@ extern "C" int cbo_gp_predict_grouped(cbo_gp *g, int64_t m_groups, int64_t group
     if (!g || !mean_out || !var_out || !Xs) return fail(CBO_ERR_INVALID, "NULL argument");
     if (m_groups <= 0 || group <= 0) return fail(CBO_ERR_INVALID, "m_groups and group must be positive");
     if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
-    const bool causal = g->X.sv != nullptr;
-    if (causal && (!pm || !pv)) return fail(CBO_ERR_INVALID, "causal gp needs candidate prior mean/variance");
     cbo_ctx *c = g->ctx;
     const int64_t m = m_groups * group;
     cbo_cands *k = nullptr;
-    int rc = cbo_cands_create(c, m, g->d, Xs, causal ? pm : nullptr, causal ? pv : nullptr, 0, &k);
+    int rc = posterior_of_host_points(g, m, Xs, pm, pv, include_noise, &k);
     if (rc != CBO_OK) return rc;
-    rc = enqueue_posterior(g, k);
-    if (rc == CBO_OK) {
-        AcqParams p;
-        p.variance = g->h.variance; p.noise_var = g->noise_var; p.y_best = 0.0; p.ei_jitter = 0.0; p.cost = 1.0;
-        p.task = CBO_TASK_MIN; p.include_noise = include_noise ? 1 : 0; p.want_ei = 0;
-        launch_acq(c->stream, c->q, c->mu, k->pm, k->pv, m, p, c->mean, c->var, nullptr, c->part_val, c->part_idx, 0,
-                   acq_blocks_for(m));
-        // group means into the (now free) q / mu vectors
-        launch_group_mean(c->stream, c->mean, m_groups, group, c->q);
-        launch_group_mean(c->stream, c->var, m_groups, group, c->mu);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(mean_out, c->q, sizeof(double) * m_groups, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(var_out, c->mu, sizeof(double) * m_groups, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) rc = fail(CBO_ERR_HIP, std::string("cbo_gp_predict_grouped: ") + hipGetErrorString(e));
-    }
-    cbo_cands_destroy(k);
-    return rc;
+    // group means into the (now free) q / mu vectors
+    launch_group_mean(c->stream, c->mean, m_groups, group, c->q);
+    launch_group_mean(c->stream, c->var, m_groups, group, c->mu);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(mean_out, c->q, sizeof(double) * m_groups, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(var_out, c->mu, sizeof(double) * m_groups, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CBO_OK;
 }
 
 // ---- tiny host-side reductions -------------------------------------------------------------------

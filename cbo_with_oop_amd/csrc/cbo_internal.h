@@ -145,11 +145,18 @@ void launch_forward_vec(hipStream_t s, const double *A, int64_t lda, int64_t n_p
 void launch_gather_column(hipStream_t s, const double *V, int64_t ldv, int64_t n_pad, double *dst);
 void launch_backsolve_vec(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt,
                           const double *src, int64_t src_stride, double *work, double *out);
-// Gradients of the posterior mean and variance w.r.t. the prediction inputs (GPy predictive_gradients):
-// dmean[c][k] = sum_i alpha_i dk(x_i, x*_c)/dx*_k, dvar[c][k] = -2 sum_i W[c][i] dk(x_i, x*_c)/dx*_k (RBF part only).
-void launch_pred_gradients(hipStream_t s, const PointSet &X, const PointSet &C, int64_t m, const KernelHyper &h,
-                           const double *inv_ls_dev /* d values: 1/l per dim */, const double *alpha, const double *W,
-                           int64_t ldw, double *dmean, double *dvar);
+// Gradients of the posterior mean and variance w.r.t. the prediction inputs (GPy predictive_gradients), batched:
+// dmean[c][k] = sum_i alpha_i dk(x_i, x*_c)/dx*_k, dvar[c][k] = -2 sum_i w_ic dk(x_i, x*_c)/dx*_k (RBF part only) for the
+// `cols` workspace columns that hold candidates [c_begin, c_begin + cols); W = Ky^-1 K* in reversed row order.
+void launch_pred_gradients(hipStream_t s, const PointSet &X, int64_t n_pad, const PointSet &C, int64_t c_begin,
+                           int64_t cols, int64_t m, const KernelHyper &h, const double *inv_ls_dev, const double *alpha,
+                           const double *W, int64_t ldw, double *dmean, double *dvar);
+// the factor for the backward substitution through the forward strip kernel (kernels_kmat.hip), row reversal, dot pair
+void launch_reversed_factor(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt, double *T,
+                            int64_t ldt, double *invT);
+void launch_reverse_rows(hipStream_t s, const double *V, int64_t ldv, int64_t n_pad, int64_t cols, double *W, int64_t ldw);
+void launch_dot2(hipStream_t s, const double *a, const double *b, int64_t n, double *out2);
+void launch_sum(hipStream_t s, const double *a, int64_t n, double *out);
 
 // V <- L^-1 V on m_pad columns (64-column strips); optional q[c] = sum_i V[i][c]^2, mu[c] = sum_i V[i][c] z[i].
 void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const double *invDt, double *V, int64_t ldv,

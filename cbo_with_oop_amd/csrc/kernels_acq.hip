@@ -96,19 +96,23 @@ void launch_group_mean(hipStream_t s, const double *in, int64_t n_groups, int64_
 // get_prediction_gradients, /root/reference/src/utils_functions/causal_acquisition_functions.py:54):
 //   dk(x_i, x*)/dx*_k = k(x_i, x*) (x_ik - x*_k) / l_k^2      (stationary RBF part; GPy's Stationary.gradients_X,
 //   which CausalRBF inherits, ignores the rank-1 causal term -- SURVEY.md §A.2)
-// One workgroup per prediction point, threads stride over the observations, block reduction per dimension.
+//   dmean[c][k] = sum_i alpha_i dk/dx*_k,    dvar[c][k] = -2 sum_i w_ic dk/dx*_k,   w_c = Ky^-1 k*(x_c)
+// for a whole batch of points: W holds the w_c as COLUMNS of the workspace the backward substitution wrote, in
+// reversed row order (W[n_pad-1-i][c] = w_ic, see reversed_factor_kernel).  One workgroup per 64 points: lane = point
+// (coalesced W reads), the four waves split the observations, LDS reduction at the end.
 // Coordinates are the (ARD-)scaled SoA copies: u = x / l, so dk/dx*_k = k (u_ik - u*_k) * inv_l_k.
 __global__ __launch_bounds__(256) void pred_gradients_kernel(const double *__restrict__ xs, int64_t ldx, int64_t n,
-                                                             const double *__restrict__ cs, int64_t ldc, int d,
-                                                             double variance, double iso_inv_l,
-                                                             const double *__restrict__ inv_ls,
+                                                             int64_t n_pad, const double *__restrict__ cs, int64_t ldc,
+                                                             int64_t c_begin, int64_t m, int d, double variance,
+                                                             double iso_inv_l, const double *__restrict__ inv_ls,
                                                              const double *__restrict__ alpha,
                                                              const double *__restrict__ W, int64_t ldw,
                                                              double *__restrict__ dmean, double *__restrict__ dvar)
 {
-    __shared__ double red[2 * CBO_MAX_DIM][256];
-    const int64_t c = blockIdx.x;
-    const int tid = threadIdx.x;
+    __shared__ double red[3][2 * CBO_MAX_DIM][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t cl = (int64_t)blockIdx.x * 64 + lane;             // column of this chunk's workspace
+    const int64_t c = c_begin + cl;                                 // candidate
     double xc[CBO_MAX_DIM], gm[CBO_MAX_DIM], gv[CBO_MAX_DIM];
 #pragma unroll
     for (int k = 0; k < CBO_MAX_DIM; ++k) {
@@ -116,8 +120,7 @@ __global__ __launch_bounds__(256) void pred_gradients_kernel(const double *__res
         gm[k] = 0.0;
         gv[k] = 0.0;
     }
-    const double *w = W + c * ldw;
-    for (int64_t i = tid; i < n; i += 256) {
+    for (int64_t i = g; i < n; i += 4) {
         double diff[CBO_MAX_DIM];
         double r2 = 0.0;
 #pragma unroll
@@ -126,42 +129,43 @@ __global__ __launch_bounds__(256) void pred_gradients_kernel(const double *__res
             r2 += diff[k] * diff[k];
         }
         const double kv = variance * exp(-0.5 * r2);
-        const double a = alpha[i] * kv, b = w[i] * kv;
+        const double a = alpha[i] * kv, b = W[(n_pad - 1 - i) * ldw + cl] * kv;
 #pragma unroll
         for (int k = 0; k < CBO_MAX_DIM; ++k) {
-            const double g = diff[k] * (inv_ls ? inv_ls[k] : iso_inv_l);
-            gm[k] += a * g;
-            gv[k] += b * g;
+            const double gk = diff[k] * (inv_ls ? inv_ls[k] : iso_inv_l);
+            gm[k] += a * gk;
+            gv[k] += b * gk;
         }
     }
+    if (g > 0) {
 #pragma unroll
-    for (int k = 0; k < CBO_MAX_DIM; ++k) {
-        red[k][tid] = gm[k];
-        red[CBO_MAX_DIM + k][tid] = gv[k];
+        for (int k = 0; k < CBO_MAX_DIM; ++k) {
+            red[g - 1][k][lane] = gm[k];
+            red[g - 1][CBO_MAX_DIM + k][lane] = gv[k];
+        }
     }
     __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if (tid < st) {
+    if (g == 0 && c < m) {
 #pragma unroll
-            for (int k = 0; k < 2 * CBO_MAX_DIM; ++k) red[k][tid] += red[k][tid + st];
+        for (int k = 0; k < CBO_MAX_DIM; ++k) {
+            if (k < d) {
+                dmean[c * d + k] = ((gm[k] + red[0][k][lane]) + red[1][k][lane]) + red[2][k][lane];
+                dvar[c * d + k] = -2.0 * (((gv[k] + red[0][CBO_MAX_DIM + k][lane]) + red[1][CBO_MAX_DIM + k][lane]) +
+                                          red[2][CBO_MAX_DIM + k][lane]);
+            }
         }
-        __syncthreads();
-    }
-    if (tid < d) {
-        dmean[c * d + tid] = red[tid][0];
-        dvar[c * d + tid] = -2.0 * red[CBO_MAX_DIM + tid][0];
     }
 }
 
-void launch_pred_gradients(hipStream_t s, const PointSet &X, const PointSet &C, int64_t m, const KernelHyper &h,
-                           const double *inv_ls_dev, const double *alpha, const double *W, int64_t ldw, double *dmean,
-                           double *dvar)
+void launch_pred_gradients(hipStream_t s, const PointSet &X, int64_t n_pad, const PointSet &C, int64_t c_begin,
+                           int64_t cols, int64_t m, const KernelHyper &h, const double *inv_ls_dev, const double *alpha,
+                           const double *W, int64_t ldw, double *dmean, double *dvar)
 {
     // ARD: coordinates are already divided by l_k (iso factor 1, per-dimension 1/l_k for the chain rule);
     // isotropic: raw coordinates, one 1/l for both
     const double iso = h.ard ? 1.0 : 1.0 / h.lengthscale;
-    hipLaunchKernelGGL(pred_gradients_kernel, dim3((unsigned)m), dim3(256), 0, s, X.xs, X.ld, X.n, C.xs, C.ld, X.d,
-                       h.variance, iso, h.ard ? inv_ls_dev : nullptr, alpha, W, ldw, dmean, dvar);
+    hipLaunchKernelGGL(pred_gradients_kernel, dim3((unsigned)(cols / 64)), dim3(256), 0, s, X.xs, X.ld, X.n, n_pad, C.xs,
+                       C.ld, c_begin, m, X.d, h.variance, iso, h.ard ? inv_ls_dev : nullptr, alpha, W, ldw, dmean, dvar);
 }
 
 int acq_blocks_for(int64_t m)

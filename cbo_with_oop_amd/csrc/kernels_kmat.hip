@@ -517,6 +517,110 @@ void launch_set_identity(hipStream_t s, double *V, int64_t ldv, int64_t n_pad)
     hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((n_pad * n_pad + 255) / 256)), dim3(256), 0, s, V, ldv, n_pad);
 }
 
+// ---- backward substitution through the forward kernel (prediction gradients for whole grids) -------
+// W = U^-1 V (U upper triangular) is a forward substitution in reversed index order: with P the reversal, P U P is
+// lower triangular, so the strip kernel (which wants the TRANSPOSED lower factor, row-major, upper part) can be handed
+//     T[k][i] = U[n-1-i][n-1-k]   (k <= i)
+// and the diagonal-tile inverses of T, which are those of U read backwards in both indices.  Built once per fit,
+// on first use.  64x64 tiles through LDS so that reads and writes are both row-contiguous.
+__global__ __launch_bounds__(256) void reversed_factor_kernel(const double *__restrict__ A, int64_t lda, int64_t n,
+                                                              double *__restrict__ T, int64_t ldt)
+{
+    __shared__ double tile[64][65];
+    const int64_t ti = blockIdx.y, tj = blockIdx.x;            // tile of T: rows 64 ti.., columns 64 tj..
+    if (tj < ti) return;                                        // T is upper triangular (by tiles)
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    // T[64 ti + a][64 tj + b] = U[n-1-64 tj-b][n-1-64 ti-a]: read U rows (b) contiguous in a
+    for (int b = ty; b < 64; b += 4) {
+        const int64_t ur = n - 1 - (64 * tj + b), uc = n - 1 - (64 * ti + tx);
+        tile[b][tx] = (uc >= ur) ? A[ur * lda + uc] : 0.0;      // tile[b][a] with a = tx
+    }
+    __syncthreads();
+    for (int a = ty; a < 64; a += 4) T[(64 * ti + a) * ldt + 64 * tj + tx] = tile[tx][a];
+}
+
+__global__ __launch_bounds__(256) void reversed_inverses_kernel(const double *__restrict__ invDt, int64_t n_tiles,
+                                                                double *__restrict__ invT)
+{
+    const int64_t b = blockIdx.x;
+    const int k = threadIdx.x >> 4, i = threadIdx.x & 15;
+    invT[b * 256 + k * 16 + i] = invDt[(n_tiles - 1 - b) * 256 + (15 - i) * 16 + (15 - k)];
+}
+
+void launch_reversed_factor(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt, double *T,
+                            int64_t ldt, double *invT)
+{
+    const unsigned nt = (unsigned)(n_pad / 64);
+    hipLaunchKernelGGL(reversed_factor_kernel, dim3(nt, nt), dim3(256), 0, s, A, lda, n_pad, T, ldt);
+    hipLaunchKernelGGL(reversed_inverses_kernel, dim3((unsigned)(n_pad / 16)), dim3(256), 0, s, invDt, n_pad / 16, invT);
+}
+
+// W[n-1-r][c] = V[r][c]: the right-hand sides of the reversed system (16-byte accesses, one row pair per block row)
+__global__ __launch_bounds__(256) void reverse_rows_kernel(const double *__restrict__ V, int64_t ldv, int64_t n,
+                                                           int64_t cols, double *__restrict__ W, int64_t ldw)
+{
+    const int64_t r = blockIdx.y;
+    const int64_t c2 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (c2 >= cols) return;
+    *reinterpret_cast<d2 *>(&W[(n - 1 - r) * ldw + c2]) = *reinterpret_cast<const d2 *>(&V[r * ldv + c2]);
+}
+
+void launch_reverse_rows(hipStream_t s, const double *V, int64_t ldv, int64_t n_pad, int64_t cols, double *W, int64_t ldw)
+{
+    hipLaunchKernelGGL(reverse_rows_kernel, dim3((unsigned)((cols / 2 + 255) / 256), (unsigned)n_pad), dim3(256), 0, s, V,
+                       ldv, n_pad, cols, W, ldw);
+}
+
+// out[0] = sum a_i b_i, out[1] = sum a_i a_i over n entries (one block, fixed order): the two scalars of the
+// append step (l^T z, l^T l) and of the likelihood gradients (tr Ky^-1 = sum q, alpha^T alpha)
+__global__ __launch_bounds__(256) void dot2_kernel(const double *__restrict__ a, const double *__restrict__ b, int64_t n,
+                                                   double *__restrict__ out2)
+{
+    __shared__ double s1[256], s2[256];
+    double x = 0.0, y = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const double ai = a[i];
+        x = __fma_rn(ai, b[i], x);
+        y = __fma_rn(ai, ai, y);
+    }
+    s1[threadIdx.x] = x;
+    s2[threadIdx.x] = y;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            s1[threadIdx.x] = __dadd_rn(s1[threadIdx.x], s1[threadIdx.x + st]);
+            s2[threadIdx.x] = __dadd_rn(s2[threadIdx.x], s2[threadIdx.x + st]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out2[0] = s1[0]; out2[1] = s2[0]; }
+}
+
+// out[0] = sum a_i (one block, fixed order)
+__global__ __launch_bounds__(256) void sum_kernel(const double *__restrict__ a, int64_t n, double *__restrict__ out)
+{
+    __shared__ double s1[256];
+    double x = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) x = __dadd_rn(x, a[i]);
+    s1[threadIdx.x] = x;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) s1[threadIdx.x] = __dadd_rn(s1[threadIdx.x], s1[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s1[0];
+}
+
+void launch_sum(hipStream_t s, const double *a, int64_t n, double *out)
+{
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, s, a, n, out);
+}
+
+void launch_dot2(hipStream_t s, const double *a, const double *b, int64_t n, double *out2)
+{
+    hipLaunchKernelGGL(dot2_kernel, dim3(1), dim3(256), 0, s, a, b, n, out2);
+}
+
 // L (row-major lower, upper zero) from the upper factor U: L[i][k] = U[k][i].
 __global__ void export_lower_kernel(const double *__restrict__ A, int64_t lda, int64_t n, double *__restrict__ L)
 {

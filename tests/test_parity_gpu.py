@@ -1249,3 +1249,33 @@ def test_path_placement_over_ranks_equals_single_process(hip, world):
         assert mode == ("sets" if len(es) >= world else "candidates")
         assert pts == single_pts
         assert np.allclose(vals, single_vals, rtol=1e-13, atol=0)
+
+
+def test_prediction_gradients_for_a_whole_grid(hip, monkeypatch):
+    """cbo_gp_predict_gradients at M = 20480 points (forward sweep + backward substitution through the same strip kernel
+    on the reversed factor), ARD lengthscales, against the oracle; then the same with the workspace cut into chunks."""
+    from cbo_with_oop_amd import _lib
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    rng = np.random.default_rng(8)
+    n, d, M = 500, 3, 20480
+    X = rng.uniform(-4, 4, (n, d))
+    y = np.sin(X).sum(1, keepdims=True) + 0.05 * rng.standard_normal((n, 1))
+    ls = np.array([1.3, 0.8, 2.0])
+    kw = dict(variance=1.5, lengthscale=ls, ard=True, noise_var=1e-3)
+    m = HipGaussianProcess(X, y, **kw)
+    post = O.fit(X, y, variance=1.5, lengthscale=ls, noise_var=1e-3)
+    Xs = rng.uniform(-4, 4, (M, d))
+    dm, dv = m.get_prediction_gradients(Xs)
+    scale_m, scale_v = None, None
+    for a in range(0, M, 4096):
+        dmo, dvo = O.predict_gradients(post, Xs[a:a + 4096])
+        scale_m = max(scale_m or 0.0, np.max(np.abs(dmo)))
+        scale_v = max(scale_v or 0.0, np.max(np.abs(dvo)))
+        assert np.max(np.abs(dm[a:a + 4096] - dmo)) <= 1e-8 * scale_m
+        assert np.max(np.abs(dv[a:a + 4096] - dvo)) <= 1e-7 * scale_v
+    ctx2 = forced_context(monkeypatch, CBO_HIP_WORKSPACE_MB=16)       # 2 x 8 MiB workspaces: 2048-column chunks
+    m2 = HipGaussianProcess(X, y, context=ctx2, **kw)
+    dm2, dv2 = m2.get_prediction_gradients(Xs)
+    assert np.array_equal(dm2, dm) and np.array_equal(dv2, dv)
+    m2.close()
+    ctx2.close()
