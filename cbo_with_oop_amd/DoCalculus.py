@@ -35,8 +35,8 @@ def do_function(gp, observed, intervened_index, index, values):
     values = np.asarray(values, dtype=np.float64)
     if values.ndim == 1:
         values = values[None, :]
-    x = intervened_inputs(observed, intervened_index, values)
-    mean, var = gp.predict_grouped(x, np.asarray(observed).shape[0])
+    # the (M * N_obs, d) intervened inputs are built on the device from `observed` and `values`
+    mean, var = gp.predict_do(observed, intervened_index, values)
     return np.float64(mean if index == 0 else var)
 
 

@@ -163,6 +163,28 @@ class HipGaussianProcess:
                                                     int(include_likelihood), _lib.dptr(mean), _lib.dptr(var)))
         return mean[:, None], var[:, None]
 
+    def predict_do(self, observed, intervened_index, values, include_likelihood=True):
+        """The do-calculus reduction with the inputs built on the device (``cbo_gp_predict_do``): for every row of
+        ``values`` ((M, n_iv)) predict at the rows of ``observed`` ((N_obs, d)) with column j replaced by
+        ``values[:, intervened_index[j]]`` where ``intervened_index[j] >= 0``, and average over the rows
+        (src/DoCalculus.py:59-60, 74-89).  Returns (mean (M,1), var (M,1)); nothing of size M * N_obs exists on the host."""
+        observed = _lib.as_f64(observed)
+        values = _lib.as_f64(values)
+        if values.ndim == 1:
+            values = values[None, :]
+        if observed.ndim != 2 or observed.shape[1] != self.input_dim:
+            raise ValueError(f"observed must be (N_obs, {self.input_dim})")
+        idx = np.ascontiguousarray(intervened_index, dtype=np.int32)
+        if idx.shape != (self.input_dim,):
+            raise ValueError("intervened_index needs one entry per input column")
+        m = values.shape[0]
+        mean, var = np.empty(m), np.empty(m)
+        self.ensure_fitted()
+        _lib.check(self._lib.cbo_gp_predict_do(self._handle, m, observed.shape[0], _lib.dptr(observed), values.shape[1],
+                                               _lib.dptr(values), idx.ctypes.data_as(_lib.c_int_p), int(include_likelihood),
+                                               _lib.dptr(mean), _lib.dptr(var)))
+        return mean[:, None], var[:, None]
+
     def predict_noiseless(self, x):
         return self.predict(x, include_likelihood=False)
 
@@ -311,8 +333,8 @@ class HipGaussianProcess:
     def get_prediction_gradients(self, x):
         """emukit ``GPyModelWrapper.get_prediction_gradients`` -> GPy ``predictive_gradients``:
         (d mean / d x (M,d), d var / d x (M,d)).  As in GPy, the mean function's and the causal rank-1 term's own
-        gradients are not included.  One backward triangular solve per point: meant for the few
-        points of a local refinement, not for grids."""
+        gradients are not included.  Any number of points (a whole grid included): forward and
+        backward substitution of the batch on the device."""
         x = _lib.as_f64(x)
         if x.ndim != 2 or x.shape[1] != self.input_dim:
             raise ValueError(f"x must be (M, {self.input_dim})")

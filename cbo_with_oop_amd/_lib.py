@@ -93,6 +93,8 @@ SIGNATURES = {
                                                 c_double_p]),
     "cbo_gp_predict_grouped": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, c_double_p, c_double_p,
                                               c_double_p, ctypes.c_int, c_double_p, c_double_p]),
+    "cbo_gp_predict_do": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, c_double_p, ctypes.c_int,
+                                         c_double_p, c_int_p, ctypes.c_int, c_double_p, c_double_p]),
     "cbo_gp_get_posterior": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p]),
     "cbo_gp_assemble_kxx": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
     "cbo_gp_n": (ctypes.c_int64, [ctypes.c_void_p]),

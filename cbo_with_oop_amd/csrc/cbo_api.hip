@@ -1815,6 +1815,61 @@ extern "C" int cbo_gp_predict_grouped(cbo_gp *g, int64_t m_groups, int64_t group
     return CBO_OK;
 }
 
+// Do-calculus prior of a batch of candidate interventions, inputs built on the device (SURVEY.md §8 f1;
+// src/DoCalculus.py:34-89): for candidate c the graph-level GP is evaluated at the n_obs observed input rows with the
+// intervened columns overwritten by values[c], and mean / variance are averaged over those rows.  Only `observed`
+// (n_obs x d) and `values` (m x n_iv) are uploaded; the m * n_obs prediction points exist on the device only.
+extern "C" int cbo_gp_predict_do(cbo_gp *g, int64_t m, int64_t n_obs, const double *observed, int n_iv,
+                                 const double *values, const int *iv_index, int include_noise, double *mean_out,
+                                 double *var_out)
+{
+    if (!g || !observed || !values || !iv_index || !mean_out || !var_out) return fail(CBO_ERR_INVALID, "NULL argument");
+    if (m <= 0 || n_obs <= 0 || n_iv <= 0) return fail(CBO_ERR_INVALID, "m, n_obs and n_iv must be positive");
+    if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
+    if (g->X.sv != nullptr) return fail(CBO_ERR_INVALID, "the do-calculus inputs go to a graph-level (non-causal) gp");
+    for (int j = 0; j < g->d; ++j)
+        if (iv_index[j] >= n_iv) return fail(CBO_ERR_INVALID, "iv_index refers to a column values does not have");
+    cbo_ctx *c = g->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t total = m * n_obs;
+    if (!c->scratch_k) { c->scratch_k = new cbo_cands(); c->scratch_k->ctx = c; }
+    cbo_cands *k = c->scratch_k;
+    int rc = cands_reserve(k, total, g->d, false);
+    if (rc != CBO_OK) return rc;
+    // staging for observed | values | iv_index: the export scratch (device), filled by three small copies
+    const size_t need = (size_t)(n_obs * g->d) + (size_t)(m * n_iv) + CBO_MAX_DIM;
+    rc = ensure_export(c, need);
+    if (rc != CBO_OK) return rc;
+    double *d_obs = c->export_buf, *d_val = d_obs + n_obs * g->d;
+    int *d_idx = reinterpret_cast<int *>(d_val + m * n_iv);
+    HIP_TRY(hipMemcpyAsync(d_obs, observed, sizeof(double) * n_obs * g->d, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_val, values, sizeof(double) * m * n_iv, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_idx, iv_index, sizeof(int) * g->d, hipMemcpyHostToDevice, c->stream));
+    k->m = total; k->d = g->d; k->index_offset = 0;
+    k->m_pad = round_up(total, kStrip);
+    k->P.n = total; k->P.ld = k->m_pad; k->P.d = g->d;
+    k->has_prior = false;
+    k->prepared_for = nullptr; k->prepared_ls.clear();
+    k->fit_stamp = 0; k->v_stamp = 0;
+    launch_expand_interventions(c->stream, d_obs, n_obs, g->d, d_val, n_iv, d_idx, m, k->raw);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));               // the host buffers are the caller's
+    rc = enqueue_posterior(g, k);
+    if (rc != CBO_OK) return rc;
+    AcqParams p;
+    p.variance = g->h.variance; p.noise_var = g->noise_var; p.y_best = 0.0; p.ei_jitter = 0.0; p.cost = 1.0;
+    p.task = CBO_TASK_MIN; p.include_noise = include_noise ? 1 : 0; p.want_ei = 0;
+    launch_acq(c->stream, c->q, c->mu, nullptr, nullptr, total, p, c->mean, c->var, nullptr, c->part_val, c->part_idx, 0,
+               acq_blocks_for(total));
+    launch_group_mean(c->stream, c->mean, m, n_obs, c->q);
+    launch_group_mean(c->stream, c->var, m, n_obs, c->mu);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(mean_out, c->q, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(var_out, c->mu, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CBO_OK;
+}
+
 // ---- tiny host-side reductions -------------------------------------------------------------------
 static bool host_better(double va, int64_t ia, double vb, int64_t ib)
 {

@@ -157,6 +157,8 @@ void launch_reversed_factor(hipStream_t s, const double *A, int64_t lda, int64_t
 void launch_reverse_rows(hipStream_t s, const double *V, int64_t ldv, int64_t n_pad, int64_t cols, double *W, int64_t ldw);
 void launch_dot2(hipStream_t s, const double *a, const double *b, int64_t n, double *out2);
 void launch_sum(hipStream_t s, const double *a, int64_t n, double *out);
+void launch_expand_interventions(hipStream_t s, const double *observed, int64_t n_obs, int d, const double *values, int n_iv,
+                                 const int *iv_index, int64_t m, double *raw);
 
 // V <- L^-1 V on m_pad columns (64-column strips); optional q[c] = sum_i V[i][c]^2, mu[c] = sum_i V[i][c] z[i].
 void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const double *invDt, double *V, int64_t ldv,

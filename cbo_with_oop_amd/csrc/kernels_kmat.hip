@@ -596,6 +596,32 @@ __global__ __launch_bounds__(256) void dot2_kernel(const double *__restrict__ a,
     if (threadIdx.x == 0) { out2[0] = s1[0]; out2[1] = s2[0]; }
 }
 
+// Do-calculus inputs on the device (src/DoCalculus.py:74-89: the observed inputs of a graph-level GP with the
+// intervened columns overwritten, one copy per candidate): raw[(c * n_obs + r) * d + j] =
+// iv_index[j] >= 0 ? values[c][iv_index[j]] : observed[r][j].  Only observed (n_obs x d) and values (m x n_iv) ever
+// cross the host link.
+__global__ __launch_bounds__(256) void expand_interventions_kernel(const double *__restrict__ observed, int64_t n_obs,
+                                                                   int d, const double *__restrict__ values, int n_iv,
+                                                                   const int *__restrict__ iv_index, int64_t total,
+                                                                   double *__restrict__ raw)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    const int64_t c = p / n_obs, r = p % n_obs;
+    for (int j = 0; j < d; ++j) {
+        const int iv = iv_index[j];
+        raw[p * d + j] = (iv >= 0) ? values[c * n_iv + iv] : observed[r * d + j];
+    }
+}
+
+void launch_expand_interventions(hipStream_t s, const double *observed, int64_t n_obs, int d, const double *values, int n_iv,
+                                 const int *iv_index, int64_t m, double *raw)
+{
+    const int64_t total = m * n_obs;
+    hipLaunchKernelGGL(expand_interventions_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, observed, n_obs,
+                       d, values, n_iv, iv_index, total, raw);
+}
+
 // out[0] = sum a_i (one block, fixed order)
 __global__ __launch_bounds__(256) void sum_kernel(const double *__restrict__ a, int64_t n, double *__restrict__ out)
 {

@@ -24,6 +24,7 @@ class CausalGradientAcquisitionOptimizer:
         self.bounds = space_bounds(space)
         self.grid_shape = list(grid_shape) if grid_shape is not None else default_grid_shape(
             len(self.bounds), budget=num_anchor_points)
+        self._grid, self._grid_model = None, None
 
     def candidates(self):
         return meshgrid_candidates(self.bounds, self.grid_shape)
@@ -44,12 +45,14 @@ class CausalGradientAcquisitionOptimizer:
         """(x_max (1,d), acquisition value at x_max (1,1)) -- emukit ``AcquisitionOptimizerBase.optimize``.
         ``acquisition`` is ``CausalExpectedImprovement(...) / Cost(...)`` (an ``AcquisitionQuotient``) or a bare
         ``CausalExpectedImprovement``."""
-        pts = self.candidates()
-        grid = CandidateGrid(pts, acquisition.model)
-        try:
-            res = acquisition.sweep(grid)
-        finally:
-            grid.close()
+        # the grid of this optimiser stays on the device while the model object is the same (no allocation per call)
+        model = acquisition.model
+        if self._grid is None or self._grid_model is not model:
+            if self._grid is not None:
+                self._grid.close()
+            self._grid, self._grid_model = CandidateGrid(self.candidates(), model), model
+        grid, pts = self._grid, self._grid.points
+        res = acquisition.sweep(grid)
         x = pts[res["best_idx"]][None, :].copy()
         fx = np.array([[res["best_val"]]])
         if refine:

@@ -151,8 +151,9 @@ int cbo_gp_lml_gradients(cbo_gp *gp, double *lml_out, double *dvariance_out, dou
  * src/utils_functions/causal_optimizer.py:59-65.  dmean_out / dvar_out: m*d row-major,
  * d mean / d x and d var / d x.  For the causal kernel GPy differentiates the stationary part only, but the
  * solve Ky^-1 k*(x) behind the variance gradient uses the full kernel, hence prior_var_s = variance_adjustment(Xs)
- * (NULL for the non-causal kernel).  Meant for a handful of points (the refinement of the best grid candidates): the variance gradient needs
- * one backward triangular solve per point. */
+ * (NULL for the non-causal kernel).  Any number of points: the variance gradient's Ky^-1 k*(x) is a forward and a
+ * backward substitution of the whole batch, both by the sweep's strip kernel (the backward one on the factor read
+ * in reversed index order, which is lower triangular again), chunked like a sweep. */
 int cbo_gp_predict_gradients(cbo_gp *gp, int64_t m, const double *Xs, const double *prior_var_s,
                              double *dmean_out, double *dvar_out);
 
@@ -164,6 +165,14 @@ int cbo_gp_predict_gradients(cbo_gp *gp, int64_t m, const double *Xs, const doub
 int cbo_gp_predict_grouped(cbo_gp *gp, int64_t m_groups, int64_t group, const double *Xs,
                            const double *prior_mean_s, const double *prior_var_s, int include_noise,
                            double *mean_out /* m_groups */, double *var_out /* m_groups */);
+
+/* The same reduction with the prediction points built on the device: candidate c's rows are the n_obs rows of
+ * `observed` (n_obs x d, the graph-level GP's inputs) with column j replaced by values[c * n_iv + iv_index[j]] wherever
+ * iv_index[j] >= 0 (DoCalculus.get_intervened_inputs, src/DoCalculus.py:80-89).  Only observed and values cross the
+ * host link -- the m * n_obs points (16384 candidates x 1000 rows = 393 MB for d = 3) never exist on the host.
+ * Non-causal (graph-level) models only. */
+int cbo_gp_predict_do(cbo_gp *gp, int64_t m, int64_t n_obs, const double *observed, int n_iv, const double *values,
+                      const int *iv_index /* d */, int include_noise, double *mean_out /* m */, double *var_out /* m */);
 
 /* Posterior state for inspection / tests (GPy posterior.woodbury_chol, .woodbury_vector).
  * L_out: n*n row-major lower triangle (upper part zero); alpha_out: n. Either may be NULL. */

@@ -1279,3 +1279,28 @@ def test_prediction_gradients_for_a_whole_grid(hip, monkeypatch):
     assert np.array_equal(dm2, dm) and np.array_equal(dv2, dv)
     m2.close()
     ctx2.close()
+
+
+def test_do_calculus_inputs_built_on_the_device(hip):
+    """cbo_gp_predict_do (observed rows + candidate values expanded on the device) equals predict_grouped on the
+    host-expanded (M * N_obs, d) array bit for bit, at a size where that array is a million rows."""
+    from cbo_with_oop_amd.DoCalculus import intervened_inputs
+    from cbo_with_oop_amd.GaussianProcessFactory import GaussianProcessFactory, GaussianProcessType
+    rng = np.random.default_rng(4)
+    n_obs, d, m = 256, 3, 4096
+    obs = rng.normal(size=(n_obs, d))
+    yy = np.sin(obs).sum(1, keepdims=True) + 0.1 * rng.standard_normal((n_obs, 1))
+    gp = GaussianProcessFactory.create(GaussianProcessType.GRAPH_GP, obs, yy, [1.0, 1.0, 10.0, False])
+    values = rng.uniform(-2, 2, (m, 2))
+    index = [1, -1, 0]                                   # column 0 <- values[:, 1], column 2 <- values[:, 0]
+    mean, var = gp.predict_do(obs, index, values)
+    x = intervened_inputs(obs, index, values)
+    assert x.shape == (m * n_obs, d)
+    mean_h, var_h = gp.predict_grouped(x, n_obs)
+    assert np.array_equal(mean, mean_h) and np.array_equal(var, var_h)
+    post = O.fit(obs, yy, noise_var=1e-2)
+    mo, vo = O.predict(post, x[:64 * n_obs])
+    assert np.allclose(mean[:64, 0], mo.reshape(64, n_obs).mean(1), rtol=1e-9, atol=1e-12)
+    assert np.allclose(var[:64, 0], vo.reshape(64, n_obs).mean(1), rtol=1e-7, atol=0)
+    with pytest.raises(Exception):
+        gp.predict_do(obs, [2, -1, 0], values)          # index beyond the columns of values
