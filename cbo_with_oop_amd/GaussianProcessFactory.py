@@ -269,10 +269,9 @@ class HipGaussianProcess:
         ls = np.ascontiguousarray(ls)
         _lib.check(self._lib.cbo_gp_set_hyper(self._handle, float(variance), _lib.dptr(ls), float(noise_var)))
         self.variance, self.lengthscale, self.noise_var = float(variance), ls, float(noise_var)
+        self.stale = True            # the device model is unfitted from here on; _fit clears the flag when it succeeds
         if fit:
             self._fit()
-        else:
-            self.stale = True
 
     def rebuild(self, X, Y, fit=True):
         """What the reference obtains by constructing a NEW model on new data (src/CBO.py:224-235 builds one each
@@ -326,7 +325,10 @@ class HipGaussianProcess:
         res = minimize(self._objective, x0, jac=True, method="L-BFGS-B",
                        options={"maxiter": int(max_iters), "maxfun": 15000})
         best = res.x if res.fun <= f0 else x0
-        self._objective(best)                 # leave the model fitted at the optimum
+        if self._objective(best)[0] >= 1e25:  # the factorisation failed at the point the optimiser settled on
+            theta0 = np.exp(x0)               # (GPy restores the previous parameters after a failed step): back to the
+            nl = self.lengthscale.size        # starting point, which was fitted before the optimisation began
+            self.set_hyperparameters(theta0[0], theta0[1:1 + nl], self.noise_var if self.fix_noise else theta0[1 + nl])
         self.optimization_result = res
         return res
 

@@ -412,11 +412,12 @@ __global__ __launch_bounds__(256) void lml_grad_tile_kernel(const double *__rest
                                                             const double *__restrict__ alpha,
                                                             const double *__restrict__ negW, int64_t ldw,
                                                             double variance, double inv_l2_iso,
+                                                            const double *__restrict__ sv /* sqrt(v(X)) or null */,
                                                             double *__restrict__ partial /* [tiles][1 + D] */)
 {
     const int tj = blockIdx.x, ti = blockIdx.y;
     const int tile = ti * gridDim.x + tj;
-    __shared__ double sx[D][64], sy[D][64], sa[64], sb[64];
+    __shared__ double sx[D][64], sy[D][64], sa[64], sb[64], svx[64], svy[64];
     __shared__ double red[256];
     const int tid = threadIdx.x;
     double s[1 + D];
@@ -428,11 +429,13 @@ __global__ __launch_bounds__(256) void lml_grad_tile_kernel(const double *__rest
 #pragma unroll
             for (int k = 0; k < D; ++k) sx[k][tid] = xs[(int64_t)k * ldx + i0 + tid];
             sa[tid] = (i0 + tid < n) ? alpha[i0 + tid] : 0.0;
+            svx[tid] = (sv && i0 + tid < n) ? sv[i0 + tid] : 0.0;
         } else if (tid < 128) {
             const int t = tid - 64;
 #pragma unroll
             for (int k = 0; k < D; ++k) sy[k][t] = xs[(int64_t)k * ldx + j0 + t];
             sb[t] = (j0 + t < n) ? alpha[j0 + t] : 0.0;
+            svy[t] = (sv && j0 + t < n) ? sv[j0 + t] : 0.0;
         }
         __syncthreads();
         const int tx = tid & 63, ty = tid >> 6;                  // column tx, rows ty, ty+4, ...
@@ -451,7 +454,11 @@ __global__ __launch_bounds__(256) void lml_grad_tile_kernel(const double *__rest
             const double kv = variance * exp(-0.5 * r2);
             const double m = (gi == gj ? 1.0 : 2.0) * (sa[ii] * sb[tx] + negW[gi * ldw + gj]);
             const double mk = m * kv;
-            s[0] += mk;
+            // the variance gradient contracts dL_dK with the kernel's own K(X, X) (GPy Stationary.update_gradients_full:
+            // sum(self.K(X, X2) * dL_dK) / variance) -- for CausalRBF that K carries the rank-1 causal term too
+            // (/root/reference/src/utils_functions/causal_kernels.py:45-62, 153-155); the lengthscale gradient goes
+            // through dK_dr, which is the stationary part alone (:84-85)
+            s[0] += mk + m * (svx[ii] * svy[tx]);
 #pragma unroll
             for (int k = 0; k < D; ++k) s[1 + k] = fma(mk, d2k[k], s[1 + k]);
         }
@@ -488,7 +495,7 @@ void launch_lml_grad(hipStream_t s, const PointSet &X, const KernelHyper &h, con
     const double inv_l2 = h.ard ? 1.0 : 1.0 / (h.lengthscale * h.lengthscale);
 #define CBO_LAUNCH_GRAD(D)                                                                                     \
     hipLaunchKernelGGL(lml_grad_tile_kernel<D>, grid, dim3(256), 0, s, X.xs, X.ld, X.n, alpha, negW, ldw, h.variance, \
-                       inv_l2, partial)
+                       inv_l2, X.sv, partial)
     switch (X.d) {
         case 1: CBO_LAUNCH_GRAD(1); break;
         case 2: CBO_LAUNCH_GRAD(2); break;

@@ -210,11 +210,17 @@ def log_marginal_likelihood_gradients(post):
     dK/dtheta by ``kern.update_gradients_full`` (GPy RBF / Stationary: dK/dvariance = K_rbf / variance,
     dK/dlengthscale_k = K_rbf r_k^2 / lengthscale_k with r_k = (x_ik - x_jk) / lengthscale_k, summed over k when not
     ARD) and dL_dthetaL = trace(dL_dK) for the Gaussian noise variance.  The causal rank-1 term of CausalRBF has no
-    parameter of its own.  Returns (dL/dvariance, dL/dlengthscale (array), dL/dnoise_var)."""
+    parameter of its own, but ``CausalRBF.update_gradients_full`` (src/utils_functions/causal_kernels.py:153-155)
+    defers to ``Stationary.update_gradients_full``, whose variance gradient is ``sum(self.K(X, X2) * dL_dK) /
+    variance`` with the kernel's OWN K -- for CausalRBF that K includes the rank-1 term (:45-62).  That quirk (it is
+    not the derivative of the causal kernel with respect to the RBF variance) is what the reference's optimiser
+    follows, so it is restated here; the lengthscale gradient goes through ``dK_dr`` (:84-85), the stationary part
+    alone.  Returns (dL/dvariance, dL/dlengthscale (array), dL/dnoise_var)."""
     ls = np.atleast_1d(np.asarray(post.lengthscale, dtype=np.float64))
     dL_dK = 0.5 * (post.alpha @ post.alpha.T - post.woodbury_inv)
     Krbf = rbf_K(post.X, post.X, post.variance, post.lengthscale)
-    d_var = float(np.sum(dL_dK * Krbf) / post.variance)
+    Kfull = Krbf if post.vX is None else causal_K(post.X, post.X, post.vX, post.vX, post.variance, post.lengthscale)
+    d_var = float(np.sum(dL_dK * Kfull) / post.variance)
     diff2 = (post.X[:, None, :] - post.X[None, :, :]) ** 2                       # (N, N, d)
     if ls.size == 1:
         d_ls = np.array([np.sum(dL_dK * Krbf * diff2.sum(-1)) / ls[0] ** 3])

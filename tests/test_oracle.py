@@ -179,7 +179,17 @@ def test_likelihood_gradients_against_finite_differences():
         def lml(**over):
             return O.log_marginal_likelihood(O.fit(X, y, **{**kw, **over}))
         h = 1e-6
-        assert d_var == pytest.approx((lml(variance=kw["variance"] + h) - lml(variance=kw["variance"] - h)) / (2 * h), rel=1e-6)
+        fd_var = (lml(variance=kw["variance"] + h) - lml(variance=kw["variance"] - h)) / (2 * h)
+        if "vX" in kw:
+            # the reference's quirk (CausalRBF defers to Stationary.update_gradients_full, which contracts dL_dK with
+            # the kernel's own K, rank-1 causal term included): the restated variance gradient is the true derivative
+            # plus sum(dL_dK * sqrt(v) sqrt(v)^T) / variance
+            dL_dK = 0.5 * (post.alpha @ post.alpha.T - post.woodbury_inv)
+            sv = np.sqrt(vX)
+            assert d_var - float(np.sum(dL_dK * (sv @ sv.T))) / kw["variance"] == pytest.approx(fd_var, rel=1e-6)
+            assert abs(d_var - fd_var) > 1e-3 * abs(fd_var)
+        else:
+            assert d_var == pytest.approx(fd_var, rel=1e-6)
         assert d_noise == pytest.approx((lml(noise_var=kw["noise_var"] + h) - lml(noise_var=kw["noise_var"] - h)) / (2 * h), rel=1e-5)
         ls = np.atleast_1d(np.asarray(kw["lengthscale"], dtype=np.float64))
         for k in range(ls.size):
