@@ -288,16 +288,10 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
                     for (int kk = 0; kk < 4; ++kk) uf[h][t][kk] = abase[(16 * h + 4 * kk) * kLdsLd + 16 * t];
             }
             asm volatile("" ::: "memory");                    // keep the reads ahead of the chain
-#pragma unroll
-            for (int h = 0; h < kDT; ++h) {
-                const int s = kDT * m + h;
-                // two independent half-sums: a chain of dependent f64 MFMAs runs at about half the issue rate
-                d4 x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
-                x = MFMA_F64(iv[h][0], -acc[s][0], x);
-                x2 = MFMA_F64(iv[h][1], -acc[s][1], x2);
-                x = MFMA_F64(iv[h][2], -acc[s][2], x);
-                x2 = MFMA_F64(iv[h][3], -acc[s][3], x2);
-                x += x2;
+            // x_s = inv(L_ss) r_s as two independent half-sums (a chain of dependent f64 MFMAs runs at about half the
+            // issue rate); every accumulator receives its updates in the same order in every variant of this kernel
+            // (tile by tile, k ascending), so the schedules stay bit-identical
+            auto emit = [&](int h, int s, const d4 &x) __attribute__((always_inline)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = i0 + 16 * s + kq + 4 * r;
@@ -307,11 +301,57 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
                         macc = fma(x[r], zr[h][r], macc);
                     }
                 }
-                // k-major order: consecutive MFMAs go to different accumulators (no dependent back-to-back issue)
+            };
+            if constexpr (kDT == 2) {
+                // two tiles per stage: tile s+1 is brought up to date first (with tile s+2 in between, so that no MFMA
+                // waits on its predecessor), then ITS solve chain issues with the rest of tile s's updates filling the
+                // gaps -- the matrix pipe does not idle through the second chain
+                const int s = kDT * m;
+                d4 x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
+                x = MFMA_F64(iv[0][0], -acc[s][0], x);
+                x2 = MFMA_F64(iv[0][1], -acc[s][1], x2);
+                x = MFMA_F64(iv[0][2], -acc[s][2], x);
+                x2 = MFMA_F64(iv[0][3], -acc[s][3], x2);
+                x += x2;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    acc[s + 1] = MFMA_F64(uf[0][s + 1][kk], x[kk], acc[s + 1]);
+                    if (s + 2 < kT) acc[s + 2] = MFMA_F64(uf[0][s + 2][kk], x[kk], acc[s + 2]);
+                }
+                emit(0, s, x);
+                const d4 na = -acc[s + 1];
+                d4 y1 = {0.0, 0.0, 0.0, 0.0}, y2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (kk & 1) y2 = MFMA_F64(iv[1][kk], na[kk], y2);
+                    else y1 = MFMA_F64(iv[1][kk], na[kk], y1);
+#pragma unroll
+                    for (int t = s + 3; t < kT; ++t) acc[t] = MFMA_F64(uf[0][t][kk], x[kk], acc[t]);
+                }
+                const d4 y = y1 + y2;
+                emit(1, s + 1, y);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-                    for (int t = s + 1; t < kT; ++t) acc[t] = MFMA_F64(uf[h][t][kk], x[kk], acc[t]);
+                    for (int t = s + 2; t < kT; ++t) acc[t] = MFMA_F64(uf[1][t][kk], y[kk], acc[t]);
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < kDT; ++h) {
+                    const int s = kDT * m + h;
+                    d4 x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
+                    x = MFMA_F64(iv[h][0], -acc[s][0], x);
+                    x2 = MFMA_F64(iv[h][1], -acc[s][1], x2);
+                    x = MFMA_F64(iv[h][2], -acc[s][2], x);
+                    x2 = MFMA_F64(iv[h][3], -acc[s][3], x2);
+                    x += x2;
+                    emit(h, s, x);
+                    // k-major order: consecutive MFMAs go to different accumulators (no dependent back-to-back issue)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                        for (int t = s + 1; t < kT; ++t) acc[t] = MFMA_F64(uf[h][t][kk], x[kk], acc[t]);
+                    }
                 }
             }
             extra_prev = 1;
