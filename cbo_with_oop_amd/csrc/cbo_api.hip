@@ -292,7 +292,11 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
             made = hipExtStreamCreateWithCUMask(&c->side_stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
             if (!made) { (void)hipGetLastError(); c->side_stream = nullptr; }
         }
-        if (!made) e = hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, prio_high);
+        if (!made) {
+            const char *sp = std::getenv("CBO_HIP_SIDE_PRIORITY");      // 1 = as high as the chain (round 1), default: normal
+            e = hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking,
+                                            (sp && std::atoi(sp) == 1) ? prio_high : (prio_low + prio_high) / 2);
+        }
     }
     // The sweep streams leave a few CUs per XCD to the factorisation: its diagonal-block kernel needs a whole
     // CU's LDS and would otherwise wait behind a queue of half-LDS sweep workgroups that keep every CU partly

@@ -172,7 +172,7 @@ void launch_trsm_update(hipStream_t s, const double *U, int64_t ldu, double *V, 
 // workgroups that lie entirely below the diagonal
 void launch_gemm_update(hipStream_t s, const double *U, int64_t ldu, const double *V, int64_t ldv, double *C,
                         int64_t ldc, int k0, int klen, int i0_begin, int i0_end, int64_t m_pad, int chunk_blocks,
-                        bool half_lds, bool upper_only);
+                        bool half_lds, bool upper_only, const int *skip_if = nullptr);
 
 // One (model, candidate set) pair of a multi-set sweep of small models (kernels_chol.hip, small_sets_kernel): every
 // pointer is device memory; filled on the host per call and uploaded as an array.

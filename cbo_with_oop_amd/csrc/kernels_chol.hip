@@ -255,22 +255,39 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t l
 // the row panel and the other waves wait for the chain.  Here wave 0 runs one step ahead and touches nothing the
 // other waves produce inside an interval:
 //   interval jb:  wave 0     X01 = inv(L_jb) S(jb, jb+1);  S(jb+1, jb+1) -= X01^T X01 (registers);  factor tile jb+1
-//                 waves 1-3  EACH forms the whole row panel X(jb, jb+1..8) in registers (no exchange between them),
-//                            then updates its share of the trailing tiles T(ti, tj) -= X_ti^T X_tj straight from
-//                            those registers (the f64 MFMA result map is both operand maps), and one of them writes
-//                            the finished factor rows to global memory
-//   ONE barrier per interval.  Solved rows never return to LDS (nobody reads them again), so no wave overwrites
-//   what another still reads; the diagonal-tile inverse is double-buffered (wave 0 writes tile jb+1's while the
-//   others read tile jb's).  The right-hand side rides along as column tile 8 (the 16 spare columns of the LDS row
+//                 waves 1-3  each solves a third of the row panel X(jb, jb+1..8) (tiles ct with ct % 3 == w), leaves
+//                            it in LDS and in global memory (finished factor rows), meets the other two at an LDS
+//                            counter, reads the whole panel back into registers and updates its share of the trailing
+//                            tiles T(ti, tj) -= X_ti^T X_tj from them (the f64 MFMA result map is both operand maps)
+//   ONE workgroup barrier per interval; the rendezvous of waves 1-3 in the middle is theirs alone (an LDS counter), so
+//   the chain never waits for it.  A solved tile overwrites its own unsolved image in S (only its owner read that),
+//   except tile jb+1, which wave 0 reads in the same interval: that one goes to a spare tile below the diagonal
+//   (rows 16..31, columns 0..15 -- the lower triangle of S is never loaded or read).  The diagonal-tile inverse is
+//   double-buffered (wave 0 writes tile jb+1's while the others read tile jb's).  The right-hand side rides along as column tile 8 (the 16 spare columns of the LDS row
 //   stride: column 128 = r, the rest zero), so z = L^-1 r needs no code of its own.
 struct Diag2Shared {
     double S[128][kDiagLd];    // the block, upper triangle; columns 128..143: rhs tile (column 128) 
     double Yt[2][16][16];      // inverse of the diagonal factor of tile jb in Yt[jb & 1]: Yt[k][i] = inv(L_d)[i][k]
+    int xcount;                // row-panel tiles published by waves 1-3 (their own rendezvous; wave 0 never waits on it)
+    int pad_[3];
 };
 
 // Register Cholesky of one 16x16 tile given in the MFMA accumulator layout (d[r] = D[kq + 4r][lc], anything below
 // the diagonal ignored); returns the factor in the same layout (zeros below the diagonal), writes the inverse to
 // LDS (transposed: the A-operand image of the row-panel product) and to global memory (what the strip TRSM reads).
+//
+// The tile's 16 pivots are one dependent chain, so what counts is the number of dependent instructions per pivot
+// (about 13 cycles each for fp64 VALU work in a lone wave; scripts/probes/tile_factor_probe.hip has the forms tried):
+//   * pivots go in blocks of four.  One MFMA with a 0/1 selection operand replicates the block's four rows to every
+//     16-lane row (t[r] = D[4b + r][lc] on all lane rows), so no cross-lane shuffle sits between two pivots;
+//   * the block's 4x4 diagonal sub-block is factored FIRST, on uniform scalars (its ten entries read once with
+//     v_readlane, every lane repeating the same arithmetic): per pivot the chain is rsqrt -> multiply -> fma.  The
+//     16-wide row scalings and updates follow from those scalars, off the chain;
+//   * rsqrt is ocml's instruction sequence (v_rsq_f64, one third-order correction) without its class-check selects,
+//     and the positivity test only records the first bad pivot (reported once, after the tile) -- a non-positive pivot
+//     lets NaN / Inf through the rest of the tile, which jitchol's retry discards anyway;
+//   * a rank-4 MFMA carries the block into the rows below it.
+// Every value goes through the same operations in the same order as the plain right-looking form.
 __device__ __forceinline__ d4 factor_tile_regs(d4 din, int lane, int pivot_row0, int *info, double (*Yt)[16],
                                                double *__restrict__ invDt_tile)
 {
@@ -281,33 +298,49 @@ __device__ __forceinline__ d4 factor_tile_regs(d4 din, int lane, int pivot_row0,
         d[r] = (kq + 4 * r <= lc) ? din[r] : 0.0;
         e[r] = (kq + 4 * r == lc) ? 1.0 : 0.0;
     }
+    const double sel = ((lc >> 2) == kq) ? 1.0 : 0.0;       // A[i = lc][k = kq] = delta(k, i >> 2)
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    int bad = 0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
+        d4 t = MFMA_F64(sel, d[b], zero);
+        d4 s = MFMA_F64(sel, e[b], zero);
+        double a[4][4], u[4][4], inv[4], dj[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = i; j < 4; ++j) a[i][j] = readlane_f64(t[i], 4 * b + j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double pj = a[j][j];
+            if (!(pj > 0.0) && bad == 0) bad = 4 * b + j + 1;
+            const double y0 = __builtin_amdgcn_rsq(pj);
+            const double tt = y0 * -pj;
+            const double ee = fma(tt, y0, 1.0);
+            const double gg = y0 * ee;
+            const double hh = fma(ee, 0.375, 0.5);
+            inv[j] = fma(gg, hh, y0);
+            dj[j] = pj * inv[j];
+#pragma unroll
+            for (int k = j + 1; k < 4; ++k) u[j][k] = a[j][k] * inv[j];
+#pragma unroll
+            for (int i = j + 1; i < 4; ++i)
+#pragma unroll
+                for (int k = i; k < 4; ++k) a[i][k] = fma(-u[j][i], u[j][k], a[i][k]);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int piv = 4 * b + j;
-            double pj = readlane_f64(d[b], 16 * j + piv);
-            if (!(pj > 0.0)) {
-                if (lane == 0) atomicCAS(info, 0, pivot_row0 + piv + 1);
-                pj = 1.0;
-            }
-            const double inv = rsqrt(pj);
-            const double dj = pj * inv;
-            const double scaled = (lc > piv) ? d[b] * inv : ((lc == piv) ? dj : 0.0);
-            if (kq == j) {
-                d[b] = scaled;
-                e[b] *= inv;
-            }
-            if (j < 3) {
-                const double ujc = __shfl(d[b], 16 * j + lc);
-                const double ejc = __shfl(e[b], 16 * j + lc);
-                const double ujr = __shfl(d[b], 16 * j + 4 * b + kq);
-                if (kq > j) {
-                    d[b] = fma(-ujr, ujc, d[b]);
-                    e[b] = fma(-ujr, ejc, e[b]);
-                }
+            t[j] = (lc > piv) ? t[j] * inv[j] : ((lc == piv) ? dj[j] : 0.0);
+            s[j] *= inv[j];
+#pragma unroll
+            for (int i = j + 1; i < 4; ++i) {
+                t[i] = fma(-u[j][i], t[j], t[i]);
+                s[i] = fma(-u[j][i], s[j], s[i]);
             }
         }
+        d[b] = (kq == 0) ? t[0] : (kq == 1) ? t[1] : (kq == 2) ? t[2] : t[3];
+        e[b] = (kq == 0) ? s[0] : (kq == 1) ? s[1] : (kq == 2) ? s[2] : s[3];
         if (b < 3) {
             const d4 keep = d, keep_e = e;
             const double na = -d[b];
@@ -317,6 +350,7 @@ __device__ __forceinline__ d4 factor_tile_regs(d4 din, int lane, int pivot_row0,
             for (int r = 0; r <= b; ++r) { d[r] = keep[r]; e[r] = keep_e[r]; }
         }
     }
+    if (bad != 0 && lane == 0) atomicCAS(info, 0, pivot_row0 + bad);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         Yt[lc][kq + 4 * r] = e[r];
@@ -378,6 +412,103 @@ __device__ __forceinline__ void diag_trailing(Diag2Shared &sh, const d4 (&x)[9],
     }
 }
 
+#ifdef CBO_DIAG_KNOBS
+// Timing-only build: s_memtime stamps of the last diagonal-block launch, [wave][interval][slot] (scripts/diag_stamps.py)
+__device__ unsigned long long g_diag_stamps[4 * 9 * 4];
+#define DSTAMP(wave_, jb_, slot_) do { if ((threadIdx.x & 63) == 0) g_diag_stamps[((wave_) * 9 + (jb_)) * 4 + (slot_)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int cbo_diag_chol_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_stamps), sizeof(unsigned long long) * 4 * 9 * 4);
+}
+#else
+#define DSTAMP(wave_, jb_, slot_) do { } while (0)
+#endif
+
+// One interval of one of waves 1..3 (W = wave - 1): its third of the row panel, the rendezvous, its trailing tiles.
+template <int W>
+__device__ __forceinline__ void diag_worker(Diag2Shared &sh, double *A, int64_t lda, int r0, int rcol,
+                                            double *__restrict__ zvec, int jb, const double (&af)[4], int lane)
+{
+    const int lc = lane & 15, kq = lane >> 4;
+    const int o = 16 * jb;
+    constexpr int ct0 = (W == 0) ? 3 : W;                 // own column tiles: ct0, ct0 + 3, ct0 + 6 (<= 8; 8 = rhs)
+    constexpr int nown = (ct0 + 6 <= 8) ? 3 : 2;
+    // tiles that are not due (ct <= jb) are solved along on whatever S holds there and land below the diagonal,
+    // where nobody looks: cheaper than branching around a chain of four MFMAs
+    DSTAMP(W + 1, jb, 0);
+    d4 xo[nown];
+    {
+        double bq[4][nown];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int n = 0; n < nown; ++n) bq[kk][n] = sh.S[o + 4 * kk + kq][16 * (ct0 + 3 * n) + lc];
+#pragma unroll
+        for (int n = 0; n < nown; ++n) xo[n] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int n = 0; n < nown; ++n) xo[n] = MFMA_F64(af[kk], bq[kk][n], xo[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < nown; ++n) {
+        const int ct = ct0 + 3 * n;
+        if (ct == jb + 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sh.S[16 + kq + 4 * r][lc] = xo[n][r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sh.S[o + kq + 4 * r][16 * ct + lc] = xo[n][r];
+        }
+    }
+    // publish, then wait for the other two (LDS operations of a wave complete in order; the counter only grows)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(&sh.xcount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // rows o .. o+15 of the factor right of the diagonal tile, and z, leave for global memory meanwhile
+#pragma unroll
+    for (int n = 0; n < nown; ++n) {
+        const int ct = ct0 + 3 * n;
+        if (ct > jb) {
+            if (ct < 8) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) A[(int64_t)(r0 + o + kq + 4 * r) * lda + r0 + 16 * ct + lc] = xo[n][r];
+            } else if (lc == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = r0 + o + kq + 4 * r;
+                    A[(int64_t)row * lda + rcol] = xo[n][r];
+                    if (zvec) zvec[row] = xo[n][r];
+                }
+            }
+        }
+    }
+    DSTAMP(W + 1, jb, 1);
+    while (__hip_atomic_load(&sh.xcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 3 * (jb + 1))
+        __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    DSTAMP(W + 1, jb, 2);
+    // the whole panel into registers (tiles <= jb are finished rows whose products nobody stores: zeros)
+    d4 x[9], nx[9];
+#pragma unroll
+    for (int ct = 1; ct <= 8; ++ct) {
+        if (ct == jb + 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[ct][r] = sh.S[16 + kq + 4 * r][lc];
+        } else if (ct > jb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[ct][r] = sh.S[o + kq + 4 * r][16 * ct + lc];
+        } else {
+            x[ct] = d4{0.0, 0.0, 0.0, 0.0};
+        }
+        nx[ct] = -x[ct];
+    }
+    // trailing tiles T(ti, tj) -= X_ti^T X_tj, jb < ti <= 7, ti <= tj <= 8, except the next diagonal tile (wave 0's).
+    // Ownership is by column (a compile-time list per wave), tiles go four at a time with their accumulation chains
+    // interleaved; a tile that is not due (ti <= jb) is computed on stale operands and simply not written back.
+    diag_trailing<W>(sh, x, nx, jb, lane);
+    DSTAMP(W + 1, jb, 3);
+}
+
 // The factorisation of a block that is already in LDS (S: upper triangle + rhs tile; the caller has synchronised).
 // `tiles` = 16-row tiles to factor (8 = the whole block; fewer when the rest is identity padding, which the caller
 // then writes out itself).  Factor rows, diagonal inverses and z go to global memory (A, invDt, zvec).
@@ -389,6 +520,7 @@ __device__ __forceinline__ void diag128_factor_in_lds(Diag2Shared &sh, double *A
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lc = lane & 15, kq = lane >> 4;
+    if (tid == 64) sh.xcount = 0;
     if (wave == 0) {
         d4 t0;
 #pragma unroll
@@ -405,6 +537,7 @@ __device__ __forceinline__ void diag128_factor_in_lds(Diag2Shared &sh, double *A
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) af[kk] = sh.Yt[jb & 1][4 * kk + kq][lc];
         if (wave == 0) {
+            DSTAMP(0, jb, 0);
             if (jb + 1 < tiles) {
                 // two half-sums each: a chain of dependent f64 MFMAs runs at about half the issue rate
                 d4 x = {0.0, 0.0, 0.0, 0.0}, xb = {0.0, 0.0, 0.0, 0.0}, acc, accb = {0.0, 0.0, 0.0, 0.0};
@@ -423,70 +556,19 @@ __device__ __forceinline__ void diag128_factor_in_lds(Diag2Shared &sh, double *A
                 acc = MFMA_F64(x[2], -x[2], acc);
                 accb = MFMA_F64(x[3], -x[3], accb);
                 acc += accb;
+                DSTAMP(0, jb, 1);
                 const d4 u = factor_tile_regs(acc, lane, r0 + o + 16, info, sh.Yt[(jb + 1) & 1],
                                               invDt + (int64_t)(r0 / 16 + jb + 1) * 256);
+                DSTAMP(0, jb, 2);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) A[(int64_t)(r0 + o + 16 + kq + 4 * r) * lda + r0 + o + 16 + lc] = u[r];
             }
+            DSTAMP(0, jb, 3);
         } else {
             const int w = wave - 1;
-            // the whole row panel of this step, tiles 1 .. 8 (8 = right-hand side), in registers; tiles <= jb are
-            // finished rows whose results nobody uses (computed along when cheaper than branching around them).
-            // k-step outer, tile inner: eight independent accumulation chains keep the matrix pipe busy
-            d4 x[9], nx[9];
-            if (jb < 4) {
-                double bq[4][9];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int ct = 1; ct <= 8; ++ct) bq[kk][ct] = sh.S[o + 4 * kk + kq][16 * ct + lc];
-#pragma unroll
-                for (int ct = 1; ct <= 8; ++ct) x[ct] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int ct = 1; ct <= 8; ++ct) x[ct] = MFMA_F64(af[kk], bq[kk][ct], x[ct]);
-            } else {
-                double bq[4][9];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int ct = 5; ct <= 8; ++ct) bq[kk][ct] = sh.S[o + 4 * kk + kq][16 * ct + lc];
-#pragma unroll
-                for (int ct = 1; ct <= 8; ++ct) x[ct] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int ct = 5; ct <= 8; ++ct) x[ct] = MFMA_F64(af[kk], bq[kk][ct], x[ct]);
-            }
-#pragma unroll
-            for (int ct = 1; ct <= 8; ++ct) nx[ct] = -x[ct];
-            // rows o .. o+15 of the factor right of the diagonal tile, and z, leave for global memory
-            if (w == jb % 3) {
-#pragma unroll
-                for (int ct = 1; ct <= 7; ++ct) {
-                    if (ct > jb) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            A[(int64_t)(r0 + o + kq + 4 * r) * lda + r0 + 16 * ct + lc] = x[ct][r];
-                    }
-                }
-                if (lc == 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = r0 + o + kq + 4 * r;
-                        A[(int64_t)row * lda + rcol] = x[8][r];
-                        if (zvec) zvec[row] = x[8][r];
-                    }
-                }
-            }
-            // trailing tiles T(ti, tj) -= X_ti^T X_tj, jb < ti <= 7, ti <= tj <= 8, except the next diagonal tile
-            // (wave 0's).  Ownership is by column (a compile-time list per wave), tiles go four at a time with their
-            // accumulation chains interleaved; a tile that is not due (ti <= jb) is computed on stale operands and
-            // simply not written back.
-            if (w == 0) diag_trailing<0>(sh, x, nx, jb, lane);
-            else if (w == 1) diag_trailing<1>(sh, x, nx, jb, lane);
-            else diag_trailing<2>(sh, x, nx, jb, lane);
+            if (w == 0) diag_worker<0>(sh, A, lda, r0, rcol, zvec, jb, af, lane);
+            else if (w == 1) diag_worker<1>(sh, A, lda, r0, rcol, zvec, jb, af, lane);
+            else diag_worker<2>(sh, A, lda, r0, rcol, zvec, jb, af, lane);
         }
         __syncthreads();
     }
@@ -498,9 +580,11 @@ __global__ __launch_bounds__(256) void potrf_diag128_v2_kernel(double *A, int64_
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Diag2Shared &sh = *reinterpret_cast<Diag2Shared *>(smem_raw);
+    if (__builtin_nontemporal_load(info) != 0) return;      // an earlier block met a non-positive pivot: abandoned
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    DSTAMP(wave, 8, 0);
     {
         const unsigned s0 = lds_byte_address(&sh.S[0][0]);
         const double *g = A + (int64_t)(r0 + wave * 32) * lda + r0 + lane * 2;
@@ -518,7 +602,9 @@ __global__ __launch_bounds__(256) void potrf_diag128_v2_kernel(double *A, int64_
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    DSTAMP(wave, 8, 1);
     diag128_factor_in_lds(sh, A, lda, r0, rcol, invDt, info, zvec, 8);
+    DSTAMP(wave, 8, 2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -571,10 +657,12 @@ __device__ __forceinline__ void panel_solve_tiles(const double *ub, d4 (&acc)[8]
 
 
 __global__ __launch_bounds__(256) void panel_trsm_kernel(double *A, int64_t lda, int r0, int col0,
-                                                         const double *__restrict__ invDt)
+                                                         const double *__restrict__ invDt,
+                                                         const int *__restrict__ skip_if)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     PanelShared &sh = *reinterpret_cast<PanelShared *>(smem_raw);
+    if (__builtin_nontemporal_load(skip_if) != 0) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -609,11 +697,12 @@ __global__ __launch_bounds__(256) void panel_trsm_kernel(double *A, int64_t lda,
     });
 }
 
-void launch_panel_trsm(hipStream_t s, double *A, int64_t lda, int r0, int col0, int n_cols, const double *invDt)
+void launch_panel_trsm(hipStream_t s, double *A, int64_t lda, int r0, int col0, int n_cols, const double *invDt,
+                       const int *skip_if)
 {
     if (n_cols <= 0) return;
     hipLaunchKernelGGL(panel_trsm_kernel, dim3((unsigned)(n_cols / kStrip)), dim3(256), sizeof(PanelShared), s, A, lda, r0,
-                       col0, invDt);
+                       col0, invDt, skip_if);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -866,8 +955,9 @@ void launch_small_sets(hipStream_t s, const cbo_small_set *sets, int n_sets, int
 // Extra blocks (blockIdx.x == nt) update the rhs column: r[i] -= sum_k P[k][i] z[k].
 template <int TS>
 __global__ __launch_bounds__(256) void syrk_kernel(double *A, int64_t lda, int r0, int n1, int c0, int nt, int rcol,
-                                                   int ti_begin, int dbg)
+                                                   int ti_begin, int dbg, const int *__restrict__ skip_if)
 {
+    if (__builtin_nontemporal_load(skip_if) != 0) return;
     const int tj = blockIdx.x, ti = blockIdx.y + ti_begin;
     const int tid = threadIdx.x;
     const double *P = A + (int64_t)r0 * lda;
@@ -973,8 +1063,10 @@ __global__ __launch_bounds__(256) void syrk_kernel(double *A, int64_t lda, int r
 // workgroup means 2x2 MFMA tiles x K/4 steps = 256 dependent-free but serial MFMAs per wave at K = 256 (7.8 us).
 // Here a workgroup takes 32 rows x 64 columns (wave w: both 16-row tiles x its 16 columns), which halves the MFMAs
 // per wave and doubles the workgroups (256 at N = 4096: every CU busy).  blockIdx.x == nt: the rhs column.
-__global__ __launch_bounds__(256) void syrk_rows_kernel(double *A, int64_t lda, int r0, int n1, int c0, int nt, int rcol)
+__global__ __launch_bounds__(256) void syrk_rows_kernel(double *A, int64_t lda, int r0, int n1, int c0, int nt, int rcol,
+                                                        const int *__restrict__ skip_if)
 {
+    if (__builtin_nontemporal_load(skip_if) != 0) return;
     const int tj = blockIdx.x, ti = blockIdx.y;                  // 64-column tile, 32-row tile (4 of them)
     const int tid = threadIdx.x;
     const double *P = A + (int64_t)r0 * lda;
@@ -1051,18 +1143,22 @@ __global__ __launch_bounds__(256) void syrk_rows_kernel(double *A, int64_t lda, 
         for (int r = 0; r < 4; ++r) A[(ib + 16 * m + kq + 4 * r) * lda + jb + lc] = cv[m][r] - acc[m][r];
 }
 
-// the next panel's 128 rows against the n1 panel rows [r0, r0 + n1): columns from c0 = r0 + n1 on, n2 of them
-static void launch_syrk_rows(hipStream_t s, double *A, int64_t lda, int r0, int n1, int n2, int rcol)
+// the first `rows` rows below the n1 panel rows [r0, r0 + n1) against those panel rows: columns from c0 = r0 + n1 on,
+// n2 of them (rows: 128 = the next panel, 256 = the next pair of panels)
+static void launch_syrk_rows(hipStream_t s, double *A, int64_t lda, int r0, int n1, int n2, int rcol, const int *skip_if,
+                             int rows = 128)
 {
     const int c0 = r0 + n1;
     const int nt = n2 / 64;
     if (nt <= 0) return;
-    hipLaunchKernelGGL(syrk_rows_kernel, dim3(nt + 1, 4), dim3(256), 0, s, A, lda, r0, n1, c0, nt, rcol);
+    if (rows > n2) rows = n2;
+    hipLaunchKernelGGL(syrk_rows_kernel, dim3(nt + 1, rows / 32), dim3(256), 0, s, A, lda, r0, n1, c0, nt, rcol,
+                       skip_if);
 }
 
 // tile rows [ti_begin, ti_end) of the trailing update (64-row tiles counted from the first trailing row)
 static void launch_syrk(hipStream_t s, double *A, int64_t lda, int r0, int n1, int n2, int rcol, int ti_begin,
-                        int ti_end)
+                        int ti_end, const int *skip_if)
 {
     const int c0 = r0 + n1;
     const int nt = n2 / 64;
@@ -1075,7 +1171,7 @@ static void launch_syrk(hipStream_t s, double *A, int64_t lda, int r0, int n1, i
     const int dbg = 0;
 #endif
     hipLaunchKernelGGL(syrk_kernel<64>, dim3(nt + 1, ti_end - ti_begin), dim3(256), 0, s, A, lda, r0, n1, c0, nt, rcol,
-                       ti_begin, dbg);
+                       ti_begin, dbg, skip_if);
 }
 
 // Rows [r0, r0 + klen) of U (all columns) and of z are final on stream `chain`: hand them to the sweep.
@@ -1152,9 +1248,9 @@ void sweep_pipe_tail(const SweepPipe &pipe, hipStream_t chain, const double *A, 
     if (pipe.mark) pipe.mark(pipe.user, chain, 0, 0.0);
 }
 
-// Look-ahead: the bulk of panel k-1's trailing update (tile rows below the next panel) runs on the side
-// stream while the main stream factors the diagonal block of panel k and solves its row panel; the two
-// meet again before the next panel's own rows are updated.
+// Look-ahead of one panel pair: the bulk of pair p-1's trailing update (everything below pair p+1's rows) runs on the
+// side stream while the main stream factors and solves pair p; the two meet before pair p's own update of pair
+// p+1's rows (schedule inside).
 void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &events, double *A, int64_t lda,
                      int64_t n_pad, double *invDt, int *info_dev, const SweepPipe *pipe)
 {
@@ -1206,48 +1302,62 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     auto sweep_rows = [&](int r0, int klen) {
         if (pipe && r0 < pipe->tail_begin) sweep_pipe_pair(*pipe, s, A, lda, invDt, n_pad, pair++, r0, klen);
     };
+    // Schedule per pair p (panels A_p, B_p):
+    //   chain:  diag A_p, panel A_p, rows B_p -= A_p (K = 128), diag B_p, panel B_p,
+    //           [wait bulk(p-1)]  rows A_{p+1}, B_{p+1} -= (A_p, B_p)  (K = 256, 256 rows)
+    //   side :  [wait panel B_p]  bulk(p): everything below B_{p+1} -= (A_p, B_p)
+    // bulk(p-1) rewrites the rows the K = 256 rows kernel of pair p rewrites, hence the wait; it has the whole chain of
+    // pair p to finish, and bulk(p) follows it on the side stream without a gap -- large factorisations are bound by
+    // the bulk updates alone, small ones by the chain alone.
     int pending = -1;                      // event index of the bulk update still in flight
     for (int k = 0; k < np; k += 2) {
         const int r0 = 128 * k;
         launch_diag(r0);
         const int n2 = (int)n_pad - r0 - 128;
         if (n2 <= 0) { sweep_rows(r0, 128); break; }
-        if (panel_form == 2 && !pipe) launch_panel_trsm(s, A, lda, r0, r0 + 128, n2, invDt);   // (beside a pipelined sweep: the half-LDS strip kernel)
+        if (panel_form == 2 && !pipe) launch_panel_trsm(s, A, lda, r0, r0 + 128, n2, invDt, info_dev);   // (beside a pipelined sweep: the half-LDS strip kernel)
         else
         launch_trsm_strips(s, A + (int64_t)r0 * lda + r0, lda, invDt + (int64_t)(r0 / 16) * 256,
                            A + (int64_t)r0 * lda + r0 + 128, lda, 128, n2, nullptr, nullptr, nullptr, false, half_lds);
-        // rows of the pair's second panel: K = 128 update with the first panel (after the previous bulk
-        // update, which touches the same rows)
-        if (pending >= 0) { hipStreamWaitEvent(s, events[pending], 0); pending = -1; }
-        if (syrk_rows_form == 2) launch_syrk_rows(s, A, lda, r0, 128, n2, rcol);
-        else launch_syrk(s, A, lda, r0, 128, n2, rcol, 0, 2);
+        // rows of the pair's second panel: K = 128 update with the first panel
+        if (syrk_rows_form == 2) launch_syrk_rows(s, A, lda, r0, 128, n2, rcol, info_dev);
+        else launch_syrk(s, A, lda, r0, 128, n2, rcol, 0, 2, info_dev);
         const int r1 = r0 + 128;
         launch_diag(r1);
         const int n3 = (int)n_pad - r1 - 128;
         if (n3 <= 0) { sweep_rows(r0, 256); break; }
-        if (panel_form == 2 && !pipe) launch_panel_trsm(s, A, lda, r1, r1 + 128, n3, invDt);
+        if (panel_form == 2 && !pipe) launch_panel_trsm(s, A, lda, r1, r1 + 128, n3, invDt, info_dev);
         else
         launch_trsm_strips(s, A + (int64_t)r1 * lda + r1, lda, invDt + (int64_t)(r1 / 16) * 256,
                            A + (int64_t)r1 * lda + r1 + 128, lda, 128, n3, nullptr, nullptr, nullptr, false, half_lds);
         sweep_rows(r0, 256);
-        // both panels against everything below them: next pair's first panel rows on this stream, ...
-        if (syrk_rows_form == 2) launch_syrk_rows(s, A, lda, r0, 256, n3, rcol);
-        else launch_syrk(s, A, lda, r0, 256, n3, rcol, 0, 2);
-        if (n3 > 128) {                                       // ... the rest on the side stream
+        // both panels against everything below them: the bulk (below the next pair) on the side stream, the next
+        // pair's own rows on this stream after the previous pair's bulk update of the same rows.  A large bulk update
+        // bounds the factorisation, so it starts as soon as the panels are solved and the rows kernel runs beside its
+        // first workgroups; a small one is hidden behind the chain anyway and would only slow the rows kernel (which is
+        // ON the chain) down, so it starts after that.
+        const int prev = pending;
+        const bool bulk = n3 > 256;
+        const bool gemm_form = bulk && n3 - 256 >= syrk_gemm_rows;
+        auto launch_bulk = [&] {
             hipEventRecord(events[2 * k], s);
             hipStreamWaitEvent(side, events[2 * k], 0);
-            // the bulk of the trailing update.  Large trailing blocks go through the LDS-staged GEMM form of the
-            // sweep's update kernel (C -= P^T P on 64-column strips x 256-row chunks, upper part only, the rhs strip
-            // as one more strip): the 64x64-tile SYRK reads its operands as fragment-shaped loads from L2 and tops
-            // out near half the fp64 MFMA rate, which is what bounds the factorisation at 16384 points
-            if (n3 - 128 >= syrk_gemm_rows)
-                launch_gemm_update(side, A, lda, A, lda, A, lda, r0, 256, r0 + 256 + 128, (int)n_pad, n_pad + kRhsCols,
-                                   syrk_gemm_chunk, syrk_gemm_half, true);
+            // Large trailing blocks go through the LDS-staged GEMM form of the sweep's update kernel (C -= P^T P on
+            // 64-column strips x 256-row chunks, upper part only, the rhs strip as one more strip): the 64x64-tile SYRK
+            // reads its operands as fragment-shaped loads from L2 and tops out near half the fp64 MFMA rate
+            if (gemm_form)
+                launch_gemm_update(side, A, lda, A, lda, A, lda, r0, 256, r0 + 256 + 256, (int)n_pad, n_pad + kRhsCols,
+                                   syrk_gemm_chunk, syrk_gemm_half, true, info_dev);
             else
-                launch_syrk(side, A, lda, r0, 256, n3, rcol, 2, n3 / 64);
+                launch_syrk(side, A, lda, r0, 256, n3, rcol, 4, n3 / 64, info_dev);
             hipEventRecord(events[2 * k + 1], side);
             pending = 2 * k + 1;
-        }
+        };
+        if (gemm_form) launch_bulk();
+        if (prev >= 0) hipStreamWaitEvent(s, events[prev], 0);
+        if (syrk_rows_form == 2) launch_syrk_rows(s, A, lda, r0, 256, n3, rcol, info_dev, 256);
+        else launch_syrk(s, A, lda, r0, 256, n3, rcol, 0, 4, info_dev);
+        if (bulk && !gemm_form) launch_bulk();
     }
     // nothing is left on the side stream that the main stream has not waited for (the last bulk update is
     // awaited before the following panel's syrk); make that explicit for robustness

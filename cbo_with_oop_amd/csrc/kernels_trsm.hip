@@ -406,8 +406,10 @@ template <int KB>
 __global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restrict__ U, int64_t ldu,
                                                           const double *V, int64_t ldv, double *C, int64_t ldc, int k0,
                                                           int klen, int i0_begin, int i0_end, int chunk_rows,
-                                                          int upper_only)
+                                                          int upper_only, const int *__restrict__ skip_if)
 {
+    // a factorisation that has met a non-positive pivot is abandoned: its remaining launches return at once
+    if (skip_if && __builtin_nontemporal_load(skip_if) != 0) return;
     using G = StageGeom<KB>;
     constexpr int kA = G::kA, kB = G::kB, kRA = G::kRA, kParts = G::kParts, kDma = G::kDma, kKS = G::kKS;
     __shared__ __align__(16) double lds[kNBuf * (kA + kB)];
@@ -562,12 +564,12 @@ void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const doubl
 void launch_trsm_update(hipStream_t s, const double *U, int64_t ldu, double *V, int64_t ldv, int k0, int klen,
                         int i0_begin, int i0_end, int64_t m_pad, int chunk_blocks, bool half_lds)
 {
-    launch_gemm_update(s, U, ldu, V, ldv, V, ldv, k0, klen, i0_begin, i0_end, m_pad, chunk_blocks, half_lds, false);
+    launch_gemm_update(s, U, ldu, V, ldv, V, ldv, k0, klen, i0_begin, i0_end, m_pad, chunk_blocks, half_lds, false, nullptr);
 }
 
 void launch_gemm_update(hipStream_t s, const double *U, int64_t ldu, const double *V, int64_t ldv, double *C,
                         int64_t ldc, int k0, int klen, int i0_begin, int i0_end, int64_t m_pad, int chunk_blocks,
-                        bool half_lds, bool upper_only)
+                        bool half_lds, bool upper_only, const int *skip_if)
 {
     if (i0_begin >= i0_end || m_pad <= 0 || klen <= 0) return;
     // klen is 128 or 256 (a multiple of the 32-row stage and at least two stages, which the vmcnt bookkeeping
@@ -578,10 +580,10 @@ void launch_gemm_update(hipStream_t s, const double *U, int64_t ldu, const doubl
     const int up = upper_only ? 1 : 0;
     if (!half_lds)
         hipLaunchKernelGGL(trsm_update_kernel<32>, grid, dim3(256), 0, s, U, ldu, V, ldv, C, ldc, k0, klen, i0_begin,
-                           i0_end, chunk_rows, up);
+                           i0_end, chunk_rows, up, skip_if);
     else
         hipLaunchKernelGGL(trsm_update_kernel<16>, grid, dim3(256), 0, s, U, ldu, V, ldv, C, ldc, k0, klen, i0_begin,
-                           i0_end, chunk_rows, up);
+                           i0_end, chunk_rows, up, skip_if);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -111,6 +111,191 @@ __device__ __forceinline__ d4 factor(d4 din, int lane, d4 &eout)
     return d;
 }
 
+// Form 3: the four rows of a pivot block replicated to every 16-lane row by one MFMA with a 0/1 selection operand
+// (t[r] = D[4b + r][lc] on all lane rows); the pivots then need only scalars (v_readlane), no ds_bpermute in the chain.
+template <>
+__device__ __forceinline__ d4 factor<3>(d4 din, int lane, d4 &eout)
+{
+    const int lc = lane & 15, kq = lane >> 4;
+    d4 d, e;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        d[r] = (kq + 4 * r <= lc) ? din[r] : 0.0;
+        e[r] = (kq + 4 * r == lc) ? 1.0 : 0.0;
+    }
+    const double sel = ((lc >> 2) == kq) ? 1.0 : 0.0;       // A[i = lc][k = kq] = delta(k, i >> 2)
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        d4 t = MFMA_F64(sel, d[b], zero);
+        d4 s = MFMA_F64(sel, e[b], zero);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piv = 4 * b + j;
+            double pj = readlane_f64(t[j], piv);
+            if (!(pj > 0.0)) pj = 1.0;
+            const double inv = rsqrt(pj);
+            const double dj = pj * inv;
+            t[j] = (lc > piv) ? t[j] * inv : ((lc == piv) ? dj : 0.0);
+            s[j] *= inv;
+#pragma unroll
+            for (int i = j + 1; i < 4; ++i) {
+                const double u = readlane_f64(t[j], 4 * b + i);
+                t[i] = fma(-u, t[j], t[i]);
+                s[i] = fma(-u, s[j], s[i]);
+            }
+        }
+        d[b] = (kq == 0) ? t[0] : (kq == 1) ? t[1] : (kq == 2) ? t[2] : t[3];
+        e[b] = (kq == 0) ? s[0] : (kq == 1) ? s[1] : (kq == 2) ? s[2] : s[3];
+        if (b < 3) {
+            const d4 keep = d, keep_e = e;
+            const double na = -d[b];
+            d = MFMA_F64(na, d[b], d);
+            e = MFMA_F64(na, e[b], e);
+#pragma unroll
+            for (int r = 0; r <= b; ++r) { d[r] = keep[r]; e[r] = keep_e[r]; }
+        }
+    }
+    eout = e;
+    return d;
+}
+
+// Form 4: as form 3, and the 4x4 diagonal sub-block of the pivot block is factored FIRST on uniform scalars (the ten
+// entries read once with v_readlane; every lane repeats the same arithmetic): the dependent chain per pivot is
+// rsqrt -> one multiply -> one fma.  The 16-wide row scalings / updates then use those scalars, off the chain.
+// Same operations on the same values in the same order as forms 0 and 3 -> the same bits.
+template <>
+__device__ __forceinline__ d4 factor<4>(d4 din, int lane, d4 &eout)
+{
+    const int lc = lane & 15, kq = lane >> 4;
+    d4 d, e;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        d[r] = (kq + 4 * r <= lc) ? din[r] : 0.0;
+        e[r] = (kq + 4 * r == lc) ? 1.0 : 0.0;
+    }
+    const double sel = ((lc >> 2) == kq) ? 1.0 : 0.0;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        d4 t = MFMA_F64(sel, d[b], zero);
+        d4 s = MFMA_F64(sel, e[b], zero);
+        double a[4][4], u[4][4], inv[4], dj[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = i; j < 4; ++j) a[i][j] = readlane_f64(t[i], 4 * b + j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double pj = a[j][j];
+            if (!(pj > 0.0)) pj = 1.0;
+            inv[j] = rsqrt(pj);
+            dj[j] = pj * inv[j];
+#pragma unroll
+            for (int k = j + 1; k < 4; ++k) u[j][k] = a[j][k] * inv[j];
+#pragma unroll
+            for (int i = j + 1; i < 4; ++i)
+#pragma unroll
+                for (int k = i; k < 4; ++k) a[i][k] = fma(-u[j][i], u[j][k], a[i][k]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piv = 4 * b + j;
+            t[j] = (lc > piv) ? t[j] * inv[j] : ((lc == piv) ? dj[j] : 0.0);
+            s[j] *= inv[j];
+#pragma unroll
+            for (int i = j + 1; i < 4; ++i) {
+                t[i] = fma(-u[j][i], t[j], t[i]);
+                s[i] = fma(-u[j][i], s[j], s[i]);
+            }
+        }
+        d[b] = (kq == 0) ? t[0] : (kq == 1) ? t[1] : (kq == 2) ? t[2] : t[3];
+        e[b] = (kq == 0) ? s[0] : (kq == 1) ? s[1] : (kq == 2) ? s[2] : s[3];
+        if (b < 3) {
+            const d4 keep = d, keep_e = e;
+            const double na = -d[b];
+            d = MFMA_F64(na, d[b], d);
+            e = MFMA_F64(na, e[b], e);
+#pragma unroll
+            for (int r = 0; r <= b; ++r) { d[r] = keep[r]; e[r] = keep_e[r]; }
+        }
+    }
+    eout = e;
+    return d;
+}
+
+// Form 5: form 4 with ocml's rsqrt sequence spelled out minus its class-check selects (identical bits for normal
+// positive pivots), and the positivity test taken off the chain (first bad pivot recorded, reported once).  Form 4: as form 3, and the 4x4 diagonal sub-block of the pivot block is factored FIRST on uniform scalars (the ten
+// entries read once with v_readlane; every lane repeats the same arithmetic): the dependent chain per pivot is
+// rsqrt -> one multiply -> one fma.  The 16-wide row scalings / updates then use those scalars, off the chain.
+// Same operations on the same values in the same order as forms 0 and 3 -> the same bits.
+template <>
+__device__ __forceinline__ d4 factor<5>(d4 din, int lane, d4 &eout)
+{
+    const int lc = lane & 15, kq = lane >> 4;
+    d4 d, e;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        d[r] = (kq + 4 * r <= lc) ? din[r] : 0.0;
+        e[r] = (kq + 4 * r == lc) ? 1.0 : 0.0;
+    }
+    const double sel = ((lc >> 2) == kq) ? 1.0 : 0.0;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    int bad = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        d4 t = MFMA_F64(sel, d[b], zero);
+        d4 s = MFMA_F64(sel, e[b], zero);
+        double a[4][4], u[4][4], inv[4], dj[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = i; j < 4; ++j) a[i][j] = readlane_f64(t[i], 4 * b + j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double pj = a[j][j];
+            if (!(pj > 0.0) && bad == 0) bad = 4 * b + j + 1;
+            const double y0 = __builtin_amdgcn_rsq(pj);
+            const double tt = y0 * -pj;
+            const double ee = fma(tt, y0, 1.0);
+            const double gg = y0 * ee;
+            const double hh = fma(ee, 0.375, 0.5);
+            inv[j] = fma(gg, hh, y0);
+            dj[j] = pj * inv[j];
+#pragma unroll
+            for (int k = j + 1; k < 4; ++k) u[j][k] = a[j][k] * inv[j];
+#pragma unroll
+            for (int i = j + 1; i < 4; ++i)
+#pragma unroll
+                for (int k = i; k < 4; ++k) a[i][k] = fma(-u[j][i], u[j][k], a[i][k]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piv = 4 * b + j;
+            t[j] = (lc > piv) ? t[j] * inv[j] : ((lc == piv) ? dj[j] : 0.0);
+            s[j] *= inv[j];
+#pragma unroll
+            for (int i = j + 1; i < 4; ++i) {
+                t[i] = fma(-u[j][i], t[j], t[i]);
+                s[i] = fma(-u[j][i], s[j], s[i]);
+            }
+        }
+        d[b] = (kq == 0) ? t[0] : (kq == 1) ? t[1] : (kq == 2) ? t[2] : t[3];
+        e[b] = (kq == 0) ? s[0] : (kq == 1) ? s[1] : (kq == 2) ? s[2] : s[3];
+        if (b < 3) {
+            const d4 keep = d, keep_e = e;
+            const double na = -d[b];
+            d = MFMA_F64(na, d[b], d);
+            e = MFMA_F64(na, e[b], e);
+#pragma unroll
+            for (int r = 0; r <= b; ++r) { d[r] = keep[r]; e[r] = keep_e[r]; }
+        }
+    }
+    if (bad) e[0] += 1e300;
+    eout = e;
+    return d;
+}
+
 template <int FORM>
 __global__ void probe(const double *T, double *U, double *E, int reps)
 {
@@ -120,9 +305,9 @@ __global__ void probe(const double *T, double *U, double *E, int reps)
     d4 u, e, acc = {0, 0, 0, 0};
     for (int i = 0; i < reps; ++i) {
         d4 in = t;
-        in[0] += acc[0] * 1e-300;                 // serialise the repetitions
-        u = factor<FORM>(in, lane, e);
-        acc += u;
+        in[0] += acc[0] * 1e-300;                 // serialise the repetitions (on the factor AND on its inverse: the
+        u = factor<FORM>(in, lane, e);            // kernel needs both before its barrier)
+        acc += u + e;
     }
     for (int r = 0; r < 4; ++r) {
         U[(kq + 4 * r) * 16 + lc] = u[r];
@@ -148,12 +333,16 @@ int main()
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     const int reps = 4000;
-    for (int form = 0; form < 3; ++form) {
+    std::vector<double> U0, E0;
+    for (int form = 0; form < 6; ++form) {
         for (int pass = 0; pass < 2; ++pass) {
             hipEventRecord(a);
             if (form == 0) hipLaunchKernelGGL(probe<0>, dim3(1), dim3(64), 0, 0, dT, dU, dE, reps);
             if (form == 1) hipLaunchKernelGGL(probe<1>, dim3(1), dim3(64), 0, 0, dT, dU, dE, reps);
             if (form == 2) hipLaunchKernelGGL(probe<2>, dim3(1), dim3(64), 0, 0, dT, dU, dE, reps);
+            if (form == 3) hipLaunchKernelGGL(probe<3>, dim3(1), dim3(64), 0, 0, dT, dU, dE, reps);
+            if (form == 4) hipLaunchKernelGGL(probe<4>, dim3(1), dim3(64), 0, 0, dT, dU, dE, reps);
+            if (form == 5) hipLaunchKernelGGL(probe<5>, dim3(1), dim3(64), 0, 0, dT, dU, dE, reps);
             hipEventRecord(b);
             hipEventSynchronize(b);
         }
@@ -176,8 +365,13 @@ int main()
                 for (int k = 0; k < 16; ++k) s += E[i * 16 + k] * ref[j * 16 + k];
                 ierr = fmax(ierr, fabs(s - (i == j ? 1.0 : 0.0)));
             }
-        printf("form %d: %.3f us per 16x16 factor (%.0f ns per pivot); max |U - ref| %.2e, |E L - I| %.2e\n", form,
-               ms * 1e3 / reps, ms * 1e6 / reps / 16, err, ierr);
+        if (form == 0) { U0 = U; E0 = E; }
+        int same = 1;
+        for (int i = 0; i < 16; ++i)
+            for (int j = i; j < 16; ++j) same &= (U[i * 16 + j] == U0[i * 16 + j]);
+        for (int i = 0; i < 256; ++i) same &= (E[i] == E0[i]) ? 1 : 2 * 0;
+        printf("form %d: %.3f us per 16x16 factor (%.0f ns per pivot); max |U - ref| %.2e, |E L - I| %.2e; bits equal to form 0: %d\n", form,
+               ms * 1e3 / reps, ms * 1e6 / reps / 16, err, ierr, same);
     }
     return 0;
 }
