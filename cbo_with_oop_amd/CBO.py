@@ -41,6 +41,7 @@ class CBOAcquisitionPath:
         self.models = []
         self.last_intervention = None
         self._grids = {}          # per set: (grid shape, prior closures, device-resident candidate grid)
+        self._grid_points = {}    # per set: (space object, grid shape object, shape, points)
         self._call_cache = {}     # handle arrays and batch costs of the multi-set sweep, valid while the objects are
         # Several GPUs (one process per GPU): ``comm`` is a sharding.Communicator (or anything with world / rank /
         # argmax), "env" = the launcher's (RANK / WORLD_SIZE), None = single process.  Whole exploration sets go to
@@ -89,9 +90,18 @@ class CBOAcquisitionPath:
         return ("sets" if self.es_size >= comm.world else "candidates"), comm.world, comm.rank
 
     def grid_points(self, s):
-        bounds = space_bounds(self.space_list[s])
-        shape = tuple(self.grid_shapes[s] or default_grid_shape(len(bounds)))
-        return shape, meshgrid_candidates(bounds, shape)
+        """(shape, points) of set s's regular grid; built once per (space object, grid shape) -- replace
+        ``space_list[s]`` / ``grid_shapes[s]`` to change it (the cache keeps the space object alive, so its identity
+        cannot be reused)."""
+        space, want = self.space_list[s], self.grid_shapes[s]
+        hit = self._grid_points.get(s)
+        if hit is not None and hit[0] is space and hit[1] is want:
+            return hit[2], hit[3]
+        bounds = space_bounds(space)
+        shape = tuple(want or default_grid_shape(len(bounds)))
+        pts = meshgrid_candidates(bounds, shape)
+        self._grid_points[s] = (space, want, shape, pts)
+        return shape, pts
 
     def candidate_grid(self, s):
         """The regular grid over the set's box, resident on the device across trials (the reference draws fresh

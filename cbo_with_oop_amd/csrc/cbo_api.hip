@@ -97,7 +97,8 @@ struct cbo_ctx {
     cbo_small_result *small_out = nullptr;                      // pinned, written by the kernel directly
     double *small_scratch = nullptr; size_t small_scratch_elems = 0;
     double *small_part_val = nullptr; int64_t *small_part_idx = nullptr; size_t small_part_elems = 0;
-    int *small_info = nullptr;                                  // device, sets_cap status words (zero between calls)
+    int *small_info = nullptr;                                  // device, sets_cap status words + sets_cap tickets (zero between calls)
+    int small_seq = 0;                                          // sequence number of the last multi-set call
     double *q = nullptr, *mu = nullptr, *mean = nullptr, *var = nullptr, *acq = nullptr; size_t vec_elems = 0;
     double *part_val = nullptr; int64_t *part_idx = nullptr;
     double *best_val = nullptr; int64_t *best_idx = nullptr;   // device
@@ -1457,8 +1458,9 @@ static int ensure_small_buffers(cbo_ctx *c, int n_sets, int blocks)
         const int cap = n_sets < 32 ? 32 : n_sets;
         HIP_TRY(hipHostMalloc(&c->sets_host, sizeof(cbo_small_set) * cap));
         HIP_TRY(hipHostMalloc(&c->small_out, sizeof(cbo_small_result) * cap));
-        HIP_TRY(hipMalloc(&c->small_info, sizeof(int) * cap));
-        HIP_TRY(hipMemset(c->small_info, 0, sizeof(int) * cap));
+        HIP_TRY(hipMalloc(&c->small_info, sizeof(int) * 2 * cap));
+        HIP_TRY(hipMemset(c->small_info, 0, sizeof(int) * 2 * cap));
+        std::memset(c->small_out, 0, sizeof(cbo_small_result) * cap);
         c->sets_cap = cap;
     }
     const size_t scratch = small_sets_scratch_doubles(n_sets, blocks), parts = (size_t)n_sets * (size_t)blocks;
@@ -1523,10 +1525,25 @@ extern "C" int cbo_acq_sweep_sets(int n_sets, cbo_gp *const *gps, cbo_cands *con
             st.cost = costs[small[j]];
         }
         const int ns = (int)small.size();
+        if (++c->small_seq == 0) c->small_seq = 1;
+        const int seq = c->small_seq;
         launch_small_sets(c->stream, c->sets_host, ns, blocks, c->small_scratch, c->small_part_val, c->small_part_idx,
-                          c->small_info, c->small_out);
+                          c->small_info, c->small_info + c->sets_cap, c->small_out, seq);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        // the result records arrive in pinned memory, each closed by the call's sequence number: poll them (a few
+        // microseconds sooner than the stream's completion signal); the stream is synchronised if that takes long
+        {
+            bool all = false;
+            for (int spin = 0; spin < (1 << 22) && !all; ++spin) {
+                all = true;
+                for (int j = 0; j < ns; ++j)
+                    if (*reinterpret_cast<volatile int *>(&c->small_out[j].seq) != seq) { all = false; break; }
+            }
+            if (!all || c->profiling) HIP_TRY(hipStreamSynchronize(c->stream));
+            for (int j = 0; j < ns; ++j)
+                if (c->small_out[j].seq != seq) return fail(CBO_ERR_HIP, "multi-set sweep: no result record");
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
         for (int j = 0; j < ns; ++j) {
             if (c->small_out[j].info != 0) continue;        // not positive definite as assembled: the jitchol ladder below
             best_vals[small[(size_t)j]] = c->small_out[j].best_val;

@@ -186,14 +186,15 @@ struct cbo_small_set {
 struct cbo_small_result {
     double best_val;
     int64_t best_idx;
-    int info, pad;                                     // first non-positive pivot (1-based) or 0
+    int info;                                          // first non-positive pivot (1-based) or 0
+    int seq;                                           // the call's sequence number, stored last: the record is complete
 };
 size_t small_sets_scratch_doubles(int n_sets, int blocks_per_set);
-// sets / out may be pinned host memory (device-mapped): the kernels then read the descriptors and write the results
-// across the host link themselves and the call needs no copy operation; info (device, n_sets ints) must be zero on
-// entry and is zero again afterwards
+// sets / out may be pinned host memory (device-mapped): the kernel then reads the descriptors and writes the results
+// across the host link itself and the call needs no copy operation (the host may poll out[].seq instead of
+// synchronising the stream); info and ticket (device, n_sets ints each) must be zero on entry and are zero again afterwards
 void launch_small_sets(hipStream_t s, const cbo_small_set *sets, int n_sets, int blocks_per_set, double *scratch,
-                       double *part_val, int64_t *part_idx, int *info, cbo_small_result *out);
+                       double *part_val, int64_t *part_idx, int *info, int *ticket, cbo_small_result *out, int seq);
 
 struct AcqParams {
     double variance, noise_var, y_best, ei_jitter, cost;

@@ -17,6 +17,7 @@
 //                             rhs[r0+128:] -= P^T z_k
 // The SYRK carries the n^3/3 flops; steps 1-2 are the serial chain.
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "cbo_device.h"
@@ -383,14 +384,16 @@ struct DiagTiles<2> {
 };
 
 template <int W>
-__device__ __forceinline__ void diag_trailing(Diag2Shared &sh, const d4 (&x)[9], const d4 (&nx)[9], int jb, int lane)
+__device__ __forceinline__ void diag_trailing(Diag2Shared &sh, const d4 (&x)[9], const d4 (&nx)[9], int jb, int lane,
+                                              int tiles)
 {
     using L = DiagTiles<W>;
     const int lc = lane & 15, kq = lane >> 4;
 #pragma unroll
     for (int g = 0; g < L::n; g += 4) {
-        // the group's last tile has the largest row index: nothing due in the group -> skip it (uniform)
-        if (L::ti[g + 3] <= jb) continue;
+        // the group's last tile has the largest row index: nothing due in the group -> skip it (uniform); its first
+        // tile the smallest: a group entirely inside the identity padding of a short block has nothing to do either
+        if (L::ti[g + 3] <= jb || L::ti[g] >= tiles) continue;
         d4 acc[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -420,14 +423,22 @@ extern "C" int cbo_diag_chol_stamps(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_stamps), sizeof(unsigned long long) * 4 * 9 * 4);
 }
+__device__ unsigned long long g_small_stamps[16];
+#define SSTAMP(i_) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_small_stamps[(i_)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int cbo_diag_small_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_small_stamps), sizeof(unsigned long long) * 16);
+}
 #else
 #define DSTAMP(wave_, jb_, slot_) do { } while (0)
+#define SSTAMP(i_) do { } while (0)
 #endif
 
 // One interval of one of waves 1..3 (W = wave - 1): its third of the row panel, the rendezvous, its trailing tiles.
 template <int W>
 __device__ __forceinline__ void diag_worker(Diag2Shared &sh, double *A, int64_t lda, int r0, int rcol,
-                                            double *__restrict__ zvec, int jb, const double (&af)[4], int lane)
+                                            double *__restrict__ zvec, int jb, const double (&af)[4], int lane,
+                                            int tiles)
 {
     const int lc = lane & 15, kq = lane >> 4;
     const int o = 16 * jb;
@@ -505,7 +516,7 @@ __device__ __forceinline__ void diag_worker(Diag2Shared &sh, double *A, int64_t 
     // trailing tiles T(ti, tj) -= X_ti^T X_tj, jb < ti <= 7, ti <= tj <= 8, except the next diagonal tile (wave 0's).
     // Ownership is by column (a compile-time list per wave), tiles go four at a time with their accumulation chains
     // interleaved; a tile that is not due (ti <= jb) is computed on stale operands and simply not written back.
-    diag_trailing<W>(sh, x, nx, jb, lane);
+    diag_trailing<W>(sh, x, nx, jb, lane, tiles);
     DSTAMP(W + 1, jb, 3);
 }
 
@@ -566,9 +577,9 @@ __device__ __forceinline__ void diag128_factor_in_lds(Diag2Shared &sh, double *A
             DSTAMP(0, jb, 3);
         } else {
             const int w = wave - 1;
-            if (w == 0) diag_worker<0>(sh, A, lda, r0, rcol, zvec, jb, af, lane);
-            else if (w == 1) diag_worker<1>(sh, A, lda, r0, rcol, zvec, jb, af, lane);
-            else diag_worker<2>(sh, A, lda, r0, rcol, zvec, jb, af, lane);
+            if (w == 0) diag_worker<0>(sh, A, lda, r0, rcol, zvec, jb, af, lane, tiles);
+            else if (w == 1) diag_worker<1>(sh, A, lda, r0, rcol, zvec, jb, af, lane, tiles);
+            else diag_worker<2>(sh, A, lda, r0, rcol, zvec, jb, af, lane, tiles);
         }
         __syncthreads();
     }
@@ -778,21 +789,69 @@ __device__ __forceinline__ void small_kstar_tiles(const SmallShared &sh, const c
             acc[t][r] = (t < tiles) ? small_kstar<D>(sh, st, 16 * t + kq + 4 * r, xc, csq, csv, inv_l2) : 0.0;
 }
 
-__global__ __launch_bounds__(256) void small_sets_kernel(const cbo_small_set *__restrict__ sets, double *scratch,
-                                                         int blocks_per_set, double *__restrict__ part_val,
-                                                         int64_t *__restrict__ part_idx, int *__restrict__ info)
+// The last workgroup of a set to finish (an atomic ticket) reduces the set's per-workgroup winners, hands the result
+// record to the host (pinned, device-mapped memory; `seq` is stored last, after a system-scope fence, so that the host
+// can poll it) and re-arms the set's status word and ticket for the next call.
+__device__ __forceinline__ void small_set_finish(double bv, int64_t bi, int set, int slot, int blocks_per_set,
+                                                 double *__restrict__ part_val, int64_t *__restrict__ part_idx,
+                                                 int *__restrict__ info, int *__restrict__ ticket,
+                                                 cbo_small_result *__restrict__ out, int seq, int *last_flag)
 {
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        part_val[slot] = bv;
+        part_idx[slot] = bi;
+        __threadfence();
+        *last_flag = (atomicAdd(&ticket[set], 1) == blocks_per_set - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (*last_flag == 0 || tid >= 64) return;
+    __threadfence();
+    bv = -INFINITY;
+    bi = INT64_MAX;
+    for (int b = tid; b < blocks_per_set; b += 64) {
+        const double v = __builtin_nontemporal_load(&part_val[set * blocks_per_set + b]);
+        const int64_t i = __builtin_nontemporal_load(&part_idx[set * blocks_per_set + b]);
+        if (better(v, i, bv, bi)) { bv = v; bi = i; }
+    }
+    wave_argmax(bv, bi);
+    if (tid == 0) {
+        out[set].best_val = bv;
+        out[set].best_idx = bi;
+        out[set].info = atomicAdd(&info[set], 0);
+        __threadfence_system();
+        *reinterpret_cast<volatile int *>(&out[set].seq) = seq;
+        info[set] = 0;
+        ticket[set] = 0;
+    }
+}
+
+// Up to kSmallByValue descriptors travel as kernel arguments (no read across the host link before the first
+// instruction that needs them); longer lists are read from the pinned array.
+constexpr int kSmallByValue = 8;
+struct SmallSetArgs { cbo_small_set s[kSmallByValue]; };
+
+template <bool BYVAL>
+__global__ __launch_bounds__(256) void small_sets_kernel(const SmallSetArgs byval, const cbo_small_set *__restrict__ sets,
+                                                         double *scratch, int blocks_per_set,
+                                                         double *__restrict__ part_val, int64_t *__restrict__ part_idx,
+                                                         int *__restrict__ info, int *__restrict__ ticket,
+                                                         cbo_small_result *__restrict__ out, int seq)
+{
+    __shared__ int last_flag;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     SmallShared &sh = *reinterpret_cast<SmallShared *>(smem_raw);
     const int set = blockIdx.y, blk = blockIdx.x;
-    const cbo_small_set st = sets[set];
+    SSTAMP(0);
+    const cbo_small_set st = BYVAL ? byval.s[set] : sets[set];
     const int slot = set * blocks_per_set + blk;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lc = lane & 15, kq = lane >> 4;
     if ((int64_t)blk * 64 >= st.m) {                              // no candidates left for this workgroup
-        if (tid == 0) { part_val[slot] = -INFINITY; part_idx[slot] = INT64_MAX; }
+        small_set_finish(-INFINITY, INT64_MAX, set, slot, blocks_per_set, part_val, part_idx, info, ticket, out, seq,
+                         &last_flag);
         return;
     }
     const int tiles = (st.n + 15) / 16;
@@ -807,6 +866,7 @@ __global__ __launch_bounds__(256) void small_sets_kernel(const cbo_small_set *__
         sh.sv[tid] = (in && st.sv) ? st.sv[tid] : 0.0;
     }
     __syncthreads();
+    SSTAMP(1);
     switch (st.d) {
         case 1: small_assemble<1>(sh, st, tiles); break;
         case 2: small_assemble<2>(sh, st, tiles); break;
@@ -819,15 +879,17 @@ __global__ __launch_bounds__(256) void small_sets_kernel(const cbo_small_set *__
     }
     {
         const int rows = 16 * tiles;
-        for (int idx = tid; idx < rows * (kDiagLd - rows); idx += 256) {
-            const int r = idx / (kDiagLd - rows), c = rows + idx % (kDiagLd - rows);
-            double v = 0.0;
-            if (c == 128 && r < st.n) v = st.pm ? __dadd_rn(st.y[r], -st.pm[r]) : st.y[r];   // r = y - m(X)
-            sh.blk.S[r][c] = v;
-        }
+        for (int r = tid >> 4; r < rows; r += 16)
+            for (int c = rows + (tid & 15); c < kDiagLd; c += 16) {
+                double v = 0.0;
+                if (c == 128 && r < st.n) v = st.pm ? __dadd_rn(st.y[r], -st.pm[r]) : st.y[r];   // r = y - m(X)
+                sh.blk.S[r][c] = v;
+            }
     }
     __syncthreads();
+    SSTAMP(2);
     diag128_factor_in_lds(sh.blk, Us, kSmallLd, 0, 128, invs, &info[set], nullptr, tiles);
+    SSTAMP(3);
     // (ends with a barrier.)  Every wave's stores of factor rows / inverses / z are complete before anyone re-reads them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -847,6 +909,7 @@ __global__ __launch_bounds__(256) void small_sets_kernel(const cbo_small_set *__
             iv[s][kk] = (s < tiles) ? invs[s * 256 + (4 * kk + kq) * 16 + lc] : 0.0;
             zr[s][kk] = (s < tiles) ? Us[(int64_t)(16 * s + kq + 4 * kk) * kSmallLd + 128] : 0.0;
         }
+    SSTAMP(4);
     // ---- K(X, X*) of this wave's 16 candidates, straight into the result layout
     const int64_t c = (int64_t)blk * 64 + wave * 16 + lc;
     const int64_t cc = (c < st.m) ? c : st.m - 1;                  // clamped: lanes beyond the set compute, nobody looks
@@ -869,6 +932,7 @@ __global__ __launch_bounds__(256) void small_sets_kernel(const cbo_small_set *__
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    SSTAMP(5);
     // ---- V = L^-1 K*, q = sum V^2, mu = V^T z (lane partials, then over the four lane groups: the strip kernel's order)
     double qacc = 0.0, macc = 0.0;
     panel_solve_tiles(&sh.blk.S[kq][lc], acc, iv, tiles, [&](int s, const d4 &x) {
@@ -883,6 +947,7 @@ __global__ __launch_bounds__(256) void small_sets_kernel(const cbo_small_set *__
     macc += __shfl_xor(macc, 16);
     macc += __shfl_xor(macc, 32);
 
+    SSTAMP(6);
     // ---- epilogue and the workgroup's arg-max
     AcqParams p;
     p.variance = st.variance; p.noise_var = st.noise_var; p.y_best = st.y_best; p.ei_jitter = st.ei_jitter;
@@ -904,48 +969,35 @@ __global__ __launch_bounds__(256) void small_sets_kernel(const cbo_small_set *__
     if (tid == 0) {
         for (int w = 1; w < 4; ++w)
             if (better(red_v[w], red_i[w], bv, bi)) { bv = red_v[w]; bi = red_i[w]; }
-        part_val[slot] = bv;
-        part_idx[slot] = bi;
     }
-}
-
-// per set: reduce the workgroups' winners, hand the result record to the host (pinned, device-mapped memory: no copy
-// operation on the stream), and re-arm the set's status word for the next call
-__global__ void small_sets_final_kernel(const double *__restrict__ part_val, const int64_t *__restrict__ part_idx,
-                                        int blocks_per_set, int *__restrict__ info, cbo_small_result *__restrict__ out)
-{
-    const int set = blockIdx.x;
-    double bv = -INFINITY;
-    int64_t bi = INT64_MAX;
-    for (int b = threadIdx.x; b < blocks_per_set; b += 64)
-        if (better(part_val[set * blocks_per_set + b], part_idx[set * blocks_per_set + b], bv, bi)) {
-            bv = part_val[set * blocks_per_set + b];
-            bi = part_idx[set * blocks_per_set + b];
-        }
-    wave_argmax(bv, bi);
-    if (threadIdx.x == 0) {
-        out[set].best_val = bv;
-        out[set].best_idx = bi;
-        out[set].info = info[set];
-        info[set] = 0;
-    }
+    SSTAMP(7);
+    small_set_finish(bv, bi, set, slot, blocks_per_set, part_val, part_idx, info, ticket, out, seq, &last_flag);
+    SSTAMP(8);
 }
 
 size_t small_sets_scratch_doubles(int n_sets, int blocks_per_set) { return (size_t)n_sets * blocks_per_set * kSmallScratch; }
 
 void launch_small_sets(hipStream_t s, const cbo_small_set *sets, int n_sets, int blocks_per_set, double *scratch,
-                       double *part_val, int64_t *part_idx, int *info, cbo_small_result *out)
+                       double *part_val, int64_t *part_idx, int *info, int *ticket, cbo_small_result *out, int seq)
 {
     static bool once = [] {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(small_sets_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)sizeof(SmallShared));
+        hipFuncSetAttribute(reinterpret_cast<const void *>(small_sets_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmallShared));
+        hipFuncSetAttribute(reinterpret_cast<const void *>(small_sets_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmallShared));
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL(small_sets_kernel, dim3((unsigned)blocks_per_set, (unsigned)n_sets), dim3(256), sizeof(SmallShared), s,
-                       sets, scratch, blocks_per_set, part_val, part_idx, info);
-    hipLaunchKernelGGL(small_sets_final_kernel, dim3((unsigned)n_sets), dim3(64), 0, s, part_val, part_idx, blocks_per_set,
-                       info, out);
+    SmallSetArgs args{};
+    const dim3 grid((unsigned)blocks_per_set, (unsigned)n_sets);
+    if (n_sets <= kSmallByValue) {
+        std::memcpy(args.s, sets, sizeof(cbo_small_set) * (size_t)n_sets);
+        hipLaunchKernelGGL(small_sets_kernel<true>, grid, dim3(256), sizeof(SmallShared), s, args, sets, scratch,
+                           blocks_per_set, part_val, part_idx, info, ticket, out, seq);
+    } else {
+        hipLaunchKernelGGL(small_sets_kernel<false>, grid, dim3(256), sizeof(SmallShared), s, args, sets, scratch,
+                           blocks_per_set, part_val, part_idx, info, ticket, out, seq);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
