@@ -41,10 +41,22 @@ class CausalGradientAcquisitionOptimizer:
         x, fx, _ = fmin_l_bfgs_b(f_df, np.asarray(x0, dtype=np.float64).reshape(-1), bounds=self.bounds, maxfun=1000)
         return x[None, :], np.array([[-fx]])
 
-    def optimize(self, acquisition, context=None, refine=False):
+    def refine_batched(self, acquisition, x0, max_rounds=200, history=8):
+        """Multi-start refinement ("batched multi-start L-BFGS from top-k grid points"): every row of
+        ``x0`` ((k,d)) is the start of its own projected L-BFGS ascent, and the k searches advance in lockstep -- one
+        ``evaluate_with_gradients`` call on a (k,d) batch per round (one pair of batched device solves), whatever each
+        search is doing (a first trial step, a backtracked one).  Returns (points (k,d), values (k,))."""
+        lo = np.array([b[0] for b in self.bounds], dtype=np.float64)
+        hi = np.array([b[1] for b in self.bounds], dtype=np.float64)
+        return lockstep_lbfgs(lambda X: _values_and_gradients(acquisition, X), np.asarray(x0, dtype=np.float64), lo, hi,
+                              max_rounds=max_rounds, history=history)
+
+    def optimize(self, acquisition, context=None, refine=False, num_starts=1):
         """(x_max (1,d), acquisition value at x_max (1,1)) -- emukit ``AcquisitionOptimizerBase.optimize``.
         ``acquisition`` is ``CausalExpectedImprovement(...) / Cost(...)`` (an ``AcquisitionQuotient``) or a bare
-        ``CausalExpectedImprovement``."""
+        ``CausalExpectedImprovement``.  ``refine=True`` adds the reference's gradient stage: from the best grid point
+        with scipy's L-BFGS-B (``num_starts=1``, what the reference does with its best anchor), or from the
+        ``num_starts`` best grid points at once (``refine_batched``)."""
         # the grid of this optimiser stays on the device while the model object is the same (no allocation per call)
         model = acquisition.model
         if self._grid is None or self._grid_model is not model:
@@ -52,11 +64,110 @@ class CausalGradientAcquisitionOptimizer:
                 self._grid.close()
             self._grid, self._grid_model = CandidateGrid(self.candidates(), model), model
         grid, pts = self._grid, self._grid.points
-        res = acquisition.sweep(grid)
+        k = max(1, min(int(num_starts), pts.shape[0])) if refine else 1
+        res = acquisition.sweep(grid, want_acq=k > 1)
         x = pts[res["best_idx"]][None, :].copy()
         fx = np.array([[res["best_val"]]])
-        if refine:
+        if refine and k == 1:
             xr, fr = self.refine(acquisition, x)
             if fr[0, 0] >= fx[0, 0]:
                 x, fx = xr, fr
+        elif refine:
+            acq = np.asarray(res["acq"], dtype=np.float64).reshape(-1)
+            top = np.argpartition(-acq, k - 1)[:k]
+            top = top[np.argsort(-acq[top], kind="stable")]
+            xs, fs = self.refine_batched(acquisition, pts[top])
+            best = int(np.argmax(fs))
+            if fs[best] >= fx[0, 0]:
+                x, fx = xs[best][None, :].copy(), np.array([[fs[best]]])
         return x, fx
+
+
+def _values_and_gradients(acquisition, X):
+    """(values (k,), gradients (k,d)) of every row of X taken as a batch of ONE point: the posterior and its gradients
+    for all rows come from one batched device call; a cost that depends on the point (cost_functions.py:11-17 sums
+    |x| over the batch it is given) is evaluated row by row, as k single-point calls of the reference would."""
+    num = getattr(acquisition, "numerator", None)
+    if num is None:
+        f, df = acquisition.evaluate_with_gradients(X)
+        return f[:, 0], df
+    f, df = num.evaluate_with_gradients(X)
+    c = np.array([float(acquisition.denominator.evaluate(X[i:i + 1])) for i in range(X.shape[0])])
+    return f[:, 0] / c, df / c[:, None]
+
+
+def lockstep_lbfgs(fun, x0, lo, hi, max_rounds=200, history=8, pgtol=1e-5, ftol=2.2e-9, c1=1e-4):
+    """Maximise ``fun`` over the box [lo, hi] from every row of ``x0`` at once.  ``fun(X)`` -> (values (k,),
+    gradients (k,d)) is called ONCE per round on the (k,d) array of the searches' current trial points.  Each search
+    is a projected L-BFGS iteration with Armijo backtracking (two-loop recursion over ``history`` pairs, steps
+    clipped to the box, curvature pairs with s.y <= 0 dropped); a search that has converged (projected gradient below
+    ``pgtol``, relative gain below ``ftol`` -- scipy's L-BFGS-B defaults -- or a vanishing step) keeps its point and
+    is re-evaluated along with the others (the batch shape stays fixed).  Returns (points (k,d), values (k,))."""
+    X = np.clip(np.asarray(x0, dtype=np.float64).copy(), lo, hi)
+    k, d = X.shape
+    F, G = fun(X)
+    F, G = -np.asarray(F, dtype=np.float64), -np.asarray(G, dtype=np.float64)          # minimise -fun
+    S = [[] for _ in range(k)]
+    Y = [[] for _ in range(k)]
+    done = np.zeros(k, dtype=bool)
+    D = np.zeros((k, d))
+    T = np.zeros(k)
+
+    def projected_gradient(x, g):
+        pg = g.copy()
+        pg[(x <= lo) & (g > 0)] = 0.0                # cannot go below the lower bound
+        pg[(x >= hi) & (g < 0)] = 0.0
+        return pg
+
+    def direction(i):
+        pg = projected_gradient(X[i], G[i])
+        q = pg.copy()
+        alphas = []
+        for s, y in zip(reversed(S[i]), reversed(Y[i])):
+            a = s.dot(q) / y.dot(s)
+            alphas.append(a)
+            q -= a * y
+        if S[i]:
+            q *= S[i][-1].dot(Y[i][-1]) / Y[i][-1].dot(Y[i][-1])
+        for (s, y), a in zip(zip(S[i], Y[i]), reversed(alphas)):
+            q += (a - y.dot(q) / y.dot(s)) * s
+        dvec = -q
+        if dvec.dot(pg) >= 0.0:                      # not a descent direction (stale curvature at a bound)
+            dvec = -pg
+            S[i].clear(); Y[i].clear()
+        return dvec, pg
+
+    for i in range(k):
+        D[i], pg = direction(i)
+        n = np.linalg.norm(pg)
+        done[i] = np.max(np.abs(pg)) <= pgtol
+        T[i] = min(1.0, 1.0 / n) if n > 0 else 0.0
+    for _ in range(max_rounds):
+        if done.all():
+            break
+        trial = np.where(done[:, None], X, np.clip(X + T[:, None] * D, lo, hi))
+        Ft, Gt = fun(trial)
+        Ft, Gt = -np.asarray(Ft, dtype=np.float64), -np.asarray(Gt, dtype=np.float64)
+        for i in range(k):
+            if done[i]:
+                continue
+            step = trial[i] - X[i]
+            if not np.isfinite(Ft[i]) or Ft[i] > F[i] + c1 * G[i].dot(step):
+                T[i] *= 0.5                          # Armijo failed: shorter step next round
+                if T[i] * np.max(np.abs(D[i])) < 1e-14:
+                    done[i] = True
+                continue
+            y = Gt[i] - G[i]
+            gain = F[i] - Ft[i]
+            if step.dot(y) > 1e-12 * np.linalg.norm(step) * np.linalg.norm(y):
+                S[i].append(step.copy()); Y[i].append(y)
+                if len(S[i]) > history:
+                    S[i].pop(0); Y[i].pop(0)
+            small = gain <= ftol * max(abs(F[i]), abs(Ft[i]), 1.0)
+            X[i], F[i], G[i] = trial[i], Ft[i], Gt[i]
+            D[i], pg = direction(i)
+            T[i] = 1.0
+            if small or np.max(np.abs(pg)) <= pgtol:
+                done[i] = True
+    return X, -F
+

@@ -610,6 +610,53 @@ def test_prediction_gradients_and_refinement(hip):
     assert np.isclose(f1[0, 0], -fxo, rtol=1e-5) and np.allclose(x1[0], xo, atol=1e-4)
 
 
+def test_multi_start_refinement_in_lockstep(hip):
+    """Top-k grid points refined at once: one batched device call per round for all k searches; every
+    search ends at least as high as it started, the winner is at least the single-start result, and the values the
+    searches report are the oracle's acquisition at the points they report.  A variable cost (summed |x| of the batch it
+    is given) is charged per point, as k separate single-point calls would."""
+    from cbo_with_oop_amd.utils_functions import CausalExpectedImprovement, CausalGradientAcquisitionOptimizer, Cost
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    from cbo_with_oop_amd.graphs import CompleteGraph
+    rng = np.random.default_rng(33)
+    X = rng.uniform([-5, -5], [4, 5], (120, 2))
+    y = np.sin(1.7 * X[:, :1]) * np.cos(1.3 * X[:, 1:]) + 0.05 * rng.standard_normal((120, 1))
+    m = HipGaussianProcess(X, y, variance=1.0, lengthscale=0.8, noise_var=1e-3)
+    post = O.fit(X, y, variance=1.0, lengthscale=0.8, noise_var=1e-3)
+    best = float(y.min())
+    bounds = CompleteGraph.bounds(["B", "D"])
+    ei = CausalExpectedImprovement(best, "min", m)
+    calls = []
+    predict = m.get_prediction_gradients
+    m.get_prediction_gradients = lambda x: (calls.append(np.shape(x)[0]), predict(x))[1]
+    for cost_kind, scale in ((1, lambda P: np.full(len(P), 2.0)), (3, None)):
+        acq = ei / Cost(CompleteGraph.get_cost_structure(cost_kind), ["B", "D"])
+        opt = CausalGradientAcquisitionOptimizer(bounds, grid_shape=[24, 24])
+        x0, f0 = opt.optimize(acq)
+        x1, f1 = opt.optimize(acq, refine=True)
+        calls.clear()
+        x8, f8 = opt.optimize(acq, refine=True, num_starts=8)
+        assert calls and set(calls) == {8}, calls                       # every round is ONE batch of the 8 searches
+        assert all(lo <= v <= hi for v, (lo, hi) in zip(x8[0], bounds))
+        fixed = cost_kind == 1      # (a variable cost prices the grid as ONE batch: grid and point values differ in scale)
+        if fixed:
+            assert f8[0, 0] >= f0[0, 0] and f8[0, 0] >= f1[0, 0] - 1e-9 * abs(f1[0, 0])
+        # the searches themselves, from the 8 best grid points
+        res = acq.sweep(opt._grid, want_acq=True)
+        a = np.asarray(res["acq"]).reshape(-1)
+        top = np.argsort(-a, kind="stable")[:8]
+        starts = opt._grid.points[top]
+        pts, vals = opt.refine_batched(acq, starts)
+        if fixed:
+            assert np.all(vals >= a[top] - 1e-12) and np.isclose(vals.max(), f8[0, 0], rtol=1e-12)
+        fo, _ = O.expected_improvement_with_gradients(post, pts, best)
+        cost = np.array([float(acq.denominator.evaluate(pts[i:i + 1])) for i in range(8)])
+        if scale is not None:
+            assert np.allclose(cost, scale(pts))
+        assert np.allclose(vals, fo[:, 0] / cost, rtol=1e-6, atol=1e-14)
+    m.close()
+
+
 def _free_port():
     import socket
     s = socket.socket()
