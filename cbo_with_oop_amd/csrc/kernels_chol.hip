@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(256) void syrk_rows_kernel(double *A, int64_t lda, 
     d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
     const double *Pa = P + (int64_t)kq * lda + ib + lc;          // A[i = lc][k = kq] = P[k][ib + i]  (+16: second row tile)
     const double *Pb = P + (int64_t)kq * lda + jb + lc;          // B[k = kq][j = lc] = P[k][jb + j]
-    constexpr int CH = 8;                                        // k-steps per software-pipeline chunk
+    constexpr int CH = 8;                                        // k-steps per software-pipeline chunk (16: more registers, no faster)
     double a0[2][CH], a1[2][CH], b[2][CH];
     auto load_chunk = [&](int k0, int buf) __attribute__((always_inline)) {
 #pragma unroll
