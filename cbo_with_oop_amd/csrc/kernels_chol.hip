@@ -1316,7 +1316,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
                         (int)sizeof(PanelShared));
     static const int panel_form = [] { const char *e = std::getenv("CBO_HIP_PANEL_FORM"); return e ? std::atoi(e) : 2; }();
     static const int syrk_gemm_rows = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_ROWS"); return e ? std::atoi(e) : 6144; }();
-    static const int syrk_gemm_chunk = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_CHUNK"); return e ? std::atoi(e) : 2; }();
+    static const int syrk_gemm_chunk = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_CHUNK"); return e ? std::atoi(e) : 1; }();
     static const bool syrk_gemm_half = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_KB"); return !(e && std::atoi(e) == 32); }();
     static const int syrk_rows_form = [] { const char *e = std::getenv("CBO_HIP_SYRK_ROWS_FORM"); return e ? std::atoi(e) : 2; }();
     static const int diag_form = [] { const char *e = std::getenv("CBO_HIP_DIAG_FORM"); return e ? std::atoi(e) : 2; }();
@@ -1350,6 +1350,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     double *zvec = pipe ? pipe->zvec : nullptr;
     // beside a pipelined sweep the panel solves use the half-LDS kernel, which fits next to a sweep workgroup
     const bool half_lds = pipe && pipe->half_lds;
+    const bool lean_panel = (panel_form == 2 && !pipe) || panel_form == 3;     // 3: also beside a pipelined sweep
     int pair = 0;
     auto sweep_rows = [&](int r0, int klen) {
         if (pipe && r0 < pipe->tail_begin) sweep_pipe_pair(*pipe, s, A, lda, invDt, n_pad, pair++, r0, klen);
@@ -1367,7 +1368,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         launch_diag(r0);
         const int n2 = (int)n_pad - r0 - 128;
         if (n2 <= 0) { sweep_rows(r0, 128); break; }
-        if (panel_form == 2 && !pipe) launch_panel_trsm(s, A, lda, r0, r0 + 128, n2, invDt, info_dev);   // (beside a pipelined sweep: the half-LDS strip kernel)
+        if (lean_panel) launch_panel_trsm(s, A, lda, r0, r0 + 128, n2, invDt, info_dev);   // (beside a pipelined sweep: the half-LDS strip kernel)
         else
         launch_trsm_strips(s, A + (int64_t)r0 * lda + r0, lda, invDt + (int64_t)(r0 / 16) * 256,
                            A + (int64_t)r0 * lda + r0 + 128, lda, 128, n2, nullptr, nullptr, nullptr, false, half_lds);
@@ -1378,7 +1379,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         launch_diag(r1);
         const int n3 = (int)n_pad - r1 - 128;
         if (n3 <= 0) { sweep_rows(r0, 256); break; }
-        if (panel_form == 2 && !pipe) launch_panel_trsm(s, A, lda, r1, r1 + 128, n3, invDt, info_dev);
+        if (lean_panel) launch_panel_trsm(s, A, lda, r1, r1 + 128, n3, invDt, info_dev);
         else
         launch_trsm_strips(s, A + (int64_t)r1 * lda + r1, lda, invDt + (int64_t)(r1 / 16) * 256,
                            A + (int64_t)r1 * lda + r1 + 128, lda, 128, n3, nullptr, nullptr, nullptr, false, half_lds);
