@@ -284,8 +284,11 @@ class HipGaussianProcess:
 
     def log_likelihood_gradients(self):
         """(d log p(y)/d variance, d/d lengthscale (array), d/d noise_var) of the fitted model: the gradients GPy's
-        inference hands its optimiser, computed on the device (``cbo_gp_lml_gradients``)."""
-        self.ensure_fitted()
+        inference hands its optimiser, computed on the device (``cbo_gp_lml_gradients``).  A model of at most 128
+        observations is not fitted for this: one launch goes from the data and the current hyper-parameters to the
+        likelihood and its gradients (the general path, jitchol ladder included, takes over when that fails)."""
+        if not self.small:
+            self.ensure_fitted()
         lml, dv, dn = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
         dls = np.zeros(self.lengthscale.size)
         _lib.check(self._lib.cbo_gp_lml_gradients(self._handle, ctypes.byref(lml), ctypes.byref(dv), _lib.dptr(dls),
@@ -302,7 +305,7 @@ class HipGaussianProcess:
         try:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore", RuntimeWarning)
-                self.set_hyperparameters(theta[0], theta[1:1 + nl], noise)
+                self.set_hyperparameters(theta[0], theta[1:1 + nl], noise, fit=not self.small)
             dv, dls, dn = self.log_likelihood_gradients()
         except np.linalg.LinAlgError:
             return 1e25, np.zeros_like(log_theta)      # GPy's optimiser treats a failed Cholesky as a rejected step

@@ -99,6 +99,7 @@ struct cbo_ctx {
     double *small_part_val = nullptr; int64_t *small_part_idx = nullptr; size_t small_part_elems = 0;
     int *small_info = nullptr;                                  // device, sets_cap status words + sets_cap tickets (zero between calls)
     int small_seq = 0;                                          // sequence number of the last multi-set call
+    cbo_small_lml_result *lml_out = nullptr;                    // pinned, written by small_lml_kernel
     double *q = nullptr, *mu = nullptr, *mean = nullptr, *var = nullptr, *acq = nullptr; size_t vec_elems = 0;
     double *part_val = nullptr; int64_t *part_idx = nullptr;
     double *best_val = nullptr; int64_t *best_idx = nullptr;   // device
@@ -394,7 +395,7 @@ static void destroy_ctx(cbo_ctx *c)
     for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->pool) hipEventDestroy(e);
     hipFree(c->W); hipFree(c->gpart); hipFree(c->mupart);
-    hipHostFree(c->sets_host); hipHostFree(c->small_out); hipFree(c->small_scratch); hipFree(c->small_part_val);
+    hipHostFree(c->sets_host); hipHostFree(c->small_out); hipHostFree(c->lml_out); hipFree(c->small_scratch); hipFree(c->small_part_val);
     hipFree(c->small_part_idx); hipFree(c->small_info);
     hipFree(c->V); hipFree(c->q); hipFree(c->mu); hipFree(c->mean); hipFree(c->var); hipFree(c->acq);
     hipFree(c->part_val); hipFree(c->part_idx); hipFree(c->best_val); hipFree(c->best_idx);
@@ -1448,6 +1449,17 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
 // fitted state alone.  A set whose factorisation meets a non-positive pivot there (jitchol's business), a larger
 // model, or an fp32 model takes the general path: cbo_gp_fit_sweep when the model is not fitted, cbo_acq_sweep
 // otherwise.
+// the model half of a one-workgroup kernel's descriptor
+static void fill_small_model(cbo_small_set &st, const cbo_gp *g)
+{
+    const bool causal = g->X.sv != nullptr;
+    st.xs = g->X.xs; st.sq = g->X.sq; st.sv = g->X.sv; st.pm = causal ? g->X.pm : nullptr; st.y = g->y;
+    st.ld = g->X.ld;
+    st.n = (int)g->n; st.d = g->d; st.zero_diag = g->h.zero_diag; st.ard = g->h.ard; st.pad_ = 0;
+    st.variance = g->h.variance; st.lengthscale = g->h.lengthscale; st.noise_var = g->noise_var;
+    st.diag_add = g->noise_var + kGpyDiagJitter;
+}
+
 static int ensure_small_buffers(cbo_ctx *c, int n_sets, int blocks)
 {
     if (n_sets > c->sets_cap) {
@@ -1515,13 +1527,11 @@ extern "C" int cbo_acq_sweep_sets(int n_sets, cbo_gp *const *gps, cbo_cands *con
             if (rc != CBO_OK) return rc;
             const bool causal = g->X.sv != nullptr;
             cbo_small_set &st = c->sets_host[j];
-            st.xs = g->X.xs; st.sq = g->X.sq; st.sv = g->X.sv; st.pm = causal ? g->X.pm : nullptr; st.y = g->y;
+            fill_small_model(st, g);
             st.cxs = k->P.xs; st.csq = k->P.sq; st.csv = causal ? k->P.sv : nullptr;
             st.cpm = causal ? k->pm : nullptr; st.cpv = causal ? k->pv : nullptr;
-            st.ld = g->X.ld; st.cld = k->P.ld; st.m = k->m; st.index_offset = k->index_offset;
-            st.n = (int)g->n; st.d = g->d; st.zero_diag = g->h.zero_diag; st.task = task;
-            st.variance = g->h.variance; st.lengthscale = g->h.lengthscale; st.noise_var = g->noise_var;
-            st.diag_add = g->noise_var + kGpyDiagJitter; st.y_best = y_best[small[j]]; st.ei_jitter = ei_jitter;
+            st.cld = k->P.ld; st.m = k->m; st.index_offset = k->index_offset;
+            st.task = task; st.y_best = y_best[small[j]]; st.ei_jitter = ei_jitter;
             st.cost = costs[small[j]];
         }
         const int ns = (int)small.size();
@@ -1663,13 +1673,73 @@ extern "C" int cbo_gp_log_marginal(cbo_gp *g, double *lml_out)
 // kern.update_gradients_full, dL_dthetaL).  Ky^-1 = L^-T L^-1 on the device: L^-1 by the sweep machinery on
 // identity right-hand sides (its q output is diag(Ky^-1)), the product by the GEMM form of the update kernel over
 // the non-zero lower-triangular part only, the contraction with dK/dtheta by one pass over the upper tiles.
+// host arithmetic shared by both forms of the likelihood gradients: hs = variance sum, lengthscale sums per dimension
+static void lml_outputs(const cbo_gp *g, const double *grad_sums, double zz, double logdet, double aa, double tr_w,
+                        double *lml_out, double *dvariance_out, double *dlengthscale_out, double *dnoise_out)
+{
+    *dvariance_out = 0.5 * grad_sums[0] / g->h.variance;
+    if (g->h.ard) {
+        for (int k = 0; k < g->d; ++k) dlengthscale_out[k] = 0.5 * grad_sums[1 + k] / g->ls[(size_t)k];
+    } else {
+        double sum = 0.0;
+        for (int k = 0; k < g->d; ++k) sum += grad_sums[1 + k];
+        dlengthscale_out[0] = 0.5 * sum / g->h.lengthscale;
+    }
+    *dnoise_out = 0.5 * (aa - tr_w);
+    if (lml_out) *lml_out = 0.5 * (-(double)g->n * 1.8378770664093453 - 2.0 * logdet - zz);
+}
+
+// Models of at most 128 observations (every model the reference builds): likelihood and gradients in ONE launch, from
+// the data and the current hyper-parameters -- no fit beforehand, none left behind.  Returns 1 when done, 0 when the
+// general path has to take over (Ky not positive definite as assembled: the jitchol ladder lives there), < 0 on error.
+static int small_lml_gradients(cbo_gp *g, double *lml_out, double *dvariance_out, double *dlengthscale_out,
+                               double *dnoise_out)
+{
+    cbo_ctx *c = g->ctx;
+    if (!(g->dtype == CBO_DTYPE_F64 && g->n_pad == kPadN && c->small_sets && g->n > 0)) return 0;
+    int rc = ensure_small_buffers(c, 1, 2);            // scratch of two workgroup slots >= factor + L^-1
+    if (rc != CBO_OK) return rc;
+    if (!c->lml_out) {
+        if (hipHostMalloc(&c->lml_out, sizeof(cbo_small_lml_result)) != hipSuccess) return fail(CBO_ERR_HIP, "hipHostMalloc");
+        std::memset(c->lml_out, 0, sizeof(cbo_small_lml_result));
+    }
+    cbo_small_set st{};
+    fill_small_model(st, g);
+    if (++c->small_seq == 0) c->small_seq = 1;
+    const int seq = c->small_seq;
+    launch_small_lml(c->stream, st, c->small_scratch, c->small_info, c->lml_out, seq);
+    if (hipGetLastError() != hipSuccess) return fail(CBO_ERR_HIP, "small_lml_kernel launch");
+    bool ready = false;
+    for (int spin = 0; spin < (1 << 22) && !ready; ++spin)
+        ready = *reinterpret_cast<volatile int *>(&c->lml_out->seq) == seq;
+    if (!ready || c->profiling) {
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(CBO_ERR_HIP, "hipStreamSynchronize");
+        if (c->lml_out->seq != seq) return fail(CBO_ERR_HIP, "likelihood kernel: no result record");
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (c->lml_out->info != 0) return 0;
+    const double *t = c->lml_out->terms;
+    lml_outputs(g, t, t[1 + CBO_MAX_DIM], t[1 + CBO_MAX_DIM + 1], t[1 + CBO_MAX_DIM + 2], t[1 + CBO_MAX_DIM + 3], lml_out,
+                dvariance_out, dlengthscale_out, dnoise_out);
+    return 1;
+}
+
 extern "C" int cbo_gp_lml_gradients(cbo_gp *g, double *lml_out, double *dvariance_out, double *dlengthscale_out,
                                     double *dnoise_out)
 {
     if (!g || !dvariance_out || !dlengthscale_out || !dnoise_out) return fail(CBO_ERR_INVALID, "NULL argument");
-    if (!g->fitted) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
     cbo_ctx *c = g->ctx;
     HIP_TRY(hipSetDevice(c->device));
+    {
+        const int done = small_lml_gradients(g, lml_out, dvariance_out, dlengthscale_out, dnoise_out);
+        if (done < 0) return done;
+        if (done == 1) return CBO_OK;
+    }
+    if (!g->fitted) {                      // (a small model that was not positive definite as assembled lands here)
+        if (g->n_pad != kPadN) return fail(CBO_ERR_NOT_FITTED, "gp is not fitted");
+        const int frc = cbo_gp_fit(g, nullptr, nullptr);
+        if (frc != CBO_OK) return frc;
+    }
     int rc = ensure_alpha(g);
     if (rc != CBO_OK) return rc;
     const int64_t n_pad = g->n_pad;
@@ -1715,17 +1785,7 @@ extern "C" int cbo_gp_lml_gradients(cbo_gp *g, double *lml_out, double *dvarianc
     double hs[24];
     HIP_TRY(hipMemcpyAsync(hs, c->part_val, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    const double tr_w = hs[22], aa = hs[20];
-    *dvariance_out = 0.5 * hs[0] / g->h.variance;
-    if (g->h.ard) {
-        for (int k = 0; k < g->d; ++k) dlengthscale_out[k] = 0.5 * hs[1 + k] / g->ls[(size_t)k];
-    } else {
-        double sum = 0.0;
-        for (int k = 0; k < g->d; ++k) sum += hs[1 + k];
-        dlengthscale_out[0] = 0.5 * sum / g->h.lengthscale;
-    }
-    *dnoise_out = 0.5 * (aa - tr_w);
-    if (lml_out) *lml_out = 0.5 * (-(double)g->n * 1.8378770664093453 - 2.0 * hs[17] - hs[16]);
+    lml_outputs(g, hs, hs[16], hs[17], hs[20], hs[22], lml_out, dvariance_out, dlengthscale_out, dnoise_out);
     return CBO_OK;
 }
 

@@ -182,6 +182,7 @@ struct cbo_small_set {
     int64_t ld, cld, m, index_offset;
     int n, d, zero_diag, task;
     double variance, lengthscale, noise_var, diag_add, y_best, ei_jitter, cost;
+    int ard, pad_;                                     // inputs pre-scaled per dimension (lengthscale gradient per dimension)
 };
 struct cbo_small_result {
     double best_val;
@@ -190,6 +191,15 @@ struct cbo_small_result {
     int seq;                                           // the call's sequence number, stored last: the record is complete
 };
 size_t small_sets_scratch_doubles(int n_sets, int blocks_per_set);
+// one-launch likelihood + gradients of a small model (kernels_chol.hip): terms[0] = variance sum, terms[1 + k] =
+// lengthscale sums per dimension, then z^T z, sum log diag(U), alpha^T alpha, tr(Ky^-1)
+constexpr int kSmallLmlTerms = 1 + CBO_MAX_DIM + 4;
+struct cbo_small_lml_result {
+    double terms[kSmallLmlTerms];
+    int info, seq;
+};
+size_t small_lml_scratch_doubles();
+void launch_small_lml(hipStream_t s, const cbo_small_set &st, double *scratch, int *info, cbo_small_lml_result *out, int seq);
 // sets / out may be pinned host memory (device-mapped): the kernel then reads the descriptors and writes the results
 // across the host link itself and the call needs no copy operation (the host may poll out[].seq instead of
 // synchronising the stream); info and ticket (device, n_sets ints each) must be zero on entry and are zero again afterwards

@@ -826,6 +826,69 @@ __device__ __forceinline__ void small_set_finish(double bv, int64_t bi, int set,
     }
 }
 
+// The model side of the one-workgroup kernels: points -> LDS, K(X,X) + diag and the rhs into the block, the
+// factorisation of the `tiles` real tiles (factor rows, inverses, z to the workgroup's scratch), the factor back into
+// LDS (what a tile solve reads), the inverses and z into registers.  Ends with loads in flight: the caller waits
+// (s_waitcnt vmcnt(0) + barrier) before the solve.
+__device__ __forceinline__ void small_model_factor(SmallShared &sh, const cbo_small_set &st, int tiles, double *Us,
+                                                   double *invs, int *info_word, double (&iv)[8][4], double (&zr)[8][4])
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, kq = lane >> 4;
+    // ---- the model's points and K(X,X) + diag, rhs, zero fill of what the factorisation reads beyond the tiles
+    if (tid < 128) {
+        const bool in = tid < st.n;
+        for (int k = 0; k < st.d; ++k) sh.xs[k][tid] = in ? st.xs[(int64_t)k * st.ld + tid] : 0.0;
+        sh.sq[tid] = in ? st.sq[tid] : 0.0;
+        sh.sv[tid] = (in && st.sv) ? st.sv[tid] : 0.0;
+    }
+    __syncthreads();
+    SSTAMP(1);
+    switch (st.d) {
+        case 1: small_assemble<1>(sh, st, tiles); break;
+        case 2: small_assemble<2>(sh, st, tiles); break;
+        case 3: small_assemble<3>(sh, st, tiles); break;
+        case 4: small_assemble<4>(sh, st, tiles); break;
+        case 5: small_assemble<5>(sh, st, tiles); break;
+        case 6: small_assemble<6>(sh, st, tiles); break;
+        case 7: small_assemble<7>(sh, st, tiles); break;
+        default: small_assemble<8>(sh, st, tiles); break;
+    }
+    {
+        const int rows = 16 * tiles;
+        for (int r = tid >> 4; r < rows; r += 16)
+            for (int c = rows + (tid & 15); c < kDiagLd; c += 16) {
+                double v = 0.0;
+                if (c == 128 && r < st.n) v = st.pm ? __dadd_rn(st.y[r], -st.pm[r]) : st.y[r];   // r = y - m(X)
+                sh.blk.S[r][c] = v;
+            }
+    }
+    __syncthreads();
+    SSTAMP(2);
+    diag128_factor_in_lds(sh.blk, Us, kSmallLd, 0, 128, invs, info_word, nullptr, tiles);
+    SSTAMP(3);
+    // (ends with a barrier.)  Every wave's stores of factor rows / inverses / z are complete before anyone re-reads them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- the factor back into LDS (rows of the factored tiles; the solve reads nothing else), inverses and z to registers
+    {
+        const unsigned s0 = lds_byte_address(&sh.blk.S[0][0]);
+        const int rows = 16 * tiles;
+        for (int p = wave; p < rows; p += 4)
+            glds16(Us + (int64_t)p * kSmallLd + lane * 2, __builtin_amdgcn_readfirstlane(s0 + 8u * (unsigned)(p * kDiagLd)));
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            iv[s][kk] = (s < tiles) ? invs[s * 256 + (4 * kk + kq) * 16 + lc] : 0.0;
+            zr[s][kk] = (s < tiles) ? Us[(int64_t)(16 * s + kq + 4 * kk) * kSmallLd + 128] : 0.0;
+        }
+}
+
 // Up to kSmallByValue descriptors travel as kernel arguments (no read across the host link before the first
 // instruction that needs them); longer lists are read from the pinned array.
 constexpr int kSmallByValue = 8;
@@ -858,57 +921,8 @@ __global__ __launch_bounds__(256) void small_sets_kernel(const SmallSetArgs byva
     double *my = scratch + (int64_t)slot * kSmallScratch;
     double *Us = my, *invs = my + 128 * kSmallLd;
 
-    // ---- the model's points and K(X,X) + diag, rhs, zero fill of what the factorisation reads beyond the tiles
-    if (tid < 128) {
-        const bool in = tid < st.n;
-        for (int k = 0; k < st.d; ++k) sh.xs[k][tid] = in ? st.xs[(int64_t)k * st.ld + tid] : 0.0;
-        sh.sq[tid] = in ? st.sq[tid] : 0.0;
-        sh.sv[tid] = (in && st.sv) ? st.sv[tid] : 0.0;
-    }
-    __syncthreads();
-    SSTAMP(1);
-    switch (st.d) {
-        case 1: small_assemble<1>(sh, st, tiles); break;
-        case 2: small_assemble<2>(sh, st, tiles); break;
-        case 3: small_assemble<3>(sh, st, tiles); break;
-        case 4: small_assemble<4>(sh, st, tiles); break;
-        case 5: small_assemble<5>(sh, st, tiles); break;
-        case 6: small_assemble<6>(sh, st, tiles); break;
-        case 7: small_assemble<7>(sh, st, tiles); break;
-        default: small_assemble<8>(sh, st, tiles); break;
-    }
-    {
-        const int rows = 16 * tiles;
-        for (int r = tid >> 4; r < rows; r += 16)
-            for (int c = rows + (tid & 15); c < kDiagLd; c += 16) {
-                double v = 0.0;
-                if (c == 128 && r < st.n) v = st.pm ? __dadd_rn(st.y[r], -st.pm[r]) : st.y[r];   // r = y - m(X)
-                sh.blk.S[r][c] = v;
-            }
-    }
-    __syncthreads();
-    SSTAMP(2);
-    diag128_factor_in_lds(sh.blk, Us, kSmallLd, 0, 128, invs, &info[set], nullptr, tiles);
-    SSTAMP(3);
-    // (ends with a barrier.)  Every wave's stores of factor rows / inverses / z are complete before anyone re-reads them
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // ---- the factor back into LDS (rows of the factored tiles; the solve reads nothing else), inverses and z to registers
-    {
-        const unsigned s0 = lds_byte_address(&sh.blk.S[0][0]);
-        const int rows = 16 * tiles;
-        for (int p = wave; p < rows; p += 4)
-            glds16(Us + (int64_t)p * kSmallLd + lane * 2, __builtin_amdgcn_readfirstlane(s0 + 8u * (unsigned)(p * kDiagLd)));
-    }
     double iv[8][4], zr[8][4];
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            iv[s][kk] = (s < tiles) ? invs[s * 256 + (4 * kk + kq) * 16 + lc] : 0.0;
-            zr[s][kk] = (s < tiles) ? Us[(int64_t)(16 * s + kq + 4 * kk) * kSmallLd + 128] : 0.0;
-        }
+    small_model_factor(sh, st, tiles, Us, invs, &info[set], iv, zr);
     SSTAMP(4);
     // ---- K(X, X*) of this wave's 16 candidates, straight into the result layout
     const int64_t c = (int64_t)blk * 64 + wave * 16 + lc;
@@ -973,6 +987,159 @@ __global__ __launch_bounds__(256) void small_sets_kernel(const SmallSetArgs byva
     SSTAMP(7);
     small_set_finish(bv, bi, set, slot, blocks_per_set, part_val, part_idx, info, ticket, out, seq, &last_flag);
     SSTAMP(8);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Log marginal likelihood and its analytic gradients for a model of at most 128 observations -- what every iterate
+// of the hyper-parameter MLE asks for (src/CBO.py:173 -> GPy model.optimize()) -- in ONE launch of one workgroup, the
+// model not fitted beforehand:
+//   K(X,X) + diag -> factorisation (as small_sets_kernel)          sum log diag(U), z^T z
+//   V = L^-1 (identity right-hand sides through the same tile solve)  alpha = V^T z, diag(Ky^-1) = column sums of V^2
+//   W = V^T V tile by tile on the matrix cores (V from the workgroup's scratch), each tile contracted at once with
+//   the kernel and its lengthscale derivatives: the sums of lml_grad_tile_kernel (kernels_kmat.hip), GPy's quirk of
+//   the causal term in the variance gradient included.
+// The record goes to pinned host memory, closed by the call's sequence number (the host polls it).
+template <int D>
+__global__ __launch_bounds__(256) void small_lml_kernel(const cbo_small_set st, double *scratch, int *__restrict__ info,
+                                                        cbo_small_lml_result *__restrict__ out, int seq)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    SmallShared &sh = *reinterpret_cast<SmallShared *>(smem_raw);
+    __shared__ double alpha_s[128];
+    __shared__ double red[4][kSmallLmlTerms];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, kq = lane >> 4;
+    const int tiles = (st.n + 15) / 16, rows = 16 * tiles;
+    double *Us = scratch, *invs = scratch + 128 * kSmallLd, *Vg = scratch + kSmallScratch;
+    double iv[8][4], zr[8][4];
+    small_model_factor(sh, st, tiles, Us, invs, info, iv, zr);
+    if (tid < 128) alpha_s[tid] = 0.0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- V = L^-1: column tile ct of the identity through the tile solve; alpha and diag(Ky^-1) fall out
+    double trw = 0.0;
+    for (int ct = wave; ct < tiles; ct += 4) {
+        d4 acc[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] = (t == ct && kq + 4 * r == lc) ? 1.0 : 0.0;
+        double qacc = 0.0, macc = 0.0;
+        double *Vc = Vg + 16 * ct + lc;
+        panel_solve_tiles(&sh.blk.S[kq][lc], acc, iv, tiles, [&](int s2, const d4 &x) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Vc[(int64_t)(16 * s2 + kq + 4 * r) * kSmallLd] = x[r];
+                qacc = fma(x[r], x[r], qacc);
+                macc = fma(x[r], zr[s2][r], macc);
+            }
+        });
+        qacc += __shfl_xor(qacc, 16);
+        qacc += __shfl_xor(qacc, 32);
+        macc += __shfl_xor(macc, 16);
+        macc += __shfl_xor(macc, 32);
+        const int col = 16 * ct + lc;
+        if (kq == 0 && col < st.n) {
+            alpha_s[col] = macc;
+            trw += qacc;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- gradient sums over the upper tile pairs, one pair per wave at a time
+    const double inv_l2 = st.ard ? 1.0 : 1.0 / (st.lengthscale * st.lengthscale);
+    double sum[1 + D];
+#pragma unroll
+    for (int k = 0; k <= D; ++k) sum[k] = 0.0;
+    int pair = 0;
+    for (int ti = 0; ti < tiles; ++ti)
+        for (int tj = ti; tj < tiles; ++tj, ++pair) {
+            if ((pair & 3) != wave) continue;                       // uniform per wave
+            d4 w = {0.0, 0.0, 0.0, 0.0}, w2 = {0.0, 0.0, 0.0, 0.0};
+            const double *Va = Vg + 16 * ti + lc, *Vb = Vg + 16 * tj + lc;
+            // V is lower triangular: rows above tile tj contribute nothing to column tile tj
+            for (int k0 = 16 * tj; k0 < rows; k0 += 8) {
+                w = MFMA_F64(Va[(int64_t)(k0 + kq) * kSmallLd], Vb[(int64_t)(k0 + kq) * kSmallLd], w);
+                w2 = MFMA_F64(Va[(int64_t)(k0 + 4 + kq) * kSmallLd], Vb[(int64_t)(k0 + 4 + kq) * kSmallLd], w2);
+            }
+            w += w2;
+            const int gj = 16 * tj + lc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = 16 * ti + kq + 4 * r;
+                if (gi >= st.n || gj >= st.n || gj < gi) continue;
+                double r2 = 0.0, d2k[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const double df = sh.xs[k][gi] - sh.xs[k][gj];
+                    d2k[k] = df * df * inv_l2;
+                    r2 += d2k[k];
+                }
+                const double kv = st.variance * exp(-0.5 * r2);
+                const double m = (gi == gj ? 1.0 : 2.0) * (alpha_s[gi] * alpha_s[gj] - w[r]);
+                const double mk = m * kv;
+                sum[0] += mk + m * (sh.sv[gi] * sh.sv[gj]);
+#pragma unroll
+                for (int k = 0; k < D; ++k) sum[1 + k] = fma(mk, d2k[k], sum[1 + k]);
+            }
+        }
+    // ---- z^T z, sum log diag(U), alpha^T alpha, tr(Ky^-1); everything reduced over the workgroup
+    double terms[kSmallLmlTerms];
+#pragma unroll
+    for (int k = 0; k < kSmallLmlTerms; ++k) terms[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k <= D; ++k) terms[k] = sum[k];
+    if (tid < st.n) {
+        const double zi = Us[(int64_t)tid * kSmallLd + 128];
+        terms[1 + CBO_MAX_DIM + 0] = zi * zi;
+        terms[1 + CBO_MAX_DIM + 1] = log(sh.blk.S[tid][tid]);
+        terms[1 + CBO_MAX_DIM + 2] = alpha_s[tid] * alpha_s[tid];
+    }
+    terms[1 + CBO_MAX_DIM + 3] = trw;
+#pragma unroll
+    for (int k = 0; k < kSmallLmlTerms; ++k) {
+        double v = terms[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < kSmallLmlTerms; ++k) out->terms[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+        out->info = atomicAdd(info, 0);
+        __threadfence_system();
+        *reinterpret_cast<volatile int *>(&out->seq) = seq;
+        *info = 0;
+    }
+}
+
+size_t small_lml_scratch_doubles() { return (size_t)kSmallScratch + (size_t)128 * kSmallLd; }
+
+void launch_small_lml(hipStream_t s, const cbo_small_set &st, double *scratch, int *info, cbo_small_lml_result *out, int seq)
+{
+#define CBO_LAUNCH_LML(D)                                                                                              \
+    do {                                                                                                               \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(small_lml_kernel<D>),                                       \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmallShared));                     \
+        hipLaunchKernelGGL(small_lml_kernel<D>, dim3(1), dim3(256), sizeof(SmallShared), s, st, scratch, info, out,    \
+                           seq);                                                                                       \
+    } while (0)
+    switch (st.d) {
+        case 1: CBO_LAUNCH_LML(1); break;
+        case 2: CBO_LAUNCH_LML(2); break;
+        case 3: CBO_LAUNCH_LML(3); break;
+        case 4: CBO_LAUNCH_LML(4); break;
+        case 5: CBO_LAUNCH_LML(5); break;
+        case 6: CBO_LAUNCH_LML(6); break;
+        case 7: CBO_LAUNCH_LML(7); break;
+        default: CBO_LAUNCH_LML(8); break;
+    }
+#undef CBO_LAUNCH_LML
 }
 
 size_t small_sets_scratch_doubles(int n_sets, int blocks_per_set) { return (size_t)n_sets * blocks_per_set * kSmallScratch; }

@@ -141,7 +141,11 @@ int cbo_gp_set_hyper(cbo_gp *gp, double variance, const double *lengthscale, dou
 int cbo_gp_log_marginal(cbo_gp *gp, double *lml_out);
 /* The gradients GPy hands its optimiser (ExactGaussianInference dL_dK -> kern.update_gradients_full, dL_dthetaL):
  * d log p(y) / d variance, / d lengthscale (1 value, or d values if ard), / d noise_var, of the fitted model, all on
- * the device (Ky^-1 = L^-T L^-1 through the sweep and GEMM kernels, then one contraction pass).  lml_out may be NULL. */
+ * the device (Ky^-1 = L^-T L^-1 through the sweep and GEMM kernels, then one contraction pass).  lml_out may be NULL.
+ * An fp64 model of at most 128 observations -- every model the reference builds, and what its per-trial optimize()
+ * iterates on -- need not be fitted: one launch goes from the data and the current hyper-parameters to all outputs and
+ * leaves the model as it was (if Ky is not positive definite as assembled, the model is fitted with the jitchol
+ * ladder and the general path answers).  Larger models: CBO_ERR_NOT_FITTED until fitted. */
 int cbo_gp_lml_gradients(cbo_gp *gp, double *lml_out, double *dvariance_out, double *dlengthscale_out,
                          double *dnoise_out);
 

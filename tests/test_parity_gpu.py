@@ -930,6 +930,70 @@ def test_likelihood_gradients_match_the_restatement(hip, n, d, ard, causal):
     assert np.array_equal(a["acq"], b["acq"])
 
 
+@pytest.mark.parametrize("n,d,ard,causal", [(10, 1, False, False), (50, 2, False, False), (100, 3, True, False),
+                                            (128, 3, False, True), (17, 4, True, True), (33, 8, False, False)])
+def test_small_model_likelihood_gradients_in_one_launch(hip, n, d, ard, causal):
+    """Models of at most 128 observations: likelihood and gradients straight from the data and the hyper-parameters
+    (one workgroup, no fit before, none left behind) against the oracle; after new hyper-parameters again; the model
+    still answers a sweep afterwards (it fits itself then)."""
+    from cbo_with_oop_amd import CausalExpectedImprovement
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    rng = np.random.default_rng(7 * n + d)
+    X = rng.uniform(-2, 2, (n, d))
+    y = np.sin(X[:, :1]) + 0.2 * X[:, -1:] + 0.05 * rng.standard_normal((n, 1))
+    prior = {}
+    if causal:
+        mean_fn = lambda a: 0.1 * a[:, :1]
+        var_fn = lambda a: 0.2 + 0.1 * np.cos(a[:, -1:]) ** 2
+        prior = dict(mean_function=mean_fn, variance_adjustment=var_fn)
+    m = HipGaussianProcess(X, y, ard=ard, variance=1.2, lengthscale=np.linspace(0.7, 1.6, d) if ard else 0.9,
+                           noise_var=0.04, fit=False, **prior)
+    assert m.small and m.stale
+    for variance, ls, noise in ((1.2, np.linspace(0.7, 1.6, d) if ard else 0.9, 0.04),
+                                (0.6, np.linspace(1.3, 0.8, d) if ard else 1.4, 0.3)):
+        m.set_hyperparameters(variance, ls, noise, fit=False)
+        dv, dls, dn = m.log_likelihood_gradients()
+        assert m.stale                                             # nothing was fitted on the way
+        okw = dict(variance=variance, lengthscale=ls, noise_var=noise)
+        if causal:
+            okw.update(mX=mean_fn(X), vX=var_fn(X))
+        post = O.fit(X, y, **okw)
+        o_dv, o_dls, o_dn = O.log_marginal_likelihood_gradients(post)
+        scale = max(abs(o_dv), np.max(np.abs(o_dls)), abs(o_dn))
+        assert m._last_lml == pytest.approx(O.log_marginal_likelihood(post), rel=1e-10)
+        assert dv == pytest.approx(o_dv, rel=1e-8, abs=1e-10 * scale)
+        assert dn == pytest.approx(o_dn, rel=1e-8, abs=1e-10 * scale)
+        np.testing.assert_allclose(dls, o_dls, rtol=1e-8, atol=1e-10 * scale)
+    Xs = rng.uniform(-2, 2, (70, d))
+    res = CausalExpectedImprovement(0.0, "min", m).sweep(Xs, want_acq=True)
+    acq, _, idx, _, _ = O.acquisition_sweep(post, Xs, 0.0, vXs=var_fn(Xs) if causal else None,
+                                            mXs=mean_fn(Xs) if causal else None)
+    assert res["best_idx"] == idx
+    m.close()
+
+
+def test_small_model_likelihood_falls_back_when_not_positive_definite(hip):
+    """Ky not positive definite as assembled (duplicated points, the reference's 1e-10 noise): the one-launch path
+    declines, the model is fitted with the jitchol ladder and the general path answers -- the oracle's numbers with
+    the same jitter."""
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    c = load_fixture("jitter_ladder")
+    import warnings
+    m = HipGaussianProcess(c["X"], c["y"], variance=float(c["variance"]), lengthscale=c["lengthscale_arg"],
+                           noise_var=float(c["noise_var"]), fit=False)
+    assert m.small and m.stale
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        dv, dls, dn = m.log_likelihood_gradients()
+    post = O.fit(c["X"], c["y"], variance=float(c["variance"]), lengthscale=c["lengthscale_arg"],
+                 noise_var=float(c["noise_var"]))
+    assert post.tries >= 1
+    o_dv, o_dls, o_dn = O.log_marginal_likelihood_gradients(post)
+    assert m._last_lml == pytest.approx(O.log_marginal_likelihood(post), rel=1e-6)
+    assert dv == pytest.approx(o_dv, rel=1e-4) and dn == pytest.approx(o_dn, rel=1e-4)
+    m.close()
+
+
 def test_complete_graph_trial_loop_end_to_end(hip):
     """The whole mirrored stack on the reference's complete graph, trial after trial: per-set GPs
     (GaussianProcessFactory), grid acquisition per set (find_next_y_point), set selection, the Monte-Carlo target
