@@ -99,6 +99,7 @@ struct cbo_ctx {
     double *small_part_val = nullptr; int64_t *small_part_idx = nullptr; size_t small_part_elems = 0;
     int *small_info = nullptr;                                  // device, sets_cap status words + sets_cap tickets (zero between calls)
     int small_seq = 0;                                          // sequence number of the last multi-set call
+    int polled_launches = 0;                                    // launches completed by polling since the last stream sync
     cbo_small_lml_result *lml_out = nullptr;                    // pinned, written by small_lml_kernel
     double *q = nullptr, *mu = nullptr, *mean = nullptr, *var = nullptr, *acq = nullptr; size_t vec_elems = 0;
     double *part_val = nullptr; int64_t *part_idx = nullptr;
@@ -1449,6 +1450,17 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
 // fitted state alone.  A set whose factorisation meets a non-positive pivot there (jitchol's business), a larger
 // model, or an fp32 model takes the general path: cbo_gp_fit_sweep when the model is not fitted, cbo_acq_sweep
 // otherwise.
+constexpr int kPollSpins = 1 << 15;       // ~0.3 ms of polling a pinned word before falling back to the stream
+// A launch whose result was polled is still "in flight" for the runtime; left unreaped by the hundred they cost one
+// call in a thousand ~70 ms (measured).  The stream is idle after a successful poll: synchronising it is cheap.
+constexpr int kPolledLaunchesPerSync = 256;
+static bool polled_launch_needs_sync(cbo_ctx *c)
+{
+    if (++c->polled_launches < kPolledLaunchesPerSync) return false;
+    c->polled_launches = 0;
+    return true;
+}
+
 // the model half of a one-workgroup kernel's descriptor
 static void fill_small_model(cbo_small_set &st, const cbo_gp *g)
 {
@@ -1541,15 +1553,16 @@ extern "C" int cbo_acq_sweep_sets(int n_sets, cbo_gp *const *gps, cbo_cands *con
                           c->small_info, c->small_info + c->sets_cap, c->small_out, seq);
         HIP_TRY(hipGetLastError());
         // the result records arrive in pinned memory, each closed by the call's sequence number: poll them (a few
-        // microseconds sooner than the stream's completion signal); the stream is synchronised if that takes long
+        // microseconds sooner than the stream's completion signal) for a few hundred microseconds, then let the
+        // runtime wait (large jobs; and about one call in a thousand, whose submission only a synchronisation completes)
         {
             bool all = false;
-            for (int spin = 0; spin < (1 << 22) && !all; ++spin) {
+            for (int spin = 0; spin < kPollSpins && !all; ++spin) {
                 all = true;
                 for (int j = 0; j < ns; ++j)
                     if (*reinterpret_cast<volatile int *>(&c->small_out[j].seq) != seq) { all = false; break; }
             }
-            if (!all || c->profiling) HIP_TRY(hipStreamSynchronize(c->stream));
+            if (!all || c->profiling || polled_launch_needs_sync(c)) HIP_TRY(hipStreamSynchronize(c->stream));
             for (int j = 0; j < ns; ++j)
                 if (c->small_out[j].seq != seq) return fail(CBO_ERR_HIP, "multi-set sweep: no result record");
             std::atomic_thread_fence(std::memory_order_acquire);
@@ -1710,9 +1723,9 @@ static int small_lml_gradients(cbo_gp *g, double *lml_out, double *dvariance_out
     launch_small_lml(c->stream, st, c->small_scratch, c->small_info, c->lml_out, seq);
     if (hipGetLastError() != hipSuccess) return fail(CBO_ERR_HIP, "small_lml_kernel launch");
     bool ready = false;
-    for (int spin = 0; spin < (1 << 22) && !ready; ++spin)
+    for (int spin = 0; spin < kPollSpins && !ready; ++spin)
         ready = *reinterpret_cast<volatile int *>(&c->lml_out->seq) == seq;
-    if (!ready || c->profiling) {
+    if (!ready || c->profiling || polled_launch_needs_sync(c)) {
         if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(CBO_ERR_HIP, "hipStreamSynchronize");
         if (c->lml_out->seq != seq) return fail(CBO_ERR_HIP, "likelihood kernel: no result record");
     }

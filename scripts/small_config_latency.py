@@ -60,6 +60,9 @@ cds = (ctypes.c_void_p * 2)(*[g._handle for g in grids_dev])
 yb, cs, vals, idxs = np.full(2, best), np.ones(2), np.empty(2), np.empty(2, dtype=np.int64)
 args = (2, gps, cds, _lib.dptr(yb), 0, 0.0, _lib.dptr(cs), _lib.dptr(vals), idxs.ctypes.data_as(_lib.c_int64_p))
 for _ in range(5): _lib.check(lib.cbo_acq_sweep_sets(*args))
-t0 = time.perf_counter()
-for _ in range(200): lib.cbo_acq_sweep_sets(*args)
-print(f"  cbo_acq_sweep_sets alone (2 sets x 200 candidates, 50 observations each): {(time.perf_counter() - t0) / 200 * 1e6:.1f} us per call")
+ts = []
+for _ in range(2000):
+    t0 = time.perf_counter(); lib.cbo_acq_sweep_sets(*args); ts.append(time.perf_counter() - t0)
+ts = np.array(ts) * 1e6
+print(f"  cbo_acq_sweep_sets alone (2 sets x 200 candidates, 50 observations each): median {np.median(ts):.1f} us, mean "
+      f"{ts.mean():.1f} us, max {ts.max():.0f} us over {len(ts)} calls ({int((ts > 1000).sum())} above 1 ms)")
