@@ -355,7 +355,7 @@ __device__ __forceinline__ d4 factor_tile_regs(d4 din, int lane, int pivot_row0,
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         Yt[lc][kq + 4 * r] = e[r];
-        invDt_tile[lc * 16 + kq + 4 * r] = e[r];
+        if (invDt_tile) invDt_tile[lc * 16 + kq + 4 * r] = e[r];
     }
     return d;
 }
@@ -434,19 +434,38 @@ extern "C" int cbo_diag_small_stamps(unsigned long long *out)
 #define SSTAMP(i_) do { } while (0)
 #endif
 
+// A store of the factor that a workgroup of the SAME launch may read (the strips of the fused diagonal + panel launch):
+// written through to the coherence point of the device instead of resting in this XCD's L2.
+template <bool PUBLISH>
+__device__ __forceinline__ void gstore(double *p, double v)
+{
+    if (PUBLISH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 // One interval of one of waves 1..3 (W = wave - 1): its third of the row panel, the rendezvous, its trailing tiles.
-template <int W>
+// The wave with W == jb % 3 also carries tile jb's diagonal factor and inverse from LDS (where wave 0 left them) to
+// global memory: the chain wave itself never waits on a global store.  PUBLISH: after its last store of the interval
+// the wave counts itself in at `flag` (row tile jb of the factor is complete when the count reaches 3 (jb + 1)).
+template <int W, bool PUBLISH>
 __device__ __forceinline__ void diag_worker(Diag2Shared &sh, double *A, int64_t lda, int r0, int rcol,
-                                            double *__restrict__ zvec, int jb, const double (&af)[4], int lane,
-                                            int tiles)
+                                            double *__restrict__ invDt, double *__restrict__ zvec, int jb,
+                                            const double (&af)[4], int lane, int tiles, int *flag)
 {
     const int lc = lane & 15, kq = lane >> 4;
     const int o = 16 * jb;
     constexpr int ct0 = (W == 0) ? 3 : W;                 // own column tiles: ct0, ct0 + 3, ct0 + 6 (<= 8; 8 = rhs)
     constexpr int nown = (ct0 + 6 <= 8) ? 3 : 2;
-    // tiles that are not due (ct <= jb) are solved along on whatever S holds there and land below the diagonal,
-    // where nobody looks: cheaper than branching around a chain of four MFMAs
+    // tiles that are not due (ct <= jb) are solved along on whatever S holds there (cheaper than branching around a
+    // chain of four MFMAs) and stored nowhere
     DSTAMP(W + 1, jb, 0);
+    if (W == jb % 3) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gstore<PUBLISH>(&A[(int64_t)(r0 + o + kq + 4 * r) * lda + r0 + o + lc], sh.S[o + kq + 4 * r][o + lc]);
+            gstore<PUBLISH>(&invDt[(int64_t)(r0 / 16 + jb) * 256 + lc * 16 + kq + 4 * r], sh.Yt[jb & 1][lc][kq + 4 * r]);
+        }
+    }
     d4 xo[nown];
     {
         double bq[4][nown];
@@ -467,7 +486,7 @@ __device__ __forceinline__ void diag_worker(Diag2Shared &sh, double *A, int64_t 
         if (ct == jb + 1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) sh.S[16 + kq + 4 * r][lc] = xo[n][r];
-        } else {
+        } else if (ct > jb) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) sh.S[o + kq + 4 * r][16 * ct + lc] = xo[n][r];
         }
@@ -482,7 +501,8 @@ __device__ __forceinline__ void diag_worker(Diag2Shared &sh, double *A, int64_t 
         if (ct > jb) {
             if (ct < 8) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) A[(int64_t)(r0 + o + kq + 4 * r) * lda + r0 + 16 * ct + lc] = xo[n][r];
+                for (int r = 0; r < 4; ++r)
+                    gstore<PUBLISH>(&A[(int64_t)(r0 + o + kq + 4 * r) * lda + r0 + 16 * ct + lc], xo[n][r]);
             } else if (lc == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -518,14 +538,19 @@ __device__ __forceinline__ void diag_worker(Diag2Shared &sh, double *A, int64_t 
     // interleaved; a tile that is not due (ti <= jb) is computed on stale operands and simply not written back.
     diag_trailing<W>(sh, x, nx, jb, lane, tiles);
     DSTAMP(W + 1, jb, 3);
+    if (PUBLISH) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have arrived
+        if (lane == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // The factorisation of a block that is already in LDS (S: upper triangle + rhs tile; the caller has synchronised).
 // `tiles` = 16-row tiles to factor (8 = the whole block; fewer when the rest is identity padding, which the caller
 // then writes out itself).  Factor rows, diagonal inverses and z go to global memory (A, invDt, zvec).
+template <bool PUBLISH = false>
 __device__ __forceinline__ void diag128_factor_in_lds(Diag2Shared &sh, double *A, int64_t lda, int r0, int rcol,
                                                       double *__restrict__ invDt, int *info,
-                                                      double *__restrict__ zvec, int tiles)
+                                                      double *__restrict__ zvec, int tiles, int *flag = nullptr)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -536,9 +561,11 @@ __device__ __forceinline__ void diag128_factor_in_lds(Diag2Shared &sh, double *A
         d4 t0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) t0[r] = sh.S[kq + 4 * r][lc];
-        const d4 u = factor_tile_regs(t0, lane, r0, info, sh.Yt[0], invDt + (int64_t)(r0 / 16) * 256);
+        // the factor of the tile stays in LDS, in the tile's own place (nobody else touches it): a worker wave takes
+        // it and the inverse to global memory in the tile's interval
+        const d4 u = factor_tile_regs(t0, lane, r0, info, sh.Yt[0], nullptr);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) A[(int64_t)(r0 + kq + 4 * r) * lda + r0 + lc] = u[r];
+        for (int r = 0; r < 4; ++r) sh.S[kq + 4 * r][lc] = u[r];
     }
     __syncthreads();
 
@@ -568,18 +595,17 @@ __device__ __forceinline__ void diag128_factor_in_lds(Diag2Shared &sh, double *A
                 accb = MFMA_F64(x[3], -x[3], accb);
                 acc += accb;
                 DSTAMP(0, jb, 1);
-                const d4 u = factor_tile_regs(acc, lane, r0 + o + 16, info, sh.Yt[(jb + 1) & 1],
-                                              invDt + (int64_t)(r0 / 16 + jb + 1) * 256);
+                const d4 u = factor_tile_regs(acc, lane, r0 + o + 16, info, sh.Yt[(jb + 1) & 1], nullptr);
                 DSTAMP(0, jb, 2);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) A[(int64_t)(r0 + o + 16 + kq + 4 * r) * lda + r0 + o + 16 + lc] = u[r];
+                for (int r = 0; r < 4; ++r) sh.S[o + 16 + kq + 4 * r][o + 16 + lc] = u[r];
             }
             DSTAMP(0, jb, 3);
         } else {
             const int w = wave - 1;
-            if (w == 0) diag_worker<0>(sh, A, lda, r0, rcol, zvec, jb, af, lane, tiles);
-            else if (w == 1) diag_worker<1>(sh, A, lda, r0, rcol, zvec, jb, af, lane, tiles);
-            else diag_worker<2>(sh, A, lda, r0, rcol, zvec, jb, af, lane, tiles);
+            if (w == 0) diag_worker<0, PUBLISH>(sh, A, lda, r0, rcol, invDt, zvec, jb, af, lane, tiles, flag);
+            else if (w == 1) diag_worker<1, PUBLISH>(sh, A, lda, r0, rcol, invDt, zvec, jb, af, lane, tiles, flag);
+            else diag_worker<2, PUBLISH>(sh, A, lda, r0, rcol, invDt, zvec, jb, af, lane, tiles, flag);
         }
         __syncthreads();
     }
