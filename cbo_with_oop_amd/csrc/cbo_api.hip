@@ -587,7 +587,7 @@ extern "C" int cbo_gp_create(cbo_ctx *c, int dtype, int64_t n, int d, const doub
     g->h.zero_diag = zero_diag ? 1 : 0;
     g->h.lengthscale = ard ? 1.0 : lengthscale[0];
     g->ls.assign(lengthscale, lengthscale + (ard ? d : 1));
-    if (hipMalloc(&g->info, sizeof(int)) != hipSuccess) { delete g; return fail(CBO_ERR_HIP, "hipMalloc info"); }
+    if (hipMalloc(&g->info, sizeof(int) * (1 + kCholFlagSlots)) != hipSuccess) { delete g; return fail(CBO_ERR_HIP, "hipMalloc info"); }
     if (ard) {
         if (hipMalloc(&g->ls_dev, sizeof(double) * d) != hipSuccess ||
             hipMemcpy(g->ls_dev, lengthscale, sizeof(double) * d, hipMemcpyHostToDevice) != hipSuccess) {
@@ -680,6 +680,7 @@ extern "C" int cbo_gp_fit(cbo_gp *g, int *tries_out, double *jitter_out)
         HIP_TRY(hipMemcpyAsync(c->h_info, g->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (*c->h_info == 0) break;
+        if (*c->h_info == kCholFusedTimeout) return fail(CBO_ERR_HIP, "a fused diagonal + panel launch gave up waiting");
         const int rc = next_jitter(g, &tries, &jitter);
         if (rc != CBO_OK) return rc;
     }
@@ -1425,6 +1426,7 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
         HIP_TRY(hipMemcpyAsync(c->h_info, g->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (*c->h_info == 0) break;
+        if (*c->h_info == kCholFusedTimeout) return fail(CBO_ERR_HIP, "a fused diagonal + panel launch gave up waiting");
         rc = next_jitter(g, &tries, &jitter);
         if (rc != CBO_OK) return rc;
     }

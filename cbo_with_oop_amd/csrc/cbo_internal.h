@@ -130,6 +130,9 @@ struct SweepPipe {
     void (*mark)(void *user, hipStream_t st, int begin, double flops);   // optional: around every sweep launch (timers)
     void *user;
 };
+// info_dev: 1 + kCholFlagSlots ints (status word, then one publication counter per 128-row panel)
+constexpr int kCholFlagSlots = 1024;
+constexpr int kCholFusedTimeout = -2147483647 - 1;     // status word when a strip of a fused launch gave up waiting
 void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &events, double *A, int64_t lda,
                      int64_t n_pad, double *invDt, int *info_dev, const SweepPipe *pipe = nullptr);
 // pair p of the pipelined sweep: rows [r0, r0 + klen) of the factor are final on stream `chain`

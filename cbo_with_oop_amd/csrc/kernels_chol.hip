@@ -16,6 +16,8 @@
 //   3. syrk_kernel            A[r0+128:, r0+128:] -= P^T P  on the upper 128x128 tiles (fp64 MFMA),
 //                             rhs[r0+128:] -= P^T z_k
 // The SYRK carries the n^3/3 flops; steps 1-2 are the serial chain.
+#include <hip/hip_ext.h>
+#include <climits>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t l
 // the row panel and the other waves wait for the chain.  Here wave 0 runs one step ahead and touches nothing the
 // other waves produce inside an interval:
 //   interval jb:  wave 0     X01 = inv(L_jb) S(jb, jb+1);  S(jb+1, jb+1) -= X01^T X01 (registers);  factor tile jb+1
+//                            (factor and inverse stay in LDS: the wave never waits on a global store)
 //                 waves 1-3  each solves a third of the row panel X(jb, jb+1..8) (tiles ct with ct % 3 == w), leaves
 //                            it in LDS and in global memory (finished factor rows), meets the other two at an LDS
 //                            counter, reads the whole panel back into registers and updates its share of the trailing
@@ -514,6 +517,11 @@ __device__ __forceinline__ void diag_worker(Diag2Shared &sh, double *A, int64_t 
         }
     }
     DSTAMP(W + 1, jb, 1);
+    if (PUBLISH && W == jb % 3) {
+        // tile jb's inverse (and diagonal factor) are out: flag[1] counts them.  The wait overlaps the rendezvous.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     while (__hip_atomic_load(&sh.xcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 3 * (jb + 1))
         __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -734,12 +742,139 @@ __global__ __launch_bounds__(256) void panel_trsm_kernel(double *A, int64_t lda,
     });
 }
 
-void launch_panel_trsm(hipStream_t s, double *A, int64_t lda, int r0, int col0, int n_cols, const double *invDt,
-                       const int *skip_if)
+// ------------------------------------------------------------------------------------------------
+// Diagonal block AND its row panel in one launch (a small cooperative group: nothing waits on a grid-wide barrier).
+// Workgroup 0 is the diagonal-block kernel above, publishing: its factor stores are written through to the device's
+// coherence point and every worker wave counts itself in at `flag` after its last store of an interval, so row tile s
+// of the block (the inverse of its diagonal tile and U[s][s+1..7]) is complete when the count reaches 3 (s + 1).
+// Workgroups 1.. are the panel's 64-column strips; each wave owns 16 columns, keeps its 128 x 16 right-hand sides in
+// registers and follows the block tile by tile: wait for row tile s, read it (coherent loads, straight into MFMA
+// operand registers: no LDS, no barrier, the four waves are independent), x_s = inv(L_ss) r_s, fold it into the
+// tiles below.  The panel solve thus hides behind the 128 pivots of the block; what is left after the block's last
+// interval is one round trip and a sixteenth of the work.  Same chains as panel_solve_tiles: same bits.
+// Forward progress: workgroup 0 never waits for a strip, and a dispatch hands out workgroups in order, so it runs
+// before any strip spins; the spin is bounded all the same (kFusedSpinLimit polls, then the status word reports
+// kFusedTimeout and the launch drains).
+constexpr int kFusedTimeout = kCholFusedTimeout;
+constexpr int kFusedSpinLimit = 1 << 22;
+
+__device__ __forceinline__ double coherent_load(const double *p)
 {
-    if (n_cols <= 0) return;
-    hipLaunchKernelGGL(panel_trsm_kernel, dim3((unsigned)(n_cols / kStrip)), dim3(256), sizeof(PanelShared), s, A, lda, r0,
-                       col0, invDt, skip_if);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void potrf_panel_fused_kernel(double *A, int64_t lda, int r0, int rcol,
+                                                                double *__restrict__ invDt, int *info,
+                                                                double *__restrict__ zvec, int col0, int *flag)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (__builtin_nontemporal_load(info) != 0) return;      // an earlier block met a non-positive pivot: abandoned
+    if (blockIdx.x == 0) {
+        Diag2Shared &sh = *reinterpret_cast<Diag2Shared *>(smem_raw);
+        {
+            const unsigned s0 = lds_byte_address(&sh.S[0][0]);
+            const double *g = A + (int64_t)(r0 + wave * 32) * lda + r0 + lane * 2;
+#pragma unroll 8
+            for (int p = 0; p < 32; ++p) {
+                if (lane >= 8 * ((wave * 32 + p) >> 4))
+                    glds16(g + (int64_t)p * lda, __builtin_amdgcn_readfirstlane(s0 + 8u * (unsigned)((wave * 32 + p) * kDiagLd)));
+            }
+        }
+        if (tid < 128) {
+            sh.S[tid][128] = A[(int64_t)(r0 + tid) * lda + rcol];
+#pragma unroll
+            for (int c = 129; c < kDiagLd; ++c) sh.S[tid][c] = 0.0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        diag128_factor_in_lds<true>(sh, A, lda, r0, rcol, invDt, info, zvec, 8, flag);
+        return;
+    }
+    // ---- a strip: 16 columns per wave
+    const int lc = lane & 15, kq = lane >> 4;
+    double *Ac = A + (int64_t)r0 * lda + col0 + (int64_t)(blockIdx.x - 1) * kStrip + wave * 16 + lc;
+    d4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = Ac[(int64_t)(16 * t + kq + 4 * r) * lda];
+    const double *inv = invDt + (int64_t)(r0 / 16) * 256 + kq * 16 + lc;
+    const double *Ub = A + (int64_t)(r0 + kq) * lda + r0 + lc;           // U[kq][lc] of the block
+    // flag[0] / 3 = row tiles of the block that are complete, flag[1] = diagonal-tile inverses that are out (inverse s
+    // precedes row tile s by most of an interval: x_s does not wait for the row, and the last step needs no row at all)
+    int rows_seen = 0, invs_seen = 0;
+    // one poll refreshes both counts (the two words share a cache line: one round trip)
+    auto wait_for = [&](bool want_row, int s) -> bool {
+        int spins = 0;
+        while ((want_row ? rows_seen : invs_seen) <= s) {
+            const int f0 = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int f1 = __hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            rows_seen = f0 / 3;
+            invs_seen = f1;
+            if ((want_row ? rows_seen : invs_seen) > s) break;
+            if (++spins > kFusedSpinLimit || __builtin_nontemporal_load(info) != 0) {
+                if (spins > kFusedSpinLimit && lane == 0) atomicCAS(info, 0, kFusedTimeout);
+                return false;                                            // uniform: every lane read the same words
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        return true;
+    };
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (!wait_for(false, s)) return;
+        // a strip that runs behind the block already knows the row is there: its fragments travel with the inverse
+        const bool have_row = s < 7 && rows_seen > s;
+        double iv[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) iv[kk] = coherent_load(inv + s * 256 + 64 * kk);
+        double ub[4][8];
+        if (have_row) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int t = s + 1; t < 8; ++t) ub[kk][t] = coherent_load(Ub + (int64_t)(16 * s + 4 * kk) * lda + 16 * t);
+        }
+        d4 x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
+        x = MFMA_F64(iv[0], acc[s][0], x);
+        x2 = MFMA_F64(iv[1], acc[s][1], x2);
+        x = MFMA_F64(iv[2], acc[s][2], x);
+        x2 = MFMA_F64(iv[3], acc[s][3], x2);
+        x += x2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ac[(int64_t)(16 * s + kq + 4 * r) * lda] = x[r];
+        if (s == 7) break;
+        if (!have_row) {
+            if (!wait_for(true, s)) return;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int t = s + 1; t < 8; ++t) ub[kk][t] = coherent_load(Ub + (int64_t)(16 * s + 4 * kk) * lda + 16 * t);
+        }
+        const d4 nx = -x;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int t = s + 1; t < 8; ++t) acc[t] = MFMA_F64(ub[kk][t], nx[kk], acc[t]);
+    }
+}
+
+void launch_panel_fused(hipStream_t s, double *A, int64_t lda, int r0, int rcol, double *invDt, int *info, double *zvec,
+                        int n_cols, int *flag, hipEvent_t done = nullptr)
+{
+    hipExtLaunchKernelGGL(potrf_panel_fused_kernel, dim3(1u + (unsigned)(n_cols / kStrip)), dim3(256), sizeof(Diag2Shared),
+                          s, nullptr, done, 0, A, lda, r0, rcol, invDt, info, zvec, r0 + 128, flag);
+}
+
+void launch_panel_trsm(hipStream_t s, double *A, int64_t lda, int r0, int col0, int n_cols, const double *invDt,
+                       const int *skip_if, hipEvent_t done = nullptr)
+{
+    if (n_cols <= 0) { if (done) hipEventRecord(done, s); return; }
+    hipExtLaunchKernelGGL(panel_trsm_kernel, dim3((unsigned)(n_cols / kStrip)), dim3(256), sizeof(PanelShared), s, nullptr,
+                          done, 0, A, lda, r0, col0, invDt, skip_if);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1390,15 +1525,16 @@ __global__ __launch_bounds__(256) void syrk_rows_kernel(double *A, int64_t lda, 
 
 // the first `rows` rows below the n1 panel rows [r0, r0 + n1) against those panel rows: columns from c0 = r0 + n1 on,
 // n2 of them (rows: 128 = the next panel, 256 = the next pair of panels)
+// `done`: an event that completes with the launch (the launch carries it: no marker packet on the stream)
 static void launch_syrk_rows(hipStream_t s, double *A, int64_t lda, int r0, int n1, int n2, int rcol, const int *skip_if,
-                             int rows = 128)
+                             int rows = 128, hipEvent_t done = nullptr)
 {
     const int c0 = r0 + n1;
     const int nt = n2 / 64;
-    if (nt <= 0) return;
+    if (nt <= 0) { if (done) hipEventRecord(done, s); return; }
     if (rows > n2) rows = n2;
-    hipLaunchKernelGGL(syrk_rows_kernel, dim3(nt + 1, rows / 32), dim3(256), 0, s, A, lda, r0, n1, c0, nt, rcol,
-                       skip_if);
+    hipExtLaunchKernelGGL(syrk_rows_kernel, dim3(nt + 1, rows / 32), dim3(256), 0, s, nullptr, done, 0, A, lda, r0, n1, c0,
+                          nt, rcol, skip_if);
 }
 
 // tile rows [ti_begin, ti_end) of the trailing update (64-row tiles counted from the first trailing row)
@@ -1493,6 +1629,11 @@ void sweep_pipe_tail(const SweepPipe &pipe, hipStream_t chain, const double *A, 
     if (pipe.mark) pipe.mark(pipe.user, chain, 0, 0.0);
 }
 
+__global__ void zero_ints_kernel(int *p, int n)
+{
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
+}
+
 // Look-ahead of one panel pair: the bulk of pair p-1's trailing update (everything below pair p+1's rows) runs on the
 // side stream while the main stream factors and solves pair p; the two meet before pair p's own update of pair
 // p+1's rows (schedule inside).
@@ -1507,7 +1648,11 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
                         (int)sizeof(Diag2Shared));
     hipFuncSetAttribute(reinterpret_cast<const void *>(panel_trsm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)sizeof(PanelShared));
-    static const int panel_form = [] { const char *e = std::getenv("CBO_HIP_PANEL_FORM"); return e ? std::atoi(e) : 2; }();
+    hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_panel_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)sizeof(Diag2Shared));
+    // 4: diagonal block + row panel in one launch (not beside a pipelined sweep); 2: separate launches, lean panel kernel;
+    // 3: the lean panel kernel also beside a pipelined sweep; 1: the strip kernel as panel solver
+    static const int panel_form = [] { const char *e = std::getenv("CBO_HIP_PANEL_FORM"); return e ? std::atoi(e) : 4; }();
     static const int syrk_gemm_rows = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_ROWS"); return e ? std::atoi(e) : 6144; }();
     static const int syrk_gemm_chunk = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_CHUNK"); return e ? std::atoi(e) : 1; }();
     static const bool syrk_gemm_half = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_KB"); return !(e && std::atoi(e) == 32); }();
@@ -1521,14 +1666,18 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
             hipLaunchKernelGGL(potrf_diag128_v2_kernel, dim3(1), dim3(256), sizeof(Diag2Shared), s, A, lda, rr, (int)n_pad,
                                invDt, info_dev, pipe ? pipe->zvec : nullptr);
     };
-    hipMemsetAsync(info_dev, 0, sizeof(int), s);
+    const int np = (int)(n_pad / 128);
+    // info_dev[0] is the status word; info_dev[1 + 2p], [2 + 2p] the publication counts of panel p's fused launch
+    const bool fused = panel_form == 4 && !pipe && 2 * np <= kCholFlagSlots;
+    // (a launch, not hipMemsetAsync: the runtime's fill costs two kernels and ~8 us of marker gaps around each)
+    hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(256), 0, s, info_dev, fused ? 1 + 2 * np : 1);
+    int *flags = info_dev + 1;
     const int rcol = (int)n_pad;
 #ifdef CBO_DIAG_KNOBS
     const int dbg = chol_dbg_mask();
 #else
     const int dbg = 0;
 #endif
-    const int np = (int)(n_pad / 128);
     while ((int)events.size() < 2 * np + 2) {
         hipEvent_t e;
         hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence);
@@ -1543,7 +1692,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     double *zvec = pipe ? pipe->zvec : nullptr;
     // beside a pipelined sweep the panel solves use the half-LDS kernel, which fits next to a sweep workgroup
     const bool half_lds = pipe && pipe->half_lds;
-    const bool lean_panel = (panel_form == 2 && !pipe) || panel_form == 3;     // 3: also beside a pipelined sweep
+    const bool lean_panel = ((panel_form == 2 || panel_form == 4) && !pipe) || panel_form == 3;
     int pair = 0;
     auto sweep_rows = [&](int r0, int klen) {
         if (pipe && r0 < pipe->tail_begin) sweep_pipe_pair(*pipe, s, A, lda, invDt, n_pad, pair++, r0, klen);
@@ -1558,10 +1707,12 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     int pending = -1;                      // event index of the bulk update still in flight
     for (int k = 0; k < np; k += 2) {
         const int r0 = 128 * k;
-        launch_diag(r0);
         const int n2 = (int)n_pad - r0 - 128;
+        if (fused && n2 > 0) launch_panel_fused(s, A, lda, r0, rcol, invDt, info_dev, nullptr, n2, flags + 2 * (r0 / 128));
+        else launch_diag(r0);
         if (n2 <= 0) { sweep_rows(r0, 128); break; }
-        if (lean_panel) launch_panel_trsm(s, A, lda, r0, r0 + 128, n2, invDt, info_dev);   // (beside a pipelined sweep: the half-LDS strip kernel)
+        if (fused) {}
+        else if (lean_panel) launch_panel_trsm(s, A, lda, r0, r0 + 128, n2, invDt, info_dev);   // (beside a pipelined sweep: the half-LDS strip kernel)
         else
         launch_trsm_strips(s, A + (int64_t)r0 * lda + r0, lda, invDt + (int64_t)(r0 / 16) * 256,
                            A + (int64_t)r0 * lda + r0 + 128, lda, 128, n2, nullptr, nullptr, nullptr, false, half_lds);
@@ -1569,10 +1720,19 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         if (syrk_rows_form == 2) launch_syrk_rows(s, A, lda, r0, 128, n2, rcol, info_dev);
         else launch_syrk(s, A, lda, r0, 128, n2, rcol, 0, 2, info_dev);
         const int r1 = r0 + 128;
-        launch_diag(r1);
         const int n3 = (int)n_pad - r1 - 128;
+        const bool bulk = n3 > 256;
+        const bool gemm_form = bulk && n3 - 256 >= syrk_gemm_rows;
+        // the event the side stream waits for completes WITH the launch it follows (no marker packet on the chain)
+        const bool carried = bulk && (fused || lean_panel) && syrk_rows_form == 2;
+        const hipEvent_t ev_panel = (carried && gemm_form) ? events[2 * k] : nullptr;
+        const hipEvent_t ev_rows = (carried && !gemm_form) ? events[2 * k] : nullptr;
+        if (fused && n3 > 0)
+            launch_panel_fused(s, A, lda, r1, rcol, invDt, info_dev, nullptr, n3, flags + 2 * (r1 / 128), ev_panel);
+        else launch_diag(r1);
         if (n3 <= 0) { sweep_rows(r0, 256); break; }
-        if (lean_panel) launch_panel_trsm(s, A, lda, r1, r1 + 128, n3, invDt, info_dev);
+        if (fused) {}
+        else if (lean_panel) launch_panel_trsm(s, A, lda, r1, r1 + 128, n3, invDt, info_dev, ev_panel);
         else
         launch_trsm_strips(s, A + (int64_t)r1 * lda + r1, lda, invDt + (int64_t)(r1 / 16) * 256,
                            A + (int64_t)r1 * lda + r1 + 128, lda, 128, n3, nullptr, nullptr, nullptr, false, half_lds);
@@ -1583,10 +1743,8 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         // first workgroups; a small one is hidden behind the chain anyway and would only slow the rows kernel (which is
         // ON the chain) down, so it starts after that.
         const int prev = pending;
-        const bool bulk = n3 > 256;
-        const bool gemm_form = bulk && n3 - 256 >= syrk_gemm_rows;
         auto launch_bulk = [&] {
-            hipEventRecord(events[2 * k], s);
+            if (!carried) hipEventRecord(events[2 * k], s);
             hipStreamWaitEvent(side, events[2 * k], 0);
             // Large trailing blocks go through the LDS-staged GEMM form of the sweep's update kernel (C -= P^T P on
             // 64-column strips x 256-row chunks, upper part only, the rhs strip as one more strip): the 64x64-tile SYRK
@@ -1601,7 +1759,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         };
         if (gemm_form) launch_bulk();
         if (prev >= 0) hipStreamWaitEvent(s, events[prev], 0);
-        if (syrk_rows_form == 2) launch_syrk_rows(s, A, lda, r0, 256, n3, rcol, info_dev, 256);
+        if (syrk_rows_form == 2) launch_syrk_rows(s, A, lda, r0, 256, n3, rcol, info_dev, 256, ev_rows);
         else launch_syrk(s, A, lda, r0, 256, n3, rcol, 0, 4, info_dev);
         if (bulk && !gemm_form) launch_bulk();
     }
