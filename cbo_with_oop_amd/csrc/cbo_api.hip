@@ -986,12 +986,26 @@ static bool prefer_right_looking(const cbo_ctx *c, int64_t n_pad, int64_t cols)
 // left to one left-looking launch after the factorisation?  The pipeline's work runs on CUs the chain leaves
 // idle, but it is the less efficient schedule (~2.9 us per 32-row stage and strip round, co-scheduled, against
 // 2.33 us for the strip kernel alone) and it slows the chain it shares the device with.  The best split found by
-// measurement (scripts/overlap_crossover.py with CBO_HIP_PIPE_TAIL, N = 2048 / 4096 / 8192 at 16384 candidates:
-// 4-5 of 8, 6 of 16, 10 of 32 pairs) is reproduced by taking pairs while their device time stays within
-// 72 us x panels x (panels / 16)^0.72 -- the chain's own time, which stretches with size as more of it turns
-// from launch latency into trailing-update work that shares the CUs.  With fewer strips than CUs the strip kernel
-// could not fill the device, so everything stays in the pipeline.  CBO_HIP_PIPE_TAIL (fraction of rows for the
-// closing launch) overrides.
+// measurement (scripts/overlap_crossover.py with CBO_HIP_PIPE_TAIL, N = 2048 / 4096 / 8192 at 16384 candidates; round 2,
+// with the chain's fused launches: 3 of 8, 5 of 16, 12 of 32 pairs) is reproduced by taking pairs while their device
+// time stays within a budget that stands for the chain's own time -- 1.0 / 3.4 / 15.1 ms at 16 / 32 / 64 panels,
+// interpolated in log-log between those and continued with the slope 1.72 outside (the chain stretches with size as
+// more of it turns from launch latency into trailing-update work that shares the CUs).  With fewer strips than CUs the
+// strip kernel could not fill the device, so everything stays in the pipeline.  CBO_HIP_PIPE_TAIL (fraction of rows for
+// the closing launch) overrides.
+static double pipeline_budget_us(int nb)
+{
+    static const double xs[3] = {4.0, 5.0, 6.0};                   // log2(panels)
+    static const double ys[3] = {10.0, 11.75, 13.88};              // log2(budget in us)
+    const double x = std::log2((double)(nb > 1 ? nb : 1));
+    double y;
+    if (x <= xs[0]) y = ys[0] + 1.72 * (x - xs[0]);
+    else if (x >= xs[2]) y = ys[2] + 1.72 * (x - xs[2]);
+    else if (x <= xs[1]) y = ys[0] + (ys[1] - ys[0]) * (x - xs[0]);
+    else y = ys[1] + (ys[2] - ys[1]) * (x - xs[1]);
+    return std::exp2(y);
+}
+
 static int pipeline_pairs(const cbo_ctx *c, int64_t n_pad, int64_t m_pad)
 {
     const int nb = (int)(n_pad / 128);
@@ -1003,7 +1017,7 @@ static int pipeline_pairs(const cbo_ctx *c, int64_t n_pad, int64_t m_pad)
     }
     if (prefer_right_looking(c, n_pad, m_pad)) return all_pairs;     // the strip kernel would leave CUs idle
     const double rounds = (double)(m_pad / kStrip) / (double)c->n_cu;
-    const double budget_us = 72.0 * nb * std::pow((double)nb / 16.0, 0.72);
+    const double budget_us = pipeline_budget_us(nb);
     double used_us = 0.0;
     int pairs = 0;
     while (pairs < all_pairs) {
@@ -1363,8 +1377,10 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
         return cbo_acq_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
     }
     // below ~1000 rows the chain is a handful of launches and there is nothing to hide it under; above, the number
-    // of pairs that go through the pipeline adapts to the shape (pipeline_pairs)
-    const bool overlap = c->overlap_mode == 1 || (c->overlap_mode != 0 && g->n_pad >= 1024);
+    // of pairs that go through the pipeline adapts to the shape (pipeline_pairs); from ~12000 rows on the factorisation
+    // is bound by its bulk updates, not by the chain, and the pipeline's extra passes over V only cost (16384 points:
+    // 1-2 % slower than the two calls, scripts/overlap_crossover.py)
+    const bool overlap = c->overlap_mode == 1 || (c->overlap_mode != 0 && g->n_pad >= 1024 && g->n_pad <= 12288);
     if (!overlap) {
         rc = cbo_gp_fit(g, tries_out, jitter_out);
         if (rc != CBO_OK) return rc;

@@ -1650,8 +1650,8 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
                         (int)sizeof(PanelShared));
     hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_panel_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)sizeof(Diag2Shared));
-    // 4: diagonal block + row panel in one launch (not beside a pipelined sweep); 2: separate launches, lean panel kernel;
-    // 3: the lean panel kernel also beside a pipelined sweep; 1: the strip kernel as panel solver
+    // 4: diagonal block + row panel in one launch; 2: separate launches (lean panel kernel, beside a pipelined sweep the
+    // half-LDS strip kernel); 3: the lean panel kernel also beside a pipelined sweep; 1: the strip kernel as panel solver
     static const int panel_form = [] { const char *e = std::getenv("CBO_HIP_PANEL_FORM"); return e ? std::atoi(e) : 4; }();
     static const int syrk_gemm_rows = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_ROWS"); return e ? std::atoi(e) : 6144; }();
     static const int syrk_gemm_chunk = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_CHUNK"); return e ? std::atoi(e) : 1; }();
@@ -1668,7 +1668,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     };
     const int np = (int)(n_pad / 128);
     // info_dev[0] is the status word; info_dev[1 + 2p], [2 + 2p] the publication counts of panel p's fused launch
-    const bool fused = panel_form == 4 && !pipe && 2 * np <= kCholFlagSlots;
+    const bool fused = panel_form == 4 && 2 * np <= kCholFlagSlots;
     // (a launch, not hipMemsetAsync: the runtime's fill costs two kernels and ~8 us of marker gaps around each)
     hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(256), 0, s, info_dev, fused ? 1 + 2 * np : 1);
     int *flags = info_dev + 1;
@@ -1708,7 +1708,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     for (int k = 0; k < np; k += 2) {
         const int r0 = 128 * k;
         const int n2 = (int)n_pad - r0 - 128;
-        if (fused && n2 > 0) launch_panel_fused(s, A, lda, r0, rcol, invDt, info_dev, nullptr, n2, flags + 2 * (r0 / 128));
+        if (fused && n2 > 0) launch_panel_fused(s, A, lda, r0, rcol, invDt, info_dev, zvec, n2, flags + 2 * (r0 / 128));
         else launch_diag(r0);
         if (n2 <= 0) { sweep_rows(r0, 128); break; }
         if (fused) {}
@@ -1728,7 +1728,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         const hipEvent_t ev_panel = (carried && gemm_form) ? events[2 * k] : nullptr;
         const hipEvent_t ev_rows = (carried && !gemm_form) ? events[2 * k] : nullptr;
         if (fused && n3 > 0)
-            launch_panel_fused(s, A, lda, r1, rcol, invDt, info_dev, nullptr, n3, flags + 2 * (r1 / 128), ev_panel);
+            launch_panel_fused(s, A, lda, r1, rcol, invDt, info_dev, zvec, n3, flags + 2 * (r1 / 128), ev_panel);
         else launch_diag(r1);
         if (n3 <= 0) { sweep_rows(r0, 256); break; }
         if (fused) {}
