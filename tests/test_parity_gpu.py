@@ -546,6 +546,47 @@ def test_bitwise_reproducibility(hip):
         assert np.array_equal(r1["mean"], r2["mean"]) and r1["best_idx"] == r2["best_idx"]
 
 
+def test_chain_launch_forms_give_the_same_bits(hip):
+    """The factorisation's chain with the diagonal block and its row panel in ONE launch (the default: workgroup 0
+    publishes row tiles, the strips follow through flags with coherent loads) against the same chain as separate
+    launches (CBO_HIP_PANEL_FORM=2), each in a process of its own: identical factors, inverses-derived posteriors and
+    sweeps, at sizes with one, several and many panels, with and without a jitchol retry."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import hashlib, sys, warnings
+import numpy as np
+sys.path.insert(0, %r)
+from cbo_with_oop_amd import CausalExpectedImprovement
+from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+h = hashlib.sha256()
+for n, noise in ((130, 1e-2), (700, 1e-2), (2300, 1e-3), (1500, 1e-10)):
+    rng = np.random.default_rng(n)
+    X = rng.uniform([-5, -5, -5], [5, 20, 5], (n, 3))
+    if noise == 1e-10:
+        X[1::2] = X[::2][: len(X[1::2])]                      # duplicated rows: the first attempt is not positive definite
+    y = np.sin(X).sum(1, keepdims=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        m = HipGaussianProcess(X, y, noise_var=noise)
+    L, alpha = m.posterior_state()
+    r = CausalExpectedImprovement(float(y.min()), "min", m).sweep(rng.uniform(-5, 5, (300, 3)), want_acq=True, want_posterior=True)
+    for a in (L, alpha, r["acq"], r["var"], r["mean"]):
+        h.update(np.ascontiguousarray(a).tobytes())
+    h.update(str((m.jitter_tries, r["best_idx"])).encode())
+    m.close()
+print("DIGEST", h.hexdigest())
+""" % ROOT
+    digests = {}
+    for form in ("4", "2"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CBO_HIP_PANEL_FORM=form),
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests[form] = [ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][-1]
+    assert digests["4"] == digests["2"], digests
+
+
 def test_optimizer_class_and_quotient_mirror_the_reference_call_sequence(hip):
     """src/utils_functions/utils.py:29-37 written out with the mirrored classes gives find_next_y_point's answer."""
     from cbo_with_oop_amd.graphs import ToyGraph
