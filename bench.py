@@ -283,7 +283,7 @@ def main():
             traffic, note = pmc_traffic("step_sequential" if args.sequential else "step")
             out["roofline"] = {
                 "kernel": "whole step: trsm_update_kernel<16> (dominant) + trsm_strip_kernel<*,16> + "
-                          "syrk_kernel<64> + potrf_diag128_kernel, co-scheduled" if not args.sequential else
+                          "syrk_kernel<64> + potrf_panel_fused_kernel (diagonal block + row panel), co-scheduled" if not args.sequential else
                           "whole step: trsm_strip_kernel<true,32> (dominant), then the factorisation's kernels",
                 "bound": "mfma", "achieved": step_tflops, "peak": peak, "unit": "TFLOP/s",
                 "frac": step_tflops / peak, "traffic": traffic, "traffic_source": note,
