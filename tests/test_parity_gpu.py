@@ -1287,6 +1287,37 @@ def test_sweep_sets_small_models_equal_the_per_set_path(hip):
         assert idx == int(f["best_idx"]), f["note"]
 
 
+def test_sweep_sets_twenty_five_sets_in_one_call(hip):
+    """The coral graph's count of exploration sets (S = 25, src/graphs/impl/CoralGraph.py:162-175) in ONE call: more
+    sets than travel as kernel arguments, so the descriptors are read from the pinned array; dimensions 1..3, ragged
+    sizes and grids, against the per-set general path (same bits) and the oracle's arg-max."""
+    from cbo_with_oop_amd import CandidateGrid
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    from cbo_with_oop_amd.graphs import meshgrid_candidates
+    rng = np.random.default_rng(25)
+    models, grids, costs, boxes = [], [], [], []
+    for sidx in range(25):
+        d = 1 + sidx % 3
+        n = 8 + (7 * sidx) % 60
+        box = [(-1.0 - 0.1 * sidx, 2.0 + 0.05 * sidx)] * d
+        X = rng.uniform(box[0][0], box[0][1], (n, d))
+        y = np.cos(X).sum(1, keepdims=True) + 0.1 * rng.standard_normal((n, 1))
+        models.append(HipGaussianProcess(X, y, noise_var=1e-3, fit=False))
+        shape = [(150,), (17, 13), (7, 6, 5)][d - 1]
+        grids.append(CandidateGrid(meshgrid_candidates(box, shape), models[-1]))
+        costs.append(float(d))
+        boxes.append((box, shape))
+    y_best = 0.1
+    got = _sweep_sets(models, grids, y_best, "min", costs)
+    ref_models = [HipGaussianProcess(m.X, m.Y, noise_var=1e-3) for m in models]
+    ref_grids = [CandidateGrid(g.points, rm) for g, rm in zip(grids, ref_models)]
+    want = _per_set_reference(hip, ref_models, ref_grids, y_best, "min", costs)
+    assert got == want
+    for m, g, c, (val, idx) in zip(models, grids, costs, got):
+        _, o_val, o_idx, _, _ = O.acquisition_sweep(O.fit(m.X, m.Y, noise_var=1e-3), g.points, y_best, cost=c)
+        assert idx == o_idx and np.isclose(val, o_val, rtol=1e-6, atol=1e-300)
+
+
 def test_sweep_sets_mixed_sizes_causal_and_jitter(hip):
     """One call over: a causal small model, a small model whose K needs jitchol's jitter (duplicate rows: the general
     path takes over for that set), a model beyond 128 observations, an fp32 model."""
