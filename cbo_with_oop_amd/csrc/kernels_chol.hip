@@ -991,8 +991,11 @@ __device__ __forceinline__ void small_set_finish(double bv, int64_t bi, int set,
 // factorisation of the `tiles` real tiles (factor rows, inverses, z to the workgroup's scratch), the factor back into
 // LDS (what a tile solve reads), the inverses and z into registers.  Ends with loads in flight: the caller waits
 // (s_waitcnt vmcnt(0) + barrier) before the solve.
+// `phases`: 1 = points + assembly + factorisation only (the factor stays in the scratch), 2 = points + the factor from
+// the scratch (somebody factored the model before this launch), 3 = both.
 __device__ __forceinline__ void small_model_factor(SmallShared &sh, const cbo_small_set &st, int tiles, double *Us,
-                                                   double *invs, int *info_word, double (&iv)[8][4], double (&zr)[8][4])
+                                                   double *invs, int *info_word, double (&iv)[8][4], double (&zr)[8][4],
+                                                   int phases = 3)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1007,6 +1010,7 @@ __device__ __forceinline__ void small_model_factor(SmallShared &sh, const cbo_sm
     }
     __syncthreads();
     SSTAMP(1);
+    if (phases & 1) {
     switch (st.d) {
         case 1: small_assemble<1>(sh, st, tiles); break;
         case 2: small_assemble<2>(sh, st, tiles); break;
@@ -1033,6 +1037,8 @@ __device__ __forceinline__ void small_model_factor(SmallShared &sh, const cbo_sm
     // (ends with a barrier.)  Every wave's stores of factor rows / inverses / z are complete before anyone re-reads them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    }
+    if (!(phases & 2)) return;
 
     // ---- the factor back into LDS (rows of the factored tiles; the solve reads nothing else), inverses and z to registers
     {
@@ -1060,7 +1066,7 @@ __global__ __launch_bounds__(256) void small_sets_kernel(const SmallSetArgs byva
                                                          double *scratch, int blocks_per_set,
                                                          double *__restrict__ part_val, int64_t *__restrict__ part_idx,
                                                          int *__restrict__ info, int *__restrict__ ticket,
-                                                         cbo_small_result *__restrict__ out, int seq)
+                                                         cbo_small_result *__restrict__ out, int seq, int phases)
 {
     __shared__ int last_flag;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -1069,6 +1075,12 @@ __global__ __launch_bounds__(256) void small_sets_kernel(const SmallSetArgs byva
     SSTAMP(0);
     const cbo_small_set st = BYVAL ? byval.s[set] : sets[set];
     const int slot = set * blocks_per_set + blk;
+    if (phases == 1) {                                            // one workgroup per set: factor it, nothing else
+        double ivx[8][4], zrx[8][4];
+        double *fs = scratch + (int64_t)(set * blocks_per_set) * kSmallScratch;
+        small_model_factor(sh, st, (st.n + 15) / 16, fs, fs + 128 * kSmallLd, &info[set], ivx, zrx, 1);
+        return;
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1079,11 +1091,12 @@ __global__ __launch_bounds__(256) void small_sets_kernel(const SmallSetArgs byva
         return;
     }
     const int tiles = (st.n + 15) / 16;
-    double *my = scratch + (int64_t)slot * kSmallScratch;
+    // phases 3: every workgroup factors the model itself, into its own scratch slot; phases 2: the set's slot 0 holds it
+    double *my = scratch + (int64_t)(phases == 2 ? set * blocks_per_set : slot) * kSmallScratch;
     double *Us = my, *invs = my + 128 * kSmallLd;
 
     double iv[8][4], zr[8][4];
-    small_model_factor(sh, st, tiles, Us, invs, &info[set], iv, zr);
+    small_model_factor(sh, st, tiles, Us, invs, &info[set], iv, zr, phases);
     SSTAMP(4);
     // ---- K(X, X*) of this wave's 16 candidates, straight into the result layout
     const int64_t c = (int64_t)blk * 64 + wave * 16 + lc;
@@ -1318,13 +1331,26 @@ void launch_small_sets(hipStream_t s, const cbo_small_set *sets, int n_sets, int
     (void)once;
     SmallSetArgs args{};
     const dim3 grid((unsigned)blocks_per_set, (unsigned)n_sets);
-    if (n_sets <= kSmallByValue) {
-        std::memcpy(args.s, sets, sizeof(cbo_small_set) * (size_t)n_sets);
-        hipLaunchKernelGGL(small_sets_kernel<true>, grid, dim3(256), sizeof(SmallShared), s, args, sets, scratch,
-                           blocks_per_set, part_val, part_idx, info, ticket, out, seq);
+    // Few candidate blocks per set (the reference's 100-200 candidates): every workgroup factors its set's model itself,
+    // ONE launch, no dependency between workgroups.  Many blocks per set (16k-candidate grids on 25 coral sets: 6400
+    // workgroups): factoring the model 256 times over costs more than a second launch -- one workgroup per set factors,
+    // then the sweep workgroups start from the factor.
+    static const int two_phase_from = [] { const char *e = std::getenv("CBO_HIP_SMALL_TWO_PHASE"); return e ? std::atoi(e) : 12; }();
+    const bool two_phase = two_phase_from > 0 && blocks_per_set >= two_phase_from;
+    auto launch = [&](const dim3 &g, int phases) {
+        if (n_sets <= kSmallByValue)
+            hipLaunchKernelGGL(small_sets_kernel<true>, g, dim3(256), sizeof(SmallShared), s, args, sets, scratch,
+                               blocks_per_set, part_val, part_idx, info, ticket, out, seq, phases);
+        else
+            hipLaunchKernelGGL(small_sets_kernel<false>, g, dim3(256), sizeof(SmallShared), s, args, sets, scratch,
+                               blocks_per_set, part_val, part_idx, info, ticket, out, seq, phases);
+    };
+    if (n_sets <= kSmallByValue) std::memcpy(args.s, sets, sizeof(cbo_small_set) * (size_t)n_sets);
+    if (two_phase) {
+        launch(dim3(1u, (unsigned)n_sets), 1);
+        launch(grid, 2);
     } else {
-        hipLaunchKernelGGL(small_sets_kernel<false>, grid, dim3(256), sizeof(SmallShared), s, args, sets, scratch,
-                           blocks_per_set, part_val, part_idx, info, ticket, out, seq);
+        launch(grid, 3);
     }
 }
 
