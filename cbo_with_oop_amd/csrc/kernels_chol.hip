@@ -7,15 +7,21 @@
 // non-positive (or NaN) pivot sets *info (first failing 1-based pivot index), which the host-side
 // jitter ladder reads after the factorisation.
 //
-// Per 128-row panel k (rows r0 = 128 k):
-//   1. potrf_diag128_kernel   one workgroup factors the 128x128 diagonal block in LDS (16x16 tiles:
-//                             register Cholesky of the tile by one wave, substitution of the tile's row
-//                             panel by all threads, rank-16 MFMA updates by the other waves), solves the
-//                             rhs rows, emits the eight 16x16 diagonal inverses the strip TRSM consumes
-//   2. trsm_strip_kernel      U[r0:r0+128, r0+128:] = U_kk^-T A[...]    (64-column strips, n = 128)
-//   3. syrk_kernel            A[r0+128:, r0+128:] -= P^T P  on the upper 128x128 tiles (fp64 MFMA),
-//                             rhs[r0+128:] -= P^T z_k
-// The SYRK carries the n^3/3 flops; steps 1-2 are the serial chain.
+// Per 128-row panel (rows r0 = 128 k; panels go in pairs, launch_cholesky has the schedule):
+//   1. potrf_panel_fused_kernel   diagonal block AND row panel in one launch: workgroup 0 factors the 128x128 block in
+//                                 LDS (potrf_diag128_v2's device function: one wave runs the chain of 16x16 register
+//                                 Choleskys, three waves solve the block's row panel and update its trailing tiles) and
+//                                 publishes finished row tiles; the other workgroups are the panel's 64-column strips
+//                                 and follow tile by tile.  Separate launches (CBO_HIP_PANEL_FORM=2):
+//                                 potrf_diag128_v2_kernel + panel_trsm_kernel; round 1's forms: potrf_diag128_kernel,
+//                                 trsm_strip_kernel as panel solver
+//   2. syrk_rows_kernel           the next panel's (pair's) own rows  -= P^T P   (the piece of the update on the chain)
+//   3. syrk_kernel<64> / trsm_update_kernel   the bulk of  A[below, below] -= P^T P  on a second stream (fp64 MFMA),
+//                                 rhs -= P^T z  along with it
+// The bulk update carries the n^3/3 flops; steps 1-2 are the serial chain.
+// Also here: backsolve / forward-solve steps for single vectors, and the one-workgroup kernels for models of at most 128
+// observations (small_sets_kernel: factor + sweep of every exploration set of a trial; small_lml_kernel: likelihood and
+// gradients of one MLE iterate).
 #include <hip/hip_ext.h>
 #include <climits>
 #include <cstdlib>
