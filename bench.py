@@ -130,7 +130,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--cpu-sample", type=int, default=None,
-                    help="candidates in the CPU-baseline sample (0 = skip; default 4096 for f64, 512 for f32)")
+                    help="candidates in the CPU-baseline sample (0 = skip; default 4096 for f64, 64 for f32: ~30 s of sweep each\n"
+                         "next to the full CPU fit)")
     ap.add_argument("--post-steps", type=int, default=3,
                     help="instrumented two-call steps after the timed region (phase timers, isolated kernel; 0 = skip)")
     ap.add_argument("--sequential", action="store_true",
@@ -140,7 +141,7 @@ def main():
     if args.steps is None:
         args.steps = 8 if f32 else 20
     if args.cpu_sample is None:
-        args.cpu_sample = 512 if f32 else 4096
+        args.cpu_sample = 64 if f32 else 4096          # the 16384-point fit alone is ~25 s of CPU; keep the sample ~30 s
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
