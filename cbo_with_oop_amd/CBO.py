@@ -54,6 +54,9 @@ class CBOAcquisitionPath:
 
     def update_all_gaussian_processes(self):
         """CBO.py:209-222."""
+        self._call_cache.clear()          # its handle arrays name the models and grids replaced below
+        for _, grid in self._grids.values():
+            grid.close()
         self._grids.clear()
         self.models = [
             GPFactory.create(self.gp_type, self.data_x[s], self.data_y[s],
@@ -71,7 +74,10 @@ class CBOAcquisitionPath:
                 and model.variance_adjustment is self.var_functions[s]:
             model.rebuild(self.data_x[s], self.data_y[s], fit=fit)      # same handle: no allocation, no new grid
             return
-        self._grids.pop(s, None)
+        self._call_cache.clear()
+        old = self._grids.pop(s, None)
+        if old is not None:
+            old[1].close()
         self.models[s] = GPFactory.create(self.gp_type, self.data_x[s], self.data_y[s],
                                           [self.mean_functions[s], self.var_functions[s]], emukit_wrapper=True, fit=fit)
 
@@ -115,6 +121,7 @@ class CBOAcquisitionPath:
         cached = self._grids.get(s)
         if cached is None or cached[0] != key:
             if cached is not None:
+                self._call_cache.clear()
                 cached[1].close()
             if mode == "candidates":
                 from .sharding import shard_bounds

@@ -5,7 +5,7 @@ For every candidate intervention value the reference builds the observed inputs 
 the intervened columns overwritten (``get_intervened_inputs``, :80-89), predicts with that GP (:77) and
 averages over the observed rows (:59-60) -- a Python loop over candidates with a dict cache.  Here all
 candidates go through ONE batched device predict whose per-candidate row means are reduced on the GPU
-(``cbo_gp_predict_grouped``).  The shipped reference indexes a dict with a list and passes the raw
+(``cbo_gp_predict_do``: the intervened inputs are expanded on the device too).  The shipped reference indexes a dict with a list and passes the raw
 interventions record instead of the variable names, so this restates the
 intended computation, with the exploration-set variable names as the "intervention".
 """

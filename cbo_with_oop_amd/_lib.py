@@ -18,6 +18,8 @@ c_int64_p = ctypes.POINTER(ctypes.c_int64)
 c_int_p = ctypes.POINTER(ctypes.c_int)
 c_void_pp = ctypes.POINTER(ctypes.c_void_p)
 
+ABI_VERSION = 2          # include/cbo_hip.h: CBO_HIP_ABI_VERSION
+ABI_DIAG_BASE = 1000     # CBO_HIP_ABI_DIAG_BASE: timing-only builds report ABI_DIAG_BASE + version
 CBO_OK = 0
 CBO_ERR_INVALID = -1
 CBO_ERR_HIP = -2
@@ -154,6 +156,14 @@ def load():
                 fn = getattr(lib, name)       # AttributeError if the .so lacks a declared symbol
                 fn.restype = restype
                 fn.argtypes = argtypes
+            version = lib.cbo_abi_version()
+            if version >= ABI_DIAG_BASE and os.environ.get("CBO_HIP_ALLOW_DIAG") != "1":
+                raise ImportError(
+                    f"{LIB_PATH} is a timing-only diagnostic build (cbo_abi_version() = {version}): its results may be "
+                    f"wrong by construction.  Measurement scripts opt in with CBO_HIP_ALLOW_DIAG=1.")
+            if version % ABI_DIAG_BASE != ABI_VERSION:
+                raise ImportError(f"{LIB_PATH} has ABI version {version}, this package binds version {ABI_VERSION}: "
+                                  f"rebuild it (`make -C cbo_with_oop_amd/csrc`)")
             _lib = lib
     return _lib
 

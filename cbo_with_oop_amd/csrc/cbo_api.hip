@@ -244,7 +244,14 @@ static void resolve_events(cbo_ctx *c)
 // ---- context -------------------------------------------------------------------------------------
 static void destroy_ctx(cbo_ctx *c);
 
-extern "C" int cbo_abi_version(void) { return CBO_HIP_ABI_VERSION; }
+extern "C" int cbo_abi_version(void)
+{
+#ifdef CBO_DIAG_KNOBS
+    return CBO_HIP_ABI_DIAG_BASE + CBO_HIP_ABI_VERSION;
+#else
+    return (f32_debug_mask() != 0 ? CBO_HIP_ABI_DIAG_BASE : 0) + CBO_HIP_ABI_VERSION;
+#endif
+}
 extern "C" const char *cbo_last_error(void) { return g_err.c_str(); }
 
 extern "C" int cbo_device_count(int *count_out)

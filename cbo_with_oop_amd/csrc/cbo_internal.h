@@ -108,6 +108,7 @@ void launch_kstar_f32(hipStream_t s, const PointSet &X, const PointSet &C, int64
 void launch_trsm_strips_f32(hipStream_t s, const float *U, int64_t ldu, const float *invDt, float *V, int64_t ldv,
                             int64_t n32, int64_t m_pad, double *q);
 int run_mfma_f32_selftest(hipStream_t s, double *max_err);
+int f32_debug_mask();      // the F32_DBG mask this library was built with (0 in a product build)
 
 // Recursive blocked Cholesky (upper) of A[0:n_pad, 0:n_pad] incl. forward solve of the rhs strip.
 // Sweep pipelined with the factorisation: as soon as a pair of 128-row panels of U is final, the strip kernel

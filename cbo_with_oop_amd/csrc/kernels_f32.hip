@@ -35,6 +35,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef F32_DBG
 #define F32_DBG 0          // timing-only builds (scripts/f32_variants.sh): bit mask of pieces to leave out; results are wrong
 #endif
+int f32_debug_mask() { return F32_DBG; }       // a non-zero mask changes cbo_abi_version(): _lib.load() refuses the build
 #if (F32_DBG & 1)
 #define SCHED_DS(n)
 #define SCHED_MFMA(n)

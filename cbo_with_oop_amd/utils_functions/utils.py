@@ -110,11 +110,20 @@ def find_next_y_points(models, current_global_best, evaluated_sets, costs_functi
     import ctypes
     from .. import _lib
     s = len(models)
-    key = (id(costs_functions), tuple(id(m) for m in models), tuple(id(g) for g in grids))
+    # The cache entry holds the models, grids and cost table themselves (strong references, compared with ``is``)
+    # next to their device handles: an ``id()`` alone comes back as soon as CPython reuses a freed address, and the
+    # handle array would then name destroyed cbo_gp / cbo_cands objects.
+    handles = tuple(int(o._handle.value or 0) for o in list(models) + list(grids))      # ctypes.c_void_p handles
     st = cache.get("sweep_sets") if cache is not None else None
-    if st is None or st["key"] != key or raw:
+    same = (st is not None and not raw and st["cost_table"] is costs_functions and st["handles"] == handles
+            and len(st["models"]) == s and all(a is b for a, b in zip(st["models"], models))
+            and all(a is b for a, b in zip(st["grids"], grids)))
+    if not same:
+        if 0 in handles:
+            raise ValueError("find_next_y_points: a model or candidate grid has been closed")
         costs = None if raw else [Cost(costs_functions, evaluated_sets[i]) for i in range(s)]
-        st = {"key": key, "costs": costs,
+        st = {"cost_table": costs_functions, "models": list(models), "grids": list(grids), "handles": handles,
+              "costs": costs,
               "batch_cost": np.array(costs_functions.values if raw else
                                      [float(costs[i].evaluate(grids[i].points)) for i in range(s)], dtype=np.float64),
               "gps": (ctypes.c_void_p * s)(*[m._handle for m in models]),

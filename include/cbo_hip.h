@@ -21,7 +21,13 @@
 extern "C" {
 #endif
 
-#define CBO_HIP_ABI_VERSION 1
+/* 2: cbo_timers gained ms_f32_convert (the library writes sizeof(cbo_timers) bytes into the caller's struct),
+ *    cbo_gp_create accepts CBO_DTYPE_F32, cbo_synchronize is device-wide.
+ * cbo_abi_version() returns this value from a product build.  Timing-only builds (CBO_DIAG_KNOBS, or a non-zero
+ * F32_DBG mask, whose results may be wrong by construction) return CBO_HIP_ABI_DIAG_BASE + this value, so that a
+ * consumer checking the version refuses them as the product. */
+#define CBO_HIP_ABI_VERSION 2
+#define CBO_HIP_ABI_DIAG_BASE 1000
 #define CBO_MAX_DIM 8
 
 typedef enum cbo_status {

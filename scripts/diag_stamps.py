@@ -1,4 +1,4 @@
-"""Timing-only (diagnostic build, CBO_HIP_LIB=.../libcbo_hip_diag.so): s_memtime stamps of the last diagonal-block
+"""Timing-only (diagnostic build, CBO_HIP_ALLOW_DIAG=1 CBO_HIP_LIB=.../libcbo_hip_diag.so): s_memtime stamps of the last diagonal-block
 launch of a factorisation -- per interval, wave 0 (loads + row tile + update | tile factor | stores) and waves 1-3
 (own panel tiles | rendezvous wait | trailing tiles).  s_memtime ticks at 100 MHz (10 ns)."""
 import ctypes, os, sys

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timing-only: price the phases of the Cholesky kernels with the diagnostic build (results are wrong by design).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-export CBO_HIP_LIB=$GRAFT_REPO_ROOT/cbo_with_oop_amd/libcbo_hip_diag.so
+export CBO_HIP_ALLOW_DIAG=1 CBO_HIP_LIB=$GRAFT_REPO_ROOT/cbo_with_oop_amd/libcbo_hip_diag.so
 for mask in ${MASKS:-0 1 2 4 8 16 32 63 64 128 192 256}; do
   export CBO_DBG_CHOL=$mask
   rm -rf gpurun_out/diag_$mask

@@ -1,4 +1,4 @@
-"""Timing-only (diagnostic build, CBO_HIP_LIB=.../libcbo_hip_diag.so): s_memtime stamps of workgroup (0, 0) of the
+"""Timing-only (diagnostic build, CBO_HIP_ALLOW_DIAG=1 CBO_HIP_LIB=.../libcbo_hip_diag.so): s_memtime stamps of workgroup (0, 0) of the
 multi-set kernel at BASELINE config 1 shape -- where its time goes, phase by phase (ticks ~ shader clocks)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

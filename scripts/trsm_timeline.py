@@ -1,5 +1,5 @@
 """Timing-only (diagnostic build): per-stage s_memtime stamps of workgroup 0 / wave 0 of the sweep's strip TRSM.
-Run with CBO_HIP_LIB=.../libcbo_hip_diag.so.  Prints, for regular and diagonal stages, the mean cycles spent
+Run with CBO_HIP_ALLOW_DIAG=1 CBO_HIP_LIB=.../libcbo_hip_diag.so.  Prints, for regular and diagonal stages, the mean cycles spent
 (a) waiting at the top (s_waitcnt + barrier) and (b) in the stage body."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1374,6 +1374,45 @@ def test_sweep_sets_switch_and_path_integration(hip, monkeypatch):
     assert run() == one_launch
 
 
+def test_path_rebuilds_between_sweeps_never_reuse_destroyed_handles(hip):
+    """A set rebuilt twice without a sweep in between (two observe trials in a row with one set, or closures that
+    change twice): the multi-set call must be handed the handles of the objects that are alive now.  The cache of the
+    handle arrays holds the models and grids themselves and is dropped on every rebuild; each round is checked against
+    the oracle on that round's data."""
+    from cbo_with_oop_amd import CBOAcquisitionPath, GaussianProcessType
+    from cbo_with_oop_amd.graphs import ToyGraph, meshgrid_candidates
+    rng = np.random.default_rng(5)
+    es = [["Z"]]
+    xs = [rng.uniform(-5, 20, (30, 1))]
+    ys = [ToyGraph.target_do_z(xs[0])]
+    closures = [lambda x: np.zeros((x.shape[0], 1)), lambda x: np.zeros((x.shape[0], 1))]
+    path = CBOAcquisitionPath(GaussianProcessType.CAUSAL_GP, es, ToyGraph.get_cost_structure(1), "min", xs, ys,
+                              [ToyGraph.bounds(s) for s in es], mean_functions=[closures[0]], var_functions=[closures[1]],
+                              grid_shapes=[[200]], comm=None)
+    path.update_all_gaussian_processes()
+    grid = meshgrid_candidates(ToyGraph.bounds(es[0]), [200])
+    for rnd in range(6):
+        best = float(path.data_y[0].min())
+        pts, vals = path.compute_best_acquisition_values(best)
+        _, val, idx, _, _ = O.acquisition_sweep(O.fit(path.data_x[0], path.data_y[0]), grid, best, cost=1.0)
+        assert np.allclose(pts[0], grid[idx][None, :]) and np.isclose(vals[0][0, 0], val, rtol=1e-5, atol=1e-300)
+        cached = path._call_cache["sweep_sets"]
+        assert cached["models"][0] is path.models[0] and cached["handles"][0] == path.models[0]._handle.value
+        # two rebuilds, no sweep between them: new closures force new model and grid objects each time
+        for _ in range(2):
+            x_add = rng.uniform(-5, 20, (1, 1))
+            path.data_x[0] = np.vstack([path.data_x[0], x_add])
+            path.data_y[0] = np.vstack([path.data_y[0], ToyGraph.target_do_z(x_add)])
+            path.mean_functions[0] = lambda x: np.zeros((x.shape[0], 1))
+            path.var_functions[0] = lambda x: np.zeros((x.shape[0], 1))
+            path.last_intervention = 0
+            if rnd % 2:
+                path.update_gaussian_process_of_last_intervention()
+            else:
+                path.update_all_gaussian_processes()
+            assert "sweep_sets" not in path._call_cache
+
+
 class _RecordingComm:
     """Stand-in for sharding.Communicator in a single process: phase "record" keeps what this rank would contribute to
     each exchange; phase "replay" answers each exchange with the reduction over all ranks' recorded contributions."""
