@@ -23,6 +23,7 @@
 // n^2/(2*128) * 8 B per column, U traffic n^2/2*8 B per strip served from L2/MALL; right-looking adds one
 // read-modify-write of the rows below per panel pair.
 #include <cstdlib>
+#include <type_traits>
 
 #include "cbo_internal.h"
 
@@ -83,6 +84,7 @@ extern "C" int cbo_diag_trsm_stamps(unsigned long long *out, int n)
 // stage g computes, across block boundaries, so the pipeline never drains.
 struct StageCursor {
     int i0, j, lim;                       // block origin, stage index within the block, stages in the block
+    int ai0, aj;                          // the same, clamped to the last stage once the cursor is past the end
     const double *a_src;                  // per-lane source of the U tile's first row handled by this wave
     const double *b_src;                  // per-lane source of the wave's first B piece
     int64_t b_stride;                     // doubles between consecutive B pieces
@@ -116,26 +118,39 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
     // Branch-free on purpose (selects and masked arithmetic only): the cursor update sits in the middle of a
     // regular stage's MFMA block, where the scheduler can only hide it if it stays in that basic block.
     const double *inv_lane = invDt + lane * 2;
-    auto locate = [&](StageCursor &c) __attribute__((always_inline)) {
+    // (three pieces, so that the regular stage can place each in the shadow of a different MFMA)
+    auto locate_a = [&](StageCursor &c) __attribute__((always_inline)) {
         const bool past = c.i0 >= n;
-        const int ai0 = past ? n - kRB : c.i0;
-        const int aj = past ? (n - kRB) / kKB + kDS - 1 : c.j;
-        const int nreg = ai0 / kKB;
-        c.a_src = ug + (int64_t)(kKB * aj) * ldu + ai0;
+        c.ai0 = past ? n - kRB : c.i0;
+        c.aj = past ? (n - kRB) / kKB + kDS - 1 : c.j;
+    };
+    auto locate_b = [&](StageCursor &c) __attribute__((always_inline)) {
+        c.a_src = ug + (int64_t)(kKB * c.aj) * ldu + c.ai0;
+    };
+    auto locate_c = [&](StageCursor &c) __attribute__((always_inline)) {
+        const int nreg = c.ai0 / kKB;
         // diagonal stage: the two 16x16 diagonal inverses go to the B region; regular stage: V rows
         // [32 aj, 32 aj + 32) of this wave's 16 columns
-        const int64_t diag = (aj >= nreg) ? 1 : 0;
-        const int64_t off_diag = ((int64_t)(ai0 / 16) + kDT * (aj - nreg)) * 256;
-        const int64_t off_reg = (int64_t)(kKB * aj) * ldv;
+        const int64_t diag = (c.aj >= nreg) ? 1 : 0;
+        const int64_t off_diag = ((int64_t)(c.ai0 / 16) + kDT * (c.aj - nreg)) * 256;
+        const int64_t off_reg = (int64_t)(kKB * c.aj) * ldv;
         const uintptr_t base = (uintptr_t)vg + ((uintptr_t)inv_lane - (uintptr_t)vg) * (uintptr_t)diag;
         c.b_src = reinterpret_cast<const double *>(base) + (off_reg + (off_diag - off_reg) * diag);
         c.b_stride = 8 * ldv + (128 - 8 * ldv) * diag;
     };
-    auto advance = [&](StageCursor &c) __attribute__((always_inline)) {
+    auto locate = [&](StageCursor &c) __attribute__((always_inline)) {
+        locate_a(c);
+        locate_b(c);
+        locate_c(c);
+    };
+    auto step = [&](StageCursor &c) __attribute__((always_inline)) {
         const int wrap = (c.j + 1 == c.lim) ? 1 : 0;
         c.i0 += kRB * wrap;
         c.j = (c.j + 1) * (1 - wrap);
         c.lim = c.lim + (c.i0 / kKB + kDS - c.lim) * wrap;
+    };
+    auto advance = [&](StageCursor &c) __attribute__((always_inline)) {
+        step(c);
         locate(c);
     };
     // the LDS-DMA instructions of a stage, split so they can sit between MFMAs: kParts groups of 3
@@ -150,6 +165,18 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
         }
         glds16(c.b_src + part * c.b_stride, lb + 8u * (unsigned)(part * 128));      // one 1 KiB B piece
     };
+    // the same instructions one at a time (q = 0, 1: the group's U rows; q = 2: its B piece)
+    auto issue_one = [&](const StageCursor &c, int buf, int part, int q) __attribute__((always_inline)) {
+        if (q < 2) {
+            const unsigned la = __builtin_amdgcn_readfirstlane(lds_byte0 + 8u * (unsigned)(buf * kABuf + (wave * G::kRA) * kLdsLd));
+            const int p = 2 * part + q;
+            glds16(c.a_src + (int64_t)p * ldu, la + 8u * (unsigned)(p * kLdsLd));
+        } else {
+            const unsigned lb = __builtin_amdgcn_readfirstlane(
+                lds_byte0 + 8u * (unsigned)(kNBuf * kABuf + buf * kBBuf + wave * (kKB * 16)));
+            glds16(c.b_src + part * c.b_stride, lb + 8u * (unsigned)(part * 128));
+        }
+    };
     auto issue_stage = [&](const StageCursor &c, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int part = 0; part < kParts; ++part) issue_part(c, buf, part);
@@ -162,7 +189,7 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] = -Vc[(int64_t)(16 * t + kq + 4 * r) * ldv];
 
-    StageCursor ahead{0, 0, kDS, nullptr, nullptr, 0};
+    StageCursor ahead{0, 0, kDS, 0, 0, nullptr, nullptr, 0};
     locate(ahead);
     issue_stage(ahead, 0);
     advance(ahead);
@@ -213,29 +240,49 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
             extra_prev = 0;
             const double *abase = lds + buf * kABuf + kq * kLdsLd + lc;
             const double *bbase = ldsB + buf * kBBuf + wave * (kKB * 16) + kq * 16 + lc;
+            // One wave per SIMD issues in order, and an instruction of any kind takes a few cycles of issue: whatever
+            // stands between two MFMAs beyond the 64 cycles the first one executes is a hole in the matrix pipe.  So
+            // every MFMA is followed by ONE small piece of the other work -- a ds_read2 of the next k-step's A
+            // fragments, its B fragment, one LDS-DMA instruction of stage g+2, a share of the cursor arithmetic --
+            // and a scheduling fence pins that order (ISA of round 2: all reads and DMA of a k-step bunched ahead of
+            // its eight MFMAs, ~600 cycles per k-step instead of 512).
 #pragma unroll
-            for (int t = 0; t < kT; ++t) af[0][t] = abase[16 * t];
-            bf[0] = bbase[0];
-            if (deferred) {
-#pragma unroll
-                for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
+            for (int t = 0; t < kT; ++t) {
+                if (deferred) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
+                if (t < kT / 2) {
+                    af[0][2 * t] = abase[32 * t];
+                    af[0][2 * t + 1] = abase[32 * t + 16];
+                } else if (t == kT / 2) {
+                    bf[0] = bbase[0];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
             STAMP(4);
 #pragma unroll
             for (int jj = 0; jj < kKS - 1; ++jj) {
+                const double *an = abase + 4 * (jj + 1) * kLdsLd;
 #pragma unroll
-                for (int t = 0; t < kT; ++t) af[(jj + 1) & 1][t] = abase[4 * (jj + 1) * kLdsLd + 16 * t];
-                bf[(jj + 1) & 1] = bbase[4 * (jj + 1) * 16];
-                if (jj < kParts) issue_part(ahead, bnext, jj);            // stage g+2's DMA rides under the MFMAs
-                if (jj == kParts) advance(ahead);                         // cursor bookkeeping under the MFMAs too
-#pragma unroll
-                for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[jj & 1][t], bf[jj & 1], acc[t]);
-                // pin "LDS reads of step jj+1, DMA, then the MFMAs of step jj": reads and DMA issue complete
-                // under the MFMAs
-                SCHED_DS(kT + 1);
-                if (jj < kParts) { SCHED_VMEM(3); }
-                SCHED_MFMA(kT);
+                for (int t = 0; t < kT; ++t) {
+                    acc[t] = MFMA_F64(af[jj & 1][t], bf[jj & 1], acc[t]);
+                    if (t < kT / 2) {
+                        af[(jj + 1) & 1][2 * t] = an[32 * t];
+                        af[(jj + 1) & 1][2 * t + 1] = an[32 * t + 16];
+                    } else if (t == kT / 2) {
+                        bf[(jj + 1) & 1] = bbase[4 * (jj + 1) * 16];
+                    } else if (jj < kParts) {
+                        issue_one(ahead, bnext, jj, t - (kT / 2 + 1));    // stage g+2's DMA rides under the MFMAs
+                    } else if (jj == kParts) {                            // cursor bookkeeping under the MFMAs too
+                        if (t == kT / 2 + 1) step(ahead);
+                        if (t == kT / 2 + 2) locate_a(ahead);
+                        if (t == kT / 2 + 3) {
+                            locate_b(ahead);
+                            if (kParts + 1 >= kKS - 1) locate_c(ahead);   // KB = 16: no further k-step in the stage
+                        }
+                    } else if (jj == kParts + 1) {
+                        if (t == kT / 2 + 1) locate_c(ahead);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             deferred = true;                                              // the last k-step sits in af[1], bf[1]
             STAMP(2);
@@ -385,6 +432,447 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// The strip kernel with TWO waves per SIMD (512 threads): a single wave cannot keep the fp64 matrix pipe busy --
+// scripts/probes/stage_probe.hip: back-to-back independent v_mfma_f64_16x16x4_f64 from one wave issue every ~75
+// cycles instead of 64, and every barrier, s_waitcnt or dependent chain of that wave is a hole in the pipe; two waves
+// per SIMD with the same LDS reads, DMA and stage barrier run at 0.88 of peak where one wave runs at 0.68-0.73.
+//
+// Same strip (64 columns), same 128-row blocks, same LDS stages (KB = 32), DMA ring and per-element operation order
+// as trsm_strip_kernel -- V, q and mu come out bit for bit the same.  The split is by ROWS: waves (cw, 0) and (cw, 1)
+// share the 16 columns of column group cw (and therefore every B fragment); wave (cw, h) owns row tiles 4h .. 4h+3 of
+// each block, i.e. half of every A tile.  Regular stages need nothing else.  In the diagonal stages the solved tiles
+// of the upper half must reach the lower half's wave: the solver wave (h = 0 in diagonal stages 0 and 1) writes x_s,
+// x_{s+1} over the two 16x16 inverses it has just consumed in the stage's B region (same size, layout = the B
+// operand's), a mid-stage barrier publishes them, and wave (cw, 1) folds them into its four tiles (32 MFMAs) while the
+// solver finishes its own updates.  q = sum V^2 and mu = V^T z keep the sequential per-lane order of the one-wave
+// kernel: the running lane partials are handed from (cw, 0) to (cw, 1) in the middle of each block and back at its
+// end through the padding columns of an LDS stage buffer (the stage barriers order the hand-over).
+constexpr int kTH = kT / 2;               // row tiles per wave
+
+template <bool SWEEP>
+__global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restrict__ U, int64_t ldu,
+                                                          const double *__restrict__ invDt, double *V, int64_t ldv,
+                                                          int n, const double *__restrict__ z,
+                                                          double *__restrict__ q_out, double *__restrict__ mu_out,
+                                                          int accumulate)
+{
+    constexpr int KB = 32;
+    using G = StageGeom<KB>;
+    constexpr int kABuf = G::kA, kBBuf = G::kB, kKS = G::kKS, kDS = G::kDiagStages, kDT = G::kDiagTiles;
+    constexpr int kRows8 = KB / 8;                    // U rows a wave fetches per stage
+    constexpr int kDma8 = kRows8 + 2;                 // LDS-DMA instructions a wave issues per stage (+ two B pieces)
+    constexpr int kSolverStores = 4 * kDT;            // V stores the solver wave issues in a diagonal stage
+    static_assert(kDT == 2 && kDS == 4 && kKS == 8 && kDma8 <= kKS - 2, "geometry the schedule below is written for");
+    __shared__ __align__(16) double lds[kNBuf * (kABuf + kBBuf)];      // 159,744 B
+    __shared__ __align__(16) double zl[SWEEP ? 2 * kRB : 2];           // z rows of the current and the next block
+
+#ifdef CBO_DIAG_KNOBS
+    // timing-only masks (CBO_HIP_STRIP_MASK, results are wrong): 1 = no arithmetic in the diagonal stages (barriers, DMA
+    // and loads stay), 2 = no hand-issued loads for the next block, 4 = no V stores, 8 / 16 = the V pieces / U tiles of every stage come from one fixed place (no HBM traffic),
+    // 256 = stage stamps on (they perturb the run: the stamp stores are not in the stage-top accounting)
+    const int dmask = accumulate >> 8;
+    accumulate &= 1;
+#else
+    constexpr int dmask = 0;
+#endif
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform: LDS bases stay scalar
+    const int cw = wave & 3, h = wave >> 2;                            // column group, row half (waves w, w+4 share a SIMD)
+    const int lc = lane & 15, kq = lane >> 4;
+    const int64_t colw = (int64_t)blockIdx.x * kStrip + cw * 16;       // first column of this wave's column group
+    double *Vc = V + colw + lc;
+    double *ldsB = lds + kNBuf * kABuf;
+    // (q, mu) hand-over slots, two doubles per lane and column group: the 16 padding columns of the first U stage
+    // buffer's 32 rows (the DMA writes 128 columns of each 144-double row, the padding is never touched)
+    double *hand = lds + (cw * 8 + (lane >> 3)) * kLdsLd + kRB + 2 * (lane & 7);
+    const unsigned lds_byte0 = lds_byte_address(lds);
+    const double *ug = U + (int64_t)(wave * kRows8) * ldu + lane * 2;
+    // B pieces (8 rows x 16 columns, 1 KiB): this wave fetches pieces 2h and 2h+1 of its column group
+    const double *vg = V + (int64_t)((lane >> 3) + 16 * h) * ldv + colw + 2 * (lane & 7);
+    const double *inv_lane = invDt + lane * 2 + 256 * h;               // diagonal stages: inverse h of the stage's two
+
+    StageCursor ahead{0, 0, kDS, 0, 0, nullptr, nullptr, 0};
+    auto locate_a = [&](StageCursor &c) __attribute__((always_inline)) {
+        const bool past = c.i0 >= n;
+        c.ai0 = past ? n - kRB : c.i0;
+        c.aj = past ? (n - kRB) / KB + kDS - 1 : c.j;
+    };
+    auto locate_b = [&](StageCursor &c) __attribute__((always_inline)) {
+        c.a_src = ug + (int64_t)(KB * c.aj) * ldu + c.ai0;
+        if (dmask & 16) c.a_src = ug;                          // timing only: every U tile from the same (cached) rows
+    };
+    auto locate_c = [&](StageCursor &c) __attribute__((always_inline)) {
+        const int nreg = c.ai0 / KB;
+        const int64_t diag = (c.aj >= nreg) ? 1 : 0;
+        const int64_t off_diag = ((int64_t)(c.ai0 / 16) + kDT * (c.aj - nreg)) * 256;
+        const int64_t off_reg = (int64_t)(KB * c.aj) * ldv;
+        const uintptr_t base = (uintptr_t)vg + ((uintptr_t)inv_lane - (uintptr_t)vg) * (uintptr_t)diag;
+        c.b_src = reinterpret_cast<const double *>(base) + (off_reg + (off_diag - off_reg) * diag);
+        c.b_stride = 8 * ldv + (128 - 8 * ldv) * diag;
+        if (dmask & 8) c.b_src = vg;                           // timing only: every V piece from the same (cached) rows
+    };
+    auto step = [&](StageCursor &c) __attribute__((always_inline)) {
+        const int wrap = (c.j + 1 == c.lim) ? 1 : 0;
+        c.i0 += kRB * wrap;
+        c.j = (c.j + 1) * (1 - wrap);
+        c.lim = c.lim + (c.i0 / KB + kDS - c.lim) * wrap;
+    };
+    auto advance = [&](StageCursor &c) __attribute__((always_inline)) {
+        step(c);
+        locate_a(c);
+        locate_b(c);
+        locate_c(c);
+    };
+    // DMA instruction i of the wave's kDma8 for the stage the cursor points at: i < kRows8: U row wave*kRows8 + i;
+    // then the two B pieces
+    auto issue_one = [&](const StageCursor &c, int buf, int i) __attribute__((always_inline)) {
+        if (i < kRows8) {
+            const unsigned la = __builtin_amdgcn_readfirstlane(
+                lds_byte0 + 8u * (unsigned)(buf * kABuf + (wave * kRows8) * kLdsLd));
+            glds16(c.a_src + (int64_t)i * ldu, la + 8u * (unsigned)(i * kLdsLd));
+        } else {
+            const unsigned lb = __builtin_amdgcn_readfirstlane(
+                lds_byte0 + 8u * (unsigned)(kNBuf * kABuf + buf * kBBuf + cw * (KB * 16) + (2 * h) * 128));
+            glds16(c.b_src + (i - kRows8) * c.b_stride, lb + 8u * (unsigned)((i - kRows8) * 128));
+        }
+    };
+    auto issue_stage = [&](const StageCursor &c, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < kDma8; ++i) issue_one(c, buf, i);
+    };
+
+    // acc holds the NEGATED residual of this wave's four row tiles
+    d4 acc[kTH];
+#pragma unroll
+    for (int t = 0; t < kTH; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = -Vc[(int64_t)(16 * (kTH * h + t) + kq + 4 * r) * ldv];
+    // What a block needs from global memory besides its DMA stream: the z rows of the tiles this wave will solve and the
+    // block's right-hand sides (K* rows).  vmcnt retires in order and the LDS-DMA instructions are invisible to the
+    // compiler's own counting, so a compiler-visible load consumed inside the steady state turns the compiler's wait
+    // for it into a wait for the DMA of two stages ahead as well -- a full HBM round trip per diagonal stage (4-5000
+    // cycles each in the first timeline of this kernel).  So these loads are issued by hand too, one block ahead, into
+    // AGPRs (which the register allocator never moves), right after the DMA issue of diagonal stage 0; the stage-top
+    // waits below count them (see wait_top), and they are read back once diagonal stage 3's top has retired them.
+    // z travels through LDS: every wave requests the next block's 128 rows (two per lane) with the other ahead loads and
+    // writes them to the half of `zl` the current block does not read (all eight waves write the same 1 KiB: no
+    // rendezvous beyond the stage barriers); the solver reads its rows from there.
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    if (SWEEP) {
+        const d2 z0 = *reinterpret_cast<const d2 *>(z + 2 * lane);
+        *reinterpret_cast<d2 *>(zl + 2 * lane) = z0;           // block 0; published by the first stage barrier
+    }
+    double accn[kTH][4];                  // next block's right-hand sides, in flight
+    d2 zn;                                // next block's z rows 2 lane, 2 lane + 1, in flight
+    constexpr int kAhead = kTH * 4 + (SWEEP ? 1 : 0);         // hand-issued loads per block
+    // load number sl (0 .. kAhead-1) for the block after the one at i0; the last block asks for its own rows again (no
+    // branch around a load: one definition, one use)
+    auto request_one = [&](int i0, int sl) __attribute__((always_inline)) {
+        const int nb = (i0 + kRB < n) ? i0 + kRB : i0;
+        if (sl < kTH * 4) {
+            const int t = sl >> 2, r = sl & 3;
+            const int row = nb + 16 * (kTH * h + t) + kq + 4 * r;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(accn[t][r]) : "v"(Vc + (int64_t)row * ldv) : "memory");
+        } else if (SWEEP) {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(zn) : "v"(z + nb + 2 * lane) : "memory");
+        }
+    };
+
+    locate_a(ahead);
+    locate_b(ahead);
+    locate_c(ahead);
+    issue_stage(ahead, 0);
+    advance(ahead);
+    issue_stage(ahead, 1);
+    advance(ahead);
+
+    int buf = 0;
+#ifdef CBO_DIAG_KNOBS
+    // waves 0 (upper half) and 4 (lower half) of workgroup 0 stamp slots 0..2 / 4..6 of each stage's record
+    const bool stamp_on = SWEEP && (dmask & 256) && blockIdx.x == 0 && lane == 0 && cw == 0;    // CBO_HIP_STRIP_MASK=256
+    const int stamp_base = 4 * h;
+    int stamp_i = 0;
+#define STAMP8(slot)                                                                                    \
+    do {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if (stamp_on && stamp_i < 4096) g_trsm_stamps[8 * stamp_i + stamp_base + (slot)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+    } while (0)
+#else
+#define STAMP8(slot)
+#endif
+    double qacc = 0.0, macc = 0.0, qtot = 0.0, mtot = 0.0;       // totals live in the h = 1 waves
+    if (SWEEP && accumulate && h == 1) {
+        qtot = q_out[colw + lc];
+        mtot = mu_out[colw + lc];
+    }
+
+    // Stage-top wait.  This wave's DMA of stage k (issued during stage k-2) has landed once only what is younger than its
+    // LAST instruction may still be in flight (vmcnt retires in order): what stage k-2 issued after its DMA (a2), and all
+    // of stage k-1 -- what it issued before or among its DMA instructions (b1), the DMA (kDma8), what it issued after
+    // (a1).  "After" are the solver's V stores of a diagonal stage and, in block 0, the hand-issued loads for block 1;
+    // "before" are the hand-issued loads for the next block, spread over the first regular stage of every later block.
+    int a1 = 0, b1 = 0, a2 = 0;
+    auto wait_top = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int extra = a1 + b1 + a2;
+#define WAIT_IF(x) if (extra == (x)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma8 + (x)) : "memory")
+        if (extra == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma8) : "memory");
+        else WAIT_IF(kSolverStores);
+        else WAIT_IF(2 * kSolverStores);
+        else WAIT_IF(kAhead);
+        else WAIT_IF(kAhead + kSolverStores);
+        else WAIT_IF(kAhead + 2 * kSolverStores);
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma8) : "memory");       // (any other count: the strict wait)
+#undef WAIT_IF
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        a2 = a1;
+        a1 = 0;
+        b1 = 0;
+    };
+    static_assert(kDma8 + kAhead + 2 * kSolverStores <= 63, "s_waitcnt vmcnt is a 6-bit count");
+#define STAGE8_TOP() wait_top()
+
+    for (int i0 = 0; i0 < n; i0 += kRB) {
+        const int nst = i0 / KB;
+        double af[2][kTH], bf[2];
+        bool deferred = false;                // af[1]/bf[1] hold the previous stage's last k-step, MFMAs not yet issued
+        // one regular stage; FIRST: the first one of a block, which also carries the hand-issued loads for the next block,
+        // one per MFMA slot ahead of the stage's last DMA instruction
+        auto regular_stage = [&](auto first_tag) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            STAMP8(0);
+            STAGE8_TOP();
+            STAMP8(1);
+            const int bnext = (buf >= 1) ? buf - 1 : 2;       // (buf + 2) % 3
+            const double *abase = lds + buf * kABuf + kq * kLdsLd + lc + 64 * h;
+            const double *bbase = ldsB + buf * kBBuf + cw * (KB * 16) + kq * 16 + lc;
+            // one small piece of the other work after every MFMA, order pinned
+#pragma unroll
+            for (int t = 0; t < kTH; ++t) {
+                if (deferred) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
+                if (t < kTH / 2) {
+                    af[0][2 * t] = abase[32 * t];
+                    af[0][2 * t + 1] = abase[32 * t + 16];
+                } else if (t == kTH / 2) {
+                    bf[0] = bbase[0];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int jj = 0; jj < kKS - 1; ++jj) {
+                const double *an = abase + 4 * (jj + 1) * kLdsLd;
+#pragma unroll
+                for (int t = 0; t < kTH; ++t) {
+                    acc[t] = MFMA_F64(af[jj & 1][t], bf[jj & 1], acc[t]);
+                    if (t < kTH / 2) {
+                        af[(jj + 1) & 1][2 * t] = an[32 * t];
+                        af[(jj + 1) & 1][2 * t + 1] = an[32 * t + 16];
+                    } else if (t == kTH / 2) {
+                        bf[(jj + 1) & 1] = bbase[4 * (jj + 1) * 16];
+                    } else if (jj < kDma8) {
+                        issue_one(ahead, bnext, jj);                      // stage g+2's DMA rides under the MFMAs
+                    }
+                    if (FIRST && t < 3 && 3 * jj + t < kAhead && !(dmask & 2)) request_one(i0, 3 * jj + t);
+                    if (jj == kDma8) {                                    // cursor bookkeeping under the MFMAs too
+                        if (t == 0) step(ahead);
+                        if (t == 1) locate_a(ahead);
+                        if (t == 2) locate_b(ahead);
+                        if (t == 3) locate_c(ahead);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (FIRST && !(dmask & 2)) b1 += kAhead;
+            deferred = true;                                              // the last k-step sits in af[1], bf[1]
+            STAMP8(2);
+            STAMP_NEXT();
+            buf = (buf == 2) ? 0 : buf + 1;
+        };
+        static_assert(3 * (kDma8 - 1) + 2 >= kAhead - 1, "every ahead load has a slot before the stage's last DMA instruction");
+        if (nst > 0) regular_stage(std::true_type{});
+        for (int j = 1; j < nst; ++j) regular_stage(std::false_type{});
+        if (deferred) {
+#pragma unroll
+            for (int t = 0; t < kTH; ++t) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
+        }
+
+        // ---- diagonal stages (two 16-row tiles each): tiles 2m, 2m+1 belong to the waves of half m >> 1
+#pragma unroll
+        for (int m = 0; m < kDS; ++m) {
+            STAMP8(0);
+            STAGE8_TOP();
+            STAMP8(1);
+            const int hs = m >> 1;                            // the solving half
+            const int ls = kDT * (m & 1);                     // its first tile of the stage, as an index into acc[]
+            const bool solver = (h == hs);
+            if (SWEEP && solver && (m == 2 || (m == 0 && ((i0 / kRB) & 1)))) {     // take over the running lane partials
+                qacc = hand[0];
+                macc = hand[1];
+            }
+            const int bnext = (buf >= 1) ? buf - 1 : 2;
+            issue_stage(ahead, bnext);
+            if (m == 0 && i0 == 0 && !(dmask & 2)) {                // block 0 has no regular stage to spread them over
+#pragma unroll
+                for (int sl = 0; sl < kAhead; ++sl) request_one(0, sl);
+                a1 += kAhead;
+            }
+            advance(ahead);
+            STAMP8(3);
+            const double *abase0 = lds + buf * kABuf + kq * kLdsLd + lc;          // U tile of the stage, all 128 columns
+            double *xreg = ldsB + buf * kBBuf + cw * (KB * 16);                   // inverses in, solved tiles out
+            if (dmask & 1) {
+                if (hs == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            } else if (solver) {
+                double iv[kDT][4], uf[kDT][kTH][4], zr[kDT][4];
+                if (SWEEP) {
+                    const double *zrow = zl + ((i0 / kRB) & 1) * kRB + KB * m + kq;
+#pragma unroll
+                    for (int hh = 0; hh < kDT; ++hh)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zr[hh][r] = zrow[16 * hh + 4 * r];
+                }
+#pragma unroll
+                for (int hh = 0; hh < kDT; ++hh) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) iv[hh][kk] = xreg[hh * 256 + (4 * kk + kq) * 16 + lc];
+#pragma unroll
+                    for (int t = ls + hh + 1; t < kTH; ++t)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+                            uf[hh][t][kk] = abase0[(16 * hh + 4 * kk) * kLdsLd + 16 * (kTH * hs + t)];
+                }
+                asm volatile("" ::: "memory");
+                auto emit = [&](int hh, int s, const d4 &x) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = i0 + 16 * s + kq + 4 * r;
+                        if (!(dmask & 4)) Vc[(int64_t)row * ldv] = x[r];
+                        if (SWEEP) {
+                            qacc = fma(x[r], x[r], qacc);
+                            macc = fma(x[r], zr[hh][r], macc);
+                        }
+                    }
+                };
+                // the solved tile, in the B-operand layout [row][column], where the inverse just used stood
+                auto publish = [&](int hh, const d4 &x) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xreg[hh * 256 + (kq + 4 * r) * 16 + lc] = x[r];
+                };
+                const int s = kDT * m;
+                d4 x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
+                x = MFMA_F64(iv[0][0], -acc[ls][0], x);
+                x2 = MFMA_F64(iv[0][1], -acc[ls][1], x2);
+                x = MFMA_F64(iv[0][2], -acc[ls][2], x);
+                x2 = MFMA_F64(iv[0][3], -acc[ls][3], x2);
+                x += x2;
+                if (hs == 0) publish(0, x);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    acc[ls + 1] = MFMA_F64(uf[0][ls + 1][kk], x[kk], acc[ls + 1]);
+                    if (ls + 2 < kTH) acc[ls + 2] = MFMA_F64(uf[0][ls + 2][kk], x[kk], acc[ls + 2]);
+                }
+                emit(0, s, x);
+                const d4 na = -acc[ls + 1];
+                d4 y1 = {0.0, 0.0, 0.0, 0.0}, y2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (kk & 1) y2 = MFMA_F64(iv[1][kk], na[kk], y2);
+                    else y1 = MFMA_F64(iv[1][kk], na[kk], y1);
+#pragma unroll
+                    for (int t = ls + 3; t < kTH; ++t) acc[t] = MFMA_F64(uf[0][t][kk], x[kk], acc[t]);
+                }
+                const d4 y = y1 + y2;
+                if (hs == 0) {
+                    publish(1, y);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                         // the lower half may read x, y now
+                }
+                emit(1, s + 1, y);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int t = ls + 2; t < kTH; ++t) acc[t] = MFMA_F64(uf[1][t][kk], y[kk], acc[t]);
+                }
+                if (!(dmask & 4)) a1 += kSolverStores;
+                if (SWEEP && (m & 1)) {                                   // done with this half's tiles: hand over
+                    if (hs == 0) {
+                        hand[0] = qacc;
+                        hand[1] = macc;
+                        qacc = 0.0;                                       // (an even block starts from zero)
+                        macc = 0.0;
+                    } else if (((i0 / kRB) & 1) || i0 + kRB >= n) {       // end of a block pair: reduce, add
+                        qacc += __shfl_xor(qacc, 16);
+                        qacc += __shfl_xor(qacc, 32);
+                        macc += __shfl_xor(macc, 16);
+                        macc += __shfl_xor(macc, 32);
+                        qtot += qacc;
+                        mtot += macc;
+                        qacc = 0.0;
+                        macc = 0.0;
+                    } else {
+                        hand[0] = qacc;
+                        hand[1] = macc;
+                    }
+                }
+            } else if (hs == 0) {
+                // lower half while the upper half solves: its U fragments against the two tiles first, then -- once the
+                // solver has published them -- the 32 MFMAs
+                double uf[kDT][kTH][4], xb[kDT][4];
+#pragma unroll
+                for (int hh = 0; hh < kDT; ++hh)
+#pragma unroll
+                    for (int t = 0; t < kTH; ++t)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+                            uf[hh][t][kk] = abase0[(16 * hh + 4 * kk) * kLdsLd + 16 * (kTH + t)];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int hh = 0; hh < kDT; ++hh)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) xb[hh][kk] = xreg[hh * 256 + (4 * kk + kq) * 16 + lc];
+#pragma unroll
+                for (int hh = 0; hh < kDT; ++hh)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int t = 0; t < kTH; ++t) acc[t] = MFMA_F64(uf[hh][t][kk], xb[hh][kk], acc[t]);
+            }
+            STAMP8(2);
+            STAMP_NEXT();
+            buf = (buf == 2) ? 0 : buf + 1;
+        }
+        // the hand-issued loads were retired by diagonal stage 3's top (they are older than that stage's DMA)
+#pragma unroll
+        for (int t = 0; t < kTH; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                asm volatile("" : "+v"(accn[t][r]));
+                acc[t][r] = -accn[t][r];
+            }
+        if (SWEEP) {
+            asm volatile("" : "+v"(zn));
+            *reinterpret_cast<d2 *>(zl + (((i0 / kRB) + 1) & 1) * kRB + 2 * lane) = zn;
+        }
+    }
+#undef STAGE8_TOP
+#undef STAMP8
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the clamped tail DMA before the LDS goes away
+    __builtin_amdgcn_s_barrier();
+
+    if (SWEEP && h == 1 && kq == 0) {
+        q_out[colw + lc] = qtot;
+        mu_out[colw + lc] = mtot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Right-looking companion of the strip kernel, used when the sweep is pipelined with the factorisation
 // (launch_cholesky with a SweepPipe): once rows [k0, k0 + klen) of U and of V are final, every row block below
 // them receives its share of the substitution,
@@ -447,16 +935,20 @@ __global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restri
         cj = (cj + 1) * (1 - wrap);
         locate();
     };
-    auto issue_part = [&](int buf, int part) __attribute__((always_inline)) {
-        const unsigned la = __builtin_amdgcn_readfirstlane(lds_byte0 + 8u * (unsigned)(buf * kA + (wave * kRA) * kLdsLd));
-        const unsigned lb = __builtin_amdgcn_readfirstlane(
-            lds_byte0 + 8u * (unsigned)(kNBuf * kA + buf * kB + wave * (KB * 16)));
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
+    auto issue_one = [&](int buf, int part, int q) __attribute__((always_inline)) {
+        if (q < 2) {
+            const unsigned la = __builtin_amdgcn_readfirstlane(lds_byte0 + 8u * (unsigned)(buf * kA + (wave * kRA) * kLdsLd));
             const int p = 2 * part + q;
             glds16(a_src + (int64_t)p * ldu, la + 8u * (unsigned)(p * kLdsLd));
+        } else {
+            const unsigned lb = __builtin_amdgcn_readfirstlane(
+                lds_byte0 + 8u * (unsigned)(kNBuf * kA + buf * kB + wave * (KB * 16)));
+            glds16(b_src + part * b_stride, lb + 8u * (unsigned)(part * 128));
         }
-        glds16(b_src + part * b_stride, lb + 8u * (unsigned)(part * 128));
+    };
+    auto issue_part = [&](int buf, int part) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) issue_one(buf, part, q);
     };
 
     // acc = -C (as in the strip kernel: the k-loop then needs no operand negation)
@@ -501,26 +993,36 @@ __global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restri
             const int bnext = (buf >= 1) ? buf - 1 : 2;
             const double *abase = lds + buf * kA + kq * kLdsLd + lc;
             const double *bbase = ldsB + buf * kB + wave * (KB * 16) + kq * 16 + lc;
+            // as in the strip kernel: one small piece of the other work after every MFMA, order pinned
 #pragma unroll
-            for (int t = 0; t < kT; ++t) af[0][t] = abase[16 * t];
-            bf[0] = bbase[0];
-            if (deferred) {
-#pragma unroll
-                for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
+            for (int t = 0; t < kT; ++t) {
+                if (deferred) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
+                if (t < kT / 2) {
+                    af[0][2 * t] = abase[32 * t];
+                    af[0][2 * t + 1] = abase[32 * t + 16];
+                } else if (t == kT / 2) {
+                    bf[0] = bbase[0];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int jj = 0; jj < kKS - 1; ++jj) {
+                const double *an = abase + 4 * (jj + 1) * kLdsLd;
 #pragma unroll
-                for (int t = 0; t < kT; ++t) af[(jj + 1) & 1][t] = abase[4 * (jj + 1) * kLdsLd + 16 * t];
-                bf[(jj + 1) & 1] = bbase[4 * (jj + 1) * 16];
-                if (jj < kParts) issue_part(bnext, jj);
-                if (jj == kParts) advance();
-#pragma unroll
-                for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[jj & 1][t], bf[jj & 1], acc[t]);
-                SCHED_DS(kT + 1);
-                if (jj < kParts) { SCHED_VMEM(3); }
-                SCHED_MFMA(kT);
+                for (int t = 0; t < kT; ++t) {
+                    acc[t] = MFMA_F64(af[jj & 1][t], bf[jj & 1], acc[t]);
+                    if (t < kT / 2) {
+                        af[(jj + 1) & 1][2 * t] = an[32 * t];
+                        af[(jj + 1) & 1][2 * t + 1] = an[32 * t + 16];
+                    } else if (t == kT / 2) {
+                        bf[(jj + 1) & 1] = bbase[4 * (jj + 1) * 16];
+                    } else if (jj < kParts) {
+                        issue_one(bnext, jj, t - (kT / 2 + 1));
+                    } else if (jj == kParts && t == kT / 2 + 1) {
+                        advance();
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             deferred = true;                       // the last k-step sits in af[1], bf[1] (kKS is even)
             buf = (buf == 2) ? 0 : buf + 1;
@@ -548,6 +1050,26 @@ void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const doubl
     // n is a multiple of 128 at every call site (n_pad of the sweep, the 128-row Cholesky panel)
     const dim3 grid((unsigned)(m_pad / kStrip));
     const int acc = accumulate ? 1 : 0;
+    // CBO_HIP_STRIP_FORM=4: the one-wave-per-SIMD kernel also where a workgroup has the CU to itself (A/B timing;
+    // same bits).  Default: two waves per SIMD (trsm_strip8_kernel).
+    static const int strip_form = [] {
+        const char *e = getenv("CBO_HIP_STRIP_FORM");
+        return e ? atoi(e) : 8;
+    }();
+    if (!half_lds && strip_form != 4) {
+#ifdef CBO_DIAG_KNOBS
+        static const int strip_mask = [] {
+            const char *e = getenv("CBO_HIP_STRIP_MASK");
+            return e ? atoi(e) : 0;
+        }();
+        const int acc = (accumulate ? 1 : 0) | (strip_mask << 8);
+#endif
+        if (q != nullptr)
+            hipLaunchKernelGGL((trsm_strip8_kernel<true>), grid, dim3(512), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, acc);
+        else
+            hipLaunchKernelGGL((trsm_strip8_kernel<false>), grid, dim3(512), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, 0);
+        return;
+    }
     if (q != nullptr) {
         if (half_lds)
             hipLaunchKernelGGL((trsm_strip_kernel<true, 16>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, acc);

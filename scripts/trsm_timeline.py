@@ -2,6 +2,7 @@
 Run with CBO_HIP_ALLOW_DIAG=1 CBO_HIP_LIB=.../libcbo_hip_diag.so.  Prints, for regular and diagonal stages, the mean cycles spent
 (a) waiting at the top (s_waitcnt + barrier) and (b) in the stage body."""
 import ctypes, os, sys
+os.environ.setdefault("CBO_HIP_STRIP_MASK", "256")        # the two-waves-per-SIMD kernel stamps only when asked
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from cbo_with_oop_amd import _lib, CausalExpectedImprovement
@@ -22,6 +23,41 @@ nst = sum(i0 // 32 + 4 for i0 in range(0, n, 128))
 buf = (ctypes.c_ulonglong * (8 * 4096))()
 rc = lib.cbo_diag_trsm_stamps(buf, 8 * 4096)
 st = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8)[:min(nst, 4096)].astype(np.int64)
+kinds, dm = [], []
+for i0 in range(0, n, 128):
+    kinds += ["reg"] * (i0 // 32) + ["diag"] * 4
+    dm += [-1] * (i0 // 32) + [0, 1, 2, 3]
+kinds, dm = np.array(kinds[:len(st)]), np.array(dm[:len(st)])
+if os.environ.get("CBO_HIP_STRIP_FORM", "8") != "4":
+    # two waves per SIMD (trsm_strip8_kernel): wave 0 (upper row half) stamps slots 0..2, wave 4 (lower half) slots 4..6
+    print("stages stamped", len(st), "total cycles (wave 0)", st[-1, 2] - st[0, 0])
+    for name, o in (("upper half (wave 0)", 0), ("lower half (wave 4)", 4)):
+        top, body = st[:, o + 1] - st[:, o], st[:, o + 2] - st[:, o + 1]
+        gap = st[1:, o] - st[:-1, o + 2]
+        sel = kinds == "reg"
+        print(f"{name}: regular stages n={sel.sum()} top(wait+barrier) mean {top[sel].mean():.0f} p90 {np.percentile(top[sel], 90):.0f}"
+              f"  body mean {body[sel].mean():.0f} p90 {np.percentile(body[sel], 90):.0f}  gap to next stage mean {gap[sel[:-1]].mean():.0f}")
+        for m in range(4):
+            sel = dm == m
+            issue = st[:, o + 3] - st[:, o + 1]
+            print(f"    diagonal stage {m}: top {top[sel].mean():.0f}  body {body[sel].mean():.0f}"
+                  f"  (of it DMA issue + ahead loads + cursor: {issue[sel].mean():.0f})")
+    per = (st[1:, 0] - st[:-1, 0])
+    print("stage period (wave 0 top to next top): regular mean", per[(kinds == "reg")[:-1]].mean(),
+          " diagonal by m", [float(per[(dm == m)[:-1]].mean()) for m in range(4)])
+    print("sum of periods: regular", per[(kinds == "reg")[:-1]].sum(), " diagonal", per[(kinds == "diag")[:-1]].sum())
+    # regular stages by position in their block: the first ones after a diagonal phase, the last ones before the next
+    jpos, jend = [], []
+    for i0 in range(0, n, 128):
+        nst_b = i0 // 32
+        jpos += list(range(nst_b)) + [-1] * 4
+        jend += [nst_b - 1 - j for j in range(nst_b)] + [-1] * 4
+    jpos, jend = np.array(jpos[:len(st)])[:-1], np.array(jend[:len(st)])[:-1]
+    big = np.array([i0 >= 1024 for i0 in range(0, n, 128) for _ in range(i0 // 32 + 4)][:len(st)])[:-1]
+    print("regular stage period by position (blocks from row 1024 on): first six",
+          [int(per[big & (jpos == j)].mean()) for j in range(6)], " last six",
+          [int(per[big & (jend == j)].mean()) for j in range(5, -1, -1)], " middle", int(per[big & (jpos >= 6) & (jend >= 6)].mean()))
+    sys.exit(0)
 kinds = []
 for i0 in range(0, n, 128):
     kinds += ["reg"] * (i0 // 32) + ["diag"] * 4

@@ -70,3 +70,16 @@ def test_missing_library_is_an_import_error(tmp_path):
             "try:\n    l.load()\nexcept ImportError as e:\n    print('IMPORTERROR')\n") % str(tmp_path / "nope.so")
     out = subprocess.run(["python", "-c", code], cwd=ROOT, capture_output=True, text=True)
     assert "IMPORTERROR" in out.stdout, out.stderr
+
+
+def test_hand_issued_loads_are_not_touched_before_their_wait():
+    """trsm_strip8_kernel issues the next block's loads by inline asm (the compiler must not count or wait for them);
+    scripts/check_hand_issued_loads.py compiles the file to ISA and verifies that no instruction names a destination
+    register between each of those loads and the block end, where the kernel's own stage-top waits have retired it."""
+    import subprocess
+    import sys
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_hand_issued_loads.py")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
