@@ -17,13 +17,21 @@ traffic inside it is the jitchol status word and the 16-byte winner.
 After the timed region a short instrumented pass (not part of `value`) runs the two-call sequence with
 per-phase hipEvent timers on the library's own stream: it prices the phases and the dominant kernel on its own.
 
-Workloads (weak scaling: fixed work per GPU, the posterior replicated, the grid cut into contiguous blocks):
-  --dtype f64 (default) = BASELINE.json configs[1]: toy_graph box, d=3, 4096 observations, 16384-candidate regular grid
-                (32x32x16) per GPU, fp64.
-  --dtype f32 = BASELINE.json configs[4] at its per-GPU shard shape: coral_graph (N, O, T) ranges, 16384 observations,
-                32768 candidates (32x32x32) per GPU; fp64 fit, fp32 sweep on the f32 MFMA.
+Workloads (--config; every BASELINE.json config has a line):
+  c1 = configs[0]: toy_graph, 50 observations, 200-candidate sweep of each of its 2 exploration sets: one
+       cbo_acq_sweep_sets call factors and sweeps every set in one launch (latency-bound; replicas over ranks).
+  c2 = configs[1] (default, the config `metric` is quoted on): toy_graph box, d=3, 4096 observations, 16384-candidate
+       regular grid (32x32x16), fp64.  Default scaling over ranks: weak (a 16384-candidate grid per GPU, as the metric's
+       "16k grid at 1/2/4/8" has been measured since round 1); --scaling strong cuts the one grid into shards.
+  c3 = configs[2]: complete_graph (B, D, E) ranges, 8192 observations, the fixed 65536-candidate grid (64x32x32) cut into
+       one contiguous shard per rank (strong scaling; RCCL arg-max).
+  c4 = configs[3]: simplified_coral_graph (N, O, T) ranges, 16384 observations, the fixed 262144-candidate grid (64^3)
+       cut into one shard per rank, fp64.  The config is an 8-GPU one: with fewer than 8 ranks each rank still takes a
+       1/8 shard (32768 candidates) unless --full-grid is given; `config.workload` says which.
+  c5 = configs[4]: coral_graph (N, O, T) ranges, as c4 in fp32 (fp64 fit, fp32 sweep on the f32 MFMA).  --dtype f32
+       is the same thing.
 
-usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f64|f32]
+usage: python bench.py [--config c1..c5] [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--full-grid]
        (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...  -- the launcher only
         provides RANK / WORLD_SIZE / LOCAL_RANK; the communicator is RCCL through the C-ABI)
 """
@@ -41,35 +49,55 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-N_OBS = 4096
-GRID_PER_GPU = (32, 32, 16)
-BOX = [(-5.0, 5.0), (-5.0, 20.0), (-5.0, 5.0)]        # toy ranges X, Z (+ a third axis, see graphs.ToyGraph)
 FP64_MFMA_PEAK_TFLOPS = 78.6                           # MI355X fp64 matrix peak (AMD datasheet; = vector peak)
 FP32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X f32-input MFMA peak (MI355X_MICROARCH.md)
-# --dtype f32 = BASELINE.json configs[4] (coral_graph, fp32 path with MFMA) at its per-GPU shard shape: the (N, O, T)
-# exploration set's ranges (/root/reference/src/graphs/impl/CoralGraph.py:177-184), 16384 observations, 256k
-# candidates over 8 GPUs = a 32x32x32 grid per GPU
-N_OBS_F32 = 16384
-GRID_PER_GPU_F32 = (32, 32, 32)
-BOX_F32 = [(-2.0, 5.0), (2.0, 4.0), (2450.0, 2500.0)]
+# BASELINE.json configs[1..4].  Boxes: toy ranges X, Z (+ a third axis, graphs.ToyGraph); the reference's interventional
+# ranges for the others (/root/reference/src/graphs/impl/CompleteGraph.py:106-112, SimplifiedCoralGraph.py:185-192,
+# CoralGraph.py:177-184).  `nominal_gpus`: the GPU count the config is written for -- with fewer ranks each rank still
+# takes 1/nominal of the fixed grid unless --full-grid.
+CONFIGS = {
+    "c2": dict(n_obs=4096, grid=(32, 32, 16), box=[(-5.0, 5.0), (-5.0, 20.0), (-5.0, 5.0)], dtype="f64", scaling="weak",
+               nominal_gpus=1, name="toy_graph box d=3, 4096 obs, 16384-candidate regular grid (BASELINE.json configs[1])",
+               cpu_sample=4096),
+    "c3": dict(n_obs=8192, grid=(64, 32, 32), box=[(-5.0, 4.0), (-5.0, 5.0), (-6.0, 3.0)], dtype="f64", scaling="strong",
+               nominal_gpus=1, name="complete_graph (B, D, E) ranges d=3, 8192 obs, 65536-candidate regular grid 64x32x32 "
+                                    "(BASELINE.json configs[2])", cpu_sample=1024),
+    "c4": dict(n_obs=16384, grid=(64, 64, 64), box=[(-2.0, 5.0), (3.0, 4.0), (2300.0, 2400.0)], dtype="f64",
+               scaling="strong", nominal_gpus=8,
+               name="simplified_coral_graph (N, O, T) ranges d=3, 16384 obs, 262144-candidate regular grid 64^3 "
+                    "(BASELINE.json configs[3])", cpu_sample=128),
+    "c5": dict(n_obs=16384, grid=(64, 64, 64), box=[(-2.0, 5.0), (2.0, 4.0), (2450.0, 2500.0)], dtype="f32",
+               scaling="strong", nominal_gpus=8,
+               name="coral_graph (N, O, T) ranges d=3, 16384 obs, 262144-candidate regular grid 64^3, fp32 sweep "
+                    "(BASELINE.json configs[4])", cpu_sample=128),
+}
 
 
-def make_problem(world, dtype="f64"):
+def make_problem(cfg, world, scaling, full_grid):
+    """(X, y, candidates of the whole job, grid shape, note).  Weak scaling stacks one grid per rank along the last
+    axis; strong scaling keeps the config's grid and the caller cuts it into contiguous shards."""
     from cbo_with_oop_amd.graphs import meshgrid_candidates
-    if dtype == "f32":
-        lo, hi = np.array([b[0] for b in BOX_F32]), np.array([b[1] for b in BOX_F32])
-        X = np.random.default_rng(0).uniform(lo, hi, (N_OBS_F32, 3))
-        u = (X - lo) / (hi - lo)
+    box, n = cfg["box"], cfg["n_obs"]
+    lo, hi = np.array([b[0] for b in box]), np.array([b[1] for b in box])
+    X = np.random.default_rng(0).uniform(lo, hi, (n, 3))
+    u = (X - lo) / (hi - lo)
+    if cfg is CONFIGS["c2"]:
+        y = (np.cos(np.exp(-X[:, 0] / 3)) - np.exp(-X[:, 1] / 20) + 0.3 * np.sin(X[:, 2])
+             + 0.1 * np.random.default_rng(1).standard_normal(n))[:, None]
+    else:
         y = (np.sin(3 * u[:, 0]) + np.cos(2 * u[:, 2]) * u[:, 1]
-             + 0.05 * np.random.default_rng(1).standard_normal(N_OBS_F32))[:, None]
-        grid = (GRID_PER_GPU_F32[0], GRID_PER_GPU_F32[1], GRID_PER_GPU_F32[2] * world)
-        return X, y, meshgrid_candidates(BOX_F32, grid), grid
-    lo, hi = np.array([b[0] for b in BOX]), np.array([b[1] for b in BOX])
-    X = np.random.default_rng(0).uniform(lo, hi, (N_OBS, 3))
-    y = (np.cos(np.exp(-X[:, 0] / 3)) - np.exp(-X[:, 1] / 20) + 0.3 * np.sin(X[:, 2])
-         + 0.1 * np.random.default_rng(1).standard_normal(N_OBS))[:, None]
-    grid = (GRID_PER_GPU[0], GRID_PER_GPU[1], GRID_PER_GPU[2] * world)
-    return X, y, meshgrid_candidates(BOX, grid), grid
+             + 0.05 * np.random.default_rng(1).standard_normal(n))[:, None]
+    g = cfg["grid"]
+    if scaling == "weak":
+        grid = (g[0], g[1], g[2] * world)
+        return X, y, meshgrid_candidates(box, grid), grid, f"one {g[0]}x{g[1]}x{g[2]} grid per GPU"
+    Xs = meshgrid_candidates(box, g)
+    nominal = cfg["nominal_gpus"]
+    if world < nominal and not full_grid:
+        share = Xs.shape[0] // nominal * world
+        return X, y, Xs[:share], g, (f"the first {world}/{nominal} of the fixed {g[0]}x{g[1]}x{g[2]} grid: each rank takes the "
+                                     f"1/{nominal} shard it has in the {nominal}-GPU configuration")
+    return X, y, Xs, g, f"the fixed {g[0]}x{g[1]}x{g[2]} grid cut into {world} contiguous shard(s)"
 
 
 def cpu_baseline(X, y, Xs, y_best, cost, sample):
@@ -91,7 +119,9 @@ def cpu_baseline(X, y, Xs, y_best, cost, sample):
             "kind": "port",
             "sample": f"full fit N={X.shape[0]} ({t_fit:.2f} s) + sweep of the first {sample} of {Xs.shape[0]} "
                       f"candidates scaled x{Xs.shape[0] / sample:.0f} ({t_sweep:.2f} s); numpy/scipy restatement "
-                      f"of the GPy/emukit path (fp64), not GPy itself"}
+                      f"of the GPy/emukit path (fp64), not GPy itself" +
+                      ("; a triangular solve with only this many right-hand sides runs below BLAS-3 speed, so this "
+                       "baseline is understated (a stated baseline, never the target)" if sample < 512 else "")}
 
 
 def kernel_sources_sha():
@@ -112,6 +142,8 @@ def pmc_traffic(section):
     stale and `traffic` is reported as null.  gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled
     (MI355X_MICROARCH.md HBM)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if section is None:
+        return None, "no PMC pass was taken at this config's shape (profiles/pmc_traffic.json covers c2 and the c5 shard)"
     try:
         doc = json.load(open(path))
         d = doc[section]
@@ -123,25 +155,136 @@ def pmc_traffic(section):
         return None, f"no PMC measurement for '{section}' ({type(e).__name__})"
 
 
+def bench_small_sets(args):
+    """--config c1 = BASELINE.json configs[0]: toy_graph, 50 observations and a 200-candidate sweep per exploration set
+    (2 sets).  Step = what CBO.intervene() does per trial at that size (/root/reference/src/CBO.py:152-164): the model of
+    the set intervened on is rebuilt, then ONE cbo_acq_sweep_sets call factors and sweeps every set in one launch, then
+    the set is picked.  Every rank runs the same pass (replicas: two 200-candidate sets are not worth sharding)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from cbo_with_oop_amd import CBOAcquisitionPath, GaussianProcessType, _lib
+    from cbo_with_oop_amd.graphs import ToyGraph, meshgrid_candidates
+    from cbo_with_oop_amd.sharding import Communicator
+    ctx = _lib.Context.get(local_rank % max(1, _lib.device_count()))
+    comm = Communicator.from_env(ctx)
+    steps = args.steps or 2000
+    rng = np.random.default_rng(0)
+    es = ToyGraph.get_exploration_set("MIS")
+    xs = [rng.uniform(-5, 5, (50, 1)), rng.uniform(-5, 20, (50, 1))]
+    ys = [ToyGraph.target_do_x(xs[0]), ToyGraph.target_do_z(xs[1])]
+    path = CBOAcquisitionPath(GaussianProcessType.NON_CAUSAL_GP, es, ToyGraph.get_cost_structure(1), "min", xs, ys,
+                              [ToyGraph.bounds(s) for s in es], grid_shapes=[[200], [200]], comm=None)
+    path.update_all_gaussian_processes()
+    best = min(float(ys[0].min()), float(ys[1].min()))
+    path.last_intervention = 1
+
+    def step():
+        path.update_gaussian_process_of_last_intervention()
+        _, vals = path.compute_best_acquisition_values(best)
+        return path.select_next_intervention(vals), vals
+
+    def fence():
+        if comm is not None:
+            comm.barrier()
+        ctx.synchronize()
+
+    for _ in range(max(5, args.warmup)):
+        choice, vals = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        choice, vals = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if comm is not None:
+        elapsed = comm.max(elapsed)
+    if rank == 0:
+        per = elapsed / steps
+        n_sets, m, n = 2, 200, 50
+        # algorithmic work of a pass: per set, factorisation n^3/3 + substitution n^2 per candidate (fp64 flops)
+        flops = n_sets * (n ** 3 / 3.0 + float(n) ** 2 * m)
+        out = {"metric": "candidate-intervention acquisitions/sec (toy_graph, 50 obs, 200 candidates x 2 sets)",
+               "value": world * n_sets * m / per, "unit": "acquisitions/s", "n_gpus": world, "steps": steps,
+               "warmup": max(5, args.warmup), "ms_per_step": per * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "toy_graph, 50 obs, 200-candidate sweep of each of the 2 exploration sets "
+                                      "(BASELINE.json configs[0]); step = rebuild the intervened set's model + one "
+                                      "cbo_acq_sweep_sets call (every set factored and swept in ONE launch) + pick",
+                          "config": "c1", "n_obs": n, "candidates_total": n_sets * m, "sets": n_sets,
+                          "parallelism": f"replicas x{world} (every rank runs the whole pass)"},
+               "winner": {"set": int(choice[1]), "acq": float(vals[choice[1]][0, 0])},
+               "kernel_sources_sha": kernel_sources_sha(),
+               "roofline": {"kernel": "small_sets_kernel (K, factorisation, K*, substitution, EI, arg-max of a set in one "
+                                      "workgroup per 64 candidates)", "bound": "mfma",
+                            "achieved": flops / per / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": flops / per / 1e12 / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                            "note": "latency-bound by construction: 8 workgroups, 50 dependent pivots per set; the "
+                                    "figure of merit is ms_per_step (host call included)",
+                            "algorithmic_flops_per_step": flops}}
+        if args.cpu_sample is None or args.cpu_sample > 0:
+            from oracle import gp_oracle as O
+            grids = [meshgrid_candidates(ToyGraph.bounds(s), [200]) for s in es]
+            posts = [O.fit(xs[s], ys[s]) for s in range(2)]
+
+            def cpu_pass():
+                posts[1] = O.fit(xs[1], ys[1])
+                v = [O.acquisition_sweep(posts[s], grids[s], best, cost=1.0)[1] for s in range(2)]
+                return O.select_next_intervention([np.array([[a]]) for a in v])
+            for _ in range(5):
+                cpu_pass()
+            reps = 200
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                cpu_choice = cpu_pass()
+            dt = (time.perf_counter() - t0) / reps
+            out["cpu_baseline"] = {"value": n_sets * m / dt, "unit": "acquisitions/s", "cores": 1, "kind": "port",
+                                   "sample": f"the whole pass, {reps} repetitions ({dt * 1e3:.3f} ms each): refit of the "
+                                             f"intervened set + sweep of both sets + pick; numpy/scipy restatement",
+                                   "same_choice": bool(int(cpu_choice) == int(choice[1]))}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if comm is not None:
+        comm.barrier()
+        comm.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20 for f64, 8 for f32)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20 for c2, fewer for the larger configs)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--config", choices=["c1", "c2", "c3", "c4", "c5"], default=None,
+                    help="BASELINE.json config (default c2, the one the metric is quoted on)")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default=None, help="f32 = --config c5")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="over ranks: weak = the config's grid per GPU, strong = the config's one grid cut into shards "
+                         "(default: weak for c2, strong for c3-c5)")
+    ap.add_argument("--full-grid", action="store_true",
+                    help="c4/c5 with fewer than 8 ranks: sweep the whole 262144-candidate grid instead of 1/8 per rank")
     ap.add_argument("--cpu-sample", type=int, default=None,
-                    help="candidates in the CPU-baseline sample (0 = skip; default 4096 for f64, 64 for f32: ~30 s of sweep each\n"
-                         "next to the full CPU fit)")
+                    help="candidates in the CPU-baseline sample (0 = skip; default per config: about 10-30 s of sweep next to\n"
+                         "the full CPU fit)")
     ap.add_argument("--post-steps", type=int, default=3,
                     help="instrumented two-call steps after the timed region (phase timers, isolated kernel; 0 = skip)")
     ap.add_argument("--sequential", action="store_true",
                     help="refit, then sweep (two calls) instead of the one cbo_gp_fit_sweep call")
     args = ap.parse_args()
+    if args.config is None:
+        args.config = "c5" if args.dtype == "f32" else "c2"
+    if args.config == "c1":
+        return bench_small_sets(args)
+    cfg = CONFIGS[args.config]
+    if args.dtype is not None and args.dtype != cfg["dtype"]:
+        sys.exit(f"--config {args.config} is an {cfg['dtype']} workload")
+    args.dtype = cfg["dtype"]
     f32 = args.dtype == "f32"
+    scaling = args.scaling or cfg["scaling"]
     if args.steps is None:
-        args.steps = 8 if f32 else 20
+        args.steps = 20 if args.config == "c2" else (8 if cfg["n_obs"] <= 8192 else 4)
     if args.cpu_sample is None:
-        args.cpu_sample = 64 if f32 else 4096          # the 16384-point fit alone is ~25 s of CPU; keep the sample ~30 s
+        args.cpu_sample = cfg["cpu_sample"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -160,9 +303,9 @@ def main():
     # under a one-process-per-GPU launcher the communicator is always formed (also for one rank, so that the RCCL
     # exchange is exercised on a one-GPU box); a plain `python bench.py` has none
     comm = Communicator.from_env(ctx)
-    X, y, Xs, grid = make_problem(world, args.dtype)
+    X, y, Xs, grid, grid_note = make_problem(cfg, world, scaling, args.full_grid)
     n_obs = X.shape[0]
-    per_gpu = GRID_PER_GPU_F32 if f32 else GRID_PER_GPU
+    per_gpu = cfg["grid"]
     y_best, cost = float(y.min()), 3.0                     # incumbent = best observation; type_cost 1 -> |set| = 3
     begin, end = shard_bounds(Xs.shape[0], world, rank)
 
@@ -224,39 +367,36 @@ def main():
         peak = FP32_MFMA_PEAK_TFLOPS if f32 else FP64_MFMA_PEAK_TFLOPS
         sweep_flops = float(n_sweep) ** 2 * m_rank               # substitution: n^2 flops per candidate column
         chol_flops = float(n_pad) ** 3 / 3.0
+        metric = {"c2": "candidate-intervention acquisitions/sec (16k grid, d=3)",
+                  "c3": "candidate-intervention acquisitions/sec (complete_graph, 8k obs, 64k grid, d=3)",
+                  "c4": "candidate-intervention acquisitions/sec (simplified_coral_graph, 16k obs, 256k grid, d=3)",
+                  "c5": "candidate-intervention acquisitions/sec (coral_graph fp32 path, 16k obs, 256k grid, d=3)"}[args.config]
         out = {
-            "metric": "candidate-intervention acquisitions/sec (16k grid, d=3)",
+            "metric": metric,
             "value": total_cands / (elapsed / args.steps),
             "unit": "acquisitions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
         }
         exchange = (f"RCCL all-gather of (val, idx) over {world} rank(s), inside libcbo_hip.so" if comm is not None
                     else "none (single process)")
-        if f32:
-            out["metric"] = ("candidate-intervention acquisitions/sec (coral_graph fp32 path, 32k-candidate shard of the "
-                             "256k grid, d=3)")
-            out["config"] = {
-                "workload": "coral_graph (N, O, T) ranges, d=3, 16384 obs, 32768-candidate regular grid per GPU = the "
-                            "per-GPU shard of BASELINE.json configs[4] (256k candidates over 8 GPUs); step = fp64 GP refit "
-                            "+ fp32 EI/cost sweep (f32 MFMA) + argmax",
-                "n_obs": n_obs, "candidates_total": int(total_cands), "grid": list(grid),
-                "candidates_per_gpu": int(total_cands // world),
-                "step_mode": "two calls, nothing overlapped" if args.sequential else
-                             "cbo_gp_fit_sweep on an fp32 model: fp64 fit, one down-conversion of the factor, fp32 sweep",
-                "exchange": exchange, "parallelism": f"candidate shards x{world}, replicated posterior"}
+        if args.sequential:
+            step_mode = "two calls, nothing overlapped"
+        elif f32:
+            step_mode = "cbo_gp_fit_sweep on an fp32 model: fp64 fit, one down-conversion of the factor, fp32 sweep"
         else:
-            out["config"] = {
-                "workload": "toy_graph box d=3, 4096 obs, 16384-candidate regular grid per GPU "
-                            "(BASELINE.json configs[1]); step = GP refit + EI/cost sweep + argmax",
-                "n_obs": n_obs, "candidates_total": int(total_cands), "grid": list(grid),
-                "candidates_per_gpu": int(total_cands // world),
-                "step_mode": "two calls, nothing overlapped" if args.sequential else
-                             "cbo_gp_fit_sweep: right-looking sweep pairs under the factorisation (4 streams), "
-                             "left-looking launch for the rest",
-                "exchange": exchange, "parallelism": f"candidate shards x{world}, replicated posterior"}
+            step_mode = ("cbo_gp_fit_sweep: right-looking sweep pairs under the factorisation (4 streams), left-looking "
+                         "launch for the rest (the call does not overlap above 12288 observations)")
+        out["config"] = {
+            "workload": f"{cfg['name']}; {grid_note}; step = " +
+                        ("fp64 GP refit + fp32 EI/cost sweep (f32 MFMA) + argmax" if f32 else
+                         "GP refit + EI/cost sweep + argmax"),
+            "config": args.config, "n_obs": n_obs, "candidates_total": int(total_cands), "grid": list(grid),
+            "candidates_per_gpu": int(-(-total_cands // world)),
+            "step_mode": step_mode, "exchange": exchange,
+            "parallelism": f"candidate shards x{world}, replicated posterior"}
         out["winner"] = {"index": int(winner[1]), "acq": float(winner[0])}
         out["kernel_sources_sha"] = kernel_sources_sha()
         if f32:
@@ -266,7 +406,7 @@ def main():
                 launches = timers["n_trsm_launches"]
                 trsm_ms = timers["ms_trsm"] / launches
                 achieved = timers["trsm_flops"] / launches / (trsm_ms * 1e-3) / 1e12
-                traffic, note = pmc_traffic("f32_strip_kernel")
+                traffic, note = pmc_traffic("f32_strip_kernel" if total_cands // world == 32768 else None)
                 out["roofline"] = {
                     "kernel": "trsm_strip_f32_kernel (V = L^-1 K* on v_mfma_f32_16x16x4_f32, fused sum V^2)",
                     "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -281,11 +421,11 @@ def main():
             # (all fp64-MFMA flops of a step / device time of a step, hipEvents around the K steps).
             step_flops = sweep_flops + chol_flops
             step_tflops = step_flops / (region_ms / args.steps * 1e-3) / 1e12
-            traffic, note = pmc_traffic("step_sequential" if args.sequential else "step")
+            traffic, note = pmc_traffic(("step_sequential" if args.sequential else "step") if args.config == "c2" else None)
             out["roofline"] = {
-                "kernel": "whole step: trsm_update_kernel<16> (dominant) + trsm_strip_kernel<*,16> + "
+                "kernel": "whole step: trsm_update_kernel<16> (dominant) + trsm_strip_kernel<*,16> + trsm_strip8_kernel + "
                           "syrk_kernel<64> + potrf_panel_fused_kernel (diagonal block + row panel), co-scheduled" if not args.sequential else
-                          "whole step: trsm_strip_kernel<true,32> (dominant), then the factorisation's kernels",
+                          "whole step: trsm_strip8_kernel<true> (dominant), then the factorisation's kernels",
                 "bound": "mfma", "achieved": step_tflops, "peak": peak, "unit": "TFLOP/s",
                 "frac": step_tflops / peak, "traffic": traffic, "traffic_source": note,
                 "per": "step", "avg_step_ms_events": region_ms / args.steps,
@@ -294,10 +434,10 @@ def main():
             launches = max(1, timers["n_trsm_launches"])
             trsm_ms = timers["ms_trsm"] / launches
             achieved = timers["trsm_flops"] / launches / (trsm_ms * 1e-3) / 1e12 if trsm_ms > 0 else 0.0
-            traffic, note = pmc_traffic("strip_kernel")
+            traffic, note = pmc_traffic("strip_kernel" if args.config == "c2" else None)
             out["roofline"]["isolated"] = {
-                "kernel": "trsm_strip_kernel<true,32> (V = L^-1 K*, fused sum V^2 and V^T z): the sweep of every set "
-                          "that is not refitted, alone on the device (instrumented pass after the timed region)",
+                "kernel": "trsm_strip8_kernel<true> (V = L^-1 K*, fused sum V^2 and V^T z; two waves per SIMD): the sweep of "
+                          "every set that is not refitted, alone on the device (instrumented pass after the timed region)",
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": traffic, "traffic_source": note,
                 "avg_launch_ms": trsm_ms, "algorithmic_flops_per_launch": timers["trsm_flops"] / launches}
@@ -318,10 +458,10 @@ def main():
                                    "unit": "GB/s", "frac": (kxx_bytes / (kxx_ms * 1e-3) / 1e9 / 8000.0) if kxx_ms > 0 else 0.0,
                                    "avg_launch_ms": kxx_ms, "algorithmic_bytes_per_launch": kxx_bytes,
                                    "note": "fp64 exp per element: ALU-bound below the HBM roof (DESIGN.md 4)"}
-        if world == 1 and args.post_steps > 0 and not f32:
+        if world == 1 and args.post_steps > 0 and args.config == "c2":
             # the north-star's HBM-bound size: K(X,X) assembly for 16384 points (one fit of such a model)
             n16 = 16384
-            lo_box, hi_box = np.array([b[0] for b in BOX]), np.array([b[1] for b in BOX])
+            lo_box, hi_box = np.array([b[0] for b in cfg["box"]]), np.array([b[1] for b in cfg["box"]])
             X16 = np.random.default_rng(2).uniform(lo_box, hi_box, (n16, 3))
             y16 = np.sin(X16).sum(1, keepdims=True)
             m16 = HipGaussianProcess(X16, y16, context=ctx, noise_var=1e-2, fit=False)
@@ -340,7 +480,7 @@ def main():
                                        "avg_launch_ms": t16["ms_kxx"], "algorithmic_bytes_per_launch": b16,
                                        "cholesky_ms": t16["ms_chol"],
                                        "cholesky_tflops": float(n16) ** 3 / 3.0 / (t16["ms_chol"] * 1e-3) / 1e12}
-        if world == 1 and args.post_steps > 0 and not f32:
+        if world == 1 and args.post_steps > 0 and args.config == "c2":
             # what a CBO trial costs once data only grow by one observation (not part of `value`: the timed steps
             # refit from scratch): append one point to a 4000-point model, then sweep the same 16384-candidate grid
             n0 = 4000

@@ -67,6 +67,11 @@ __device__ unsigned long long g_trsm_stamps[8 * 4096];
         __builtin_amdgcn_sched_barrier(0);                                                   \
     } while (0)
 #define STAMP_NEXT() do { if (stamp_on) ++stamp_i; } while (0)
+__device__ unsigned long long g_trsm_fine[4 * 16];      // [diagonal stage][point] of one block, solver wave of column group 0
+extern "C" int cbo_diag_trsm_fine(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trsm_fine), sizeof(unsigned long long) * 4 * 16);
+}
 extern "C" int cbo_diag_trsm_stamps(unsigned long long *out, int n)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trsm_stamps), sizeof(unsigned long long) * (size_t)n);   // 8 per stage
@@ -579,6 +584,12 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
         }
     };
 
+    // block 0 has no regular stage to spread block 1's ahead loads over: they go first, ahead of the whole DMA stream
+    // (the first stage top retires them)
+    if (!(dmask & 2)) {
+#pragma unroll
+        for (int sl = 0; sl < kAhead; ++sl) request_one(0, sl);
+    }
     locate_a(ahead);
     locate_b(ahead);
     locate_c(ahead);
@@ -599,8 +610,16 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
         if (stamp_on && stamp_i < 4096) g_trsm_stamps[8 * stamp_i + stamp_base + (slot)] = __builtin_amdgcn_s_memtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                              \
     } while (0)
+#define FINE(pt)                                                                                        \
+    do {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if ((dmask & 512) && blockIdx.x == 0 && lane == 0 && cw == 0 && i0 == 2048)                     \
+            g_trsm_fine[16 * m + (pt)] = __builtin_amdgcn_s_memtime();                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+    } while (0)
 #else
 #define STAMP8(slot)
+#define FINE(pt)
 #endif
     double qacc = 0.0, macc = 0.0, qtot = 0.0, mtot = 0.0;       // totals live in the h = 1 waves
     if (SWEEP && accumulate && h == 1) {
@@ -611,8 +630,8 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
     // Stage-top wait.  This wave's DMA of stage k (issued during stage k-2) has landed once only what is younger than its
     // LAST instruction may still be in flight (vmcnt retires in order): what stage k-2 issued after its DMA (a2), and all
     // of stage k-1 -- what it issued before or among its DMA instructions (b1), the DMA (kDma8), what it issued after
-    // (a1).  "After" are the solver's V stores of a diagonal stage and, in block 0, the hand-issued loads for block 1;
-    // "before" are the hand-issued loads for the next block, spread over the first regular stage of every later block.
+    // (a1).  "After" are the solver's V stores of a diagonal stage; "before" are the
+    // hand-issued loads for the next block, spread over the first regular stage of a block.
     int a1 = 0, b1 = 0, a2 = 0;
     auto wait_top = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -706,6 +725,7 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
             STAGE8_TOP();
             STAMP8(1);
             const int hs = m >> 1;                            // the solving half
+            if (h == hs) FINE(0);
             const int ls = kDT * (m & 1);                     // its first tile of the stage, as an index into acc[]
             const bool solver = (h == hs);
             if (SWEEP && solver && (m == 2 || (m == 0 && ((i0 / kRB) & 1)))) {     // take over the running lane partials
@@ -713,41 +733,50 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
                 macc = hand[1];
             }
             const int bnext = (buf >= 1) ? buf - 1 : 2;
-            issue_stage(ahead, bnext);
-            if (m == 0 && i0 == 0 && !(dmask & 2)) {                // block 0 has no regular stage to spread them over
-#pragma unroll
-                for (int sl = 0; sl < kAhead; ++sl) request_one(0, sl);
-                a1 += kAhead;
-            }
-            advance(ahead);
-            STAMP8(3);
+            // the stage's DMA issue and cursor arithmetic: placed where the wave would otherwise wait (behind the first
+            // MFMAs of the solve, ahead of the lower half's rendezvous), always ahead of the stage's V stores
+            auto stage_dma = [&]() __attribute__((always_inline)) {
+                issue_stage(ahead, bnext);
+                advance(ahead);
+                STAMP8(3);
+            };
             const double *abase0 = lds + buf * kABuf + kq * kLdsLd + lc;          // U tile of the stage, all 128 columns
             double *xreg = ldsB + buf * kBBuf + cw * (KB * 16);                   // inverses in, solved tiles out
             if (dmask & 1) {
+                stage_dma();
                 if (hs == 0) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_s_barrier();
                 }
             } else if (solver) {
                 double iv[kDT][4], uf[kDT][kTH][4], zr[kDT][4];
-                if (SWEEP) {
-                    const double *zrow = zl + ((i0 / kRB) & 1) * kRB + KB * m + kq;
+                // the first tile's inverse first: its solve starts as soon as these four values are in; every other LDS
+                // operand of the stage is requested behind the solve's first MFMAs
 #pragma unroll
-                    for (int hh = 0; hh < kDT; ++hh)
+                for (int kk = 0; kk < 4; ++kk) iv[0][kk] = xreg[(4 * kk + kq) * 16 + lc];
+                auto fetch_rest = [&]() __attribute__((always_inline)) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) zr[hh][r] = zrow[16 * hh + 4 * r];
-                }
+                    for (int hh = 0; hh < kDT; ++hh) {
+                        if (hh > 0) {
 #pragma unroll
-                for (int hh = 0; hh < kDT; ++hh) {
+                            for (int kk = 0; kk < 4; ++kk) iv[hh][kk] = xreg[hh * 256 + (4 * kk + kq) * 16 + lc];
+                        }
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) iv[hh][kk] = xreg[hh * 256 + (4 * kk + kq) * 16 + lc];
+                        for (int t = ls + hh + 1; t < kTH; ++t)
 #pragma unroll
-                    for (int t = ls + hh + 1; t < kTH; ++t)
+                            for (int kk = 0; kk < 4; ++kk)
+                                uf[hh][t][kk] = abase0[(16 * hh + 4 * kk) * kLdsLd + 16 * (kTH * hs + t)];
+                    }
+                    if (SWEEP) {
+                        const double *zrow = zl + ((i0 / kRB) & 1) * kRB + KB * m + kq;
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk)
-                            uf[hh][t][kk] = abase0[(16 * hh + 4 * kk) * kLdsLd + 16 * (kTH * hs + t)];
-                }
-                asm volatile("" ::: "memory");
+                        for (int hh = 0; hh < kDT; ++hh)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) zr[hh][r] = zrow[16 * hh + 4 * r];
+                    }
+                };
+                FINE(1);
                 auto emit = [&](int hh, int s, const d4 &x) __attribute__((always_inline)) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -770,12 +799,35 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
                 x2 = MFMA_F64(iv[0][1], -acc[ls][1], x2);
                 x = MFMA_F64(iv[0][2], -acc[ls][2], x);
                 x2 = MFMA_F64(iv[0][3], -acc[ls][3], x2);
+                __builtin_amdgcn_sched_barrier(0);
+                FINE(2);
+                fetch_rest();                                             // under the four MFMAs in flight
+                __builtin_amdgcn_sched_barrier(0);
+                FINE(3);
                 x += x2;
-                if (hs == 0) publish(0, x);
+                asm volatile("" : "+v"(x));
+                FINE(4);
+                if (hs == 0) {
+                    publish(0, x);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                         // the lower half may read x now
+                }
+                FINE(5);
+                // the update of the next tile is a chain of four dependent MFMAs: the stage's DMA issue and cursor
+                // arithmetic sit in its gaps (and ahead of the stage's V stores, as the stage-top accounting assumes)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     acc[ls + 1] = MFMA_F64(uf[0][ls + 1][kk], x[kk], acc[ls + 1]);
                     if (ls + 2 < kTH) acc[ls + 2] = MFMA_F64(uf[0][ls + 2][kk], x[kk], acc[ls + 2]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kk < 3) {
+                        issue_one(ahead, bnext, 2 * kk);
+                        issue_one(ahead, bnext, 2 * kk + 1);
+                    } else {
+                        advance(ahead);
+                        STAMP8(3);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 emit(0, s, x);
                 const d4 na = -acc[ls + 1];
@@ -787,18 +839,22 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
 #pragma unroll
                     for (int t = ls + 3; t < kTH; ++t) acc[t] = MFMA_F64(uf[0][t][kk], x[kk], acc[t]);
                 }
-                const d4 y = y1 + y2;
+                d4 y = y1 + y2;
+                asm volatile("" : "+v"(y));
+                FINE(6);
                 if (hs == 0) {
                     publish(1, y);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();                         // the lower half may read x, y now
+                    __builtin_amdgcn_s_barrier();                         // ... and y
                 }
+                FINE(7);
                 emit(1, s + 1, y);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
                     for (int t = ls + 2; t < kTH; ++t) acc[t] = MFMA_F64(uf[1][t][kk], y[kk], acc[t]);
                 }
+                FINE(8);
                 if (!(dmask & 4)) a1 += kSolverStores;
                 if (SWEEP && (m & 1)) {                                   // done with this half's tiles: hand over
                     if (hs == 0) {
@@ -821,8 +877,8 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
                     }
                 }
             } else if (hs == 0) {
-                // lower half while the upper half solves: its U fragments against the two tiles first, then -- once the
-                // solver has published them -- the 32 MFMAs
+                // lower half while the upper half solves: its U fragments against the two tiles first, then -- as the
+                // solver publishes them -- 16 MFMAs per tile
                 double uf[kDT][kTH][4], xb[kDT][4];
 #pragma unroll
                 for (int hh = 0; hh < kDT; ++hh)
@@ -831,18 +887,20 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk)
                             uf[hh][t][kk] = abase0[(16 * hh + 4 * kk) * kLdsLd + 16 * (kTH + t)];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+                stage_dma();
 #pragma unroll
-                for (int hh = 0; hh < kDT; ++hh)
+                for (int hh = 0; hh < kDT; ++hh) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                         // tile hh of the stage is published
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) xb[hh][kk] = xreg[hh * 256 + (4 * kk + kq) * 16 + lc];
-#pragma unroll
-                for (int hh = 0; hh < kDT; ++hh)
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                         for (int t = 0; t < kTH; ++t) acc[t] = MFMA_F64(uf[hh][t][kk], xb[hh][kk], acc[t]);
+                }
+            } else {
+                stage_dma();                                              // upper half, nothing left to solve in this block
             }
             STAMP8(2);
             STAMP_NEXT();
@@ -863,6 +921,7 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
     }
 #undef STAGE8_TOP
 #undef STAMP8
+#undef FINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the clamped tail DMA before the LDS goes away
     __builtin_amdgcn_s_barrier();
 

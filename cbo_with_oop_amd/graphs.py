@@ -109,8 +109,11 @@ class CoralGraph(_Graph):
 
 
 class SimplifiedCoralGraph(CoralGraph):
-    """src/graphs/impl/SimplifiedCoralGraph.py:185-192 (same variables and ranges as CoralGraph)."""
+    """src/graphs/impl/SimplifiedCoralGraph.py:185-192: CoralGraph's variables and exploration sets, its own (narrower)
+    interventional ranges."""
     name = "simplified_coral_graph"
+    _ranges = OrderedDict([("N", (-2, 5)), ("O", (3, 4)), ("C", (0.3, 0.4)), ("T", (2300, 2400)),
+                           ("D", (2000, 2080))])
 
 
 class ToyGraph(_Graph):

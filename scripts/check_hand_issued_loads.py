@@ -19,45 +19,55 @@ def registers(text):
 
 
 def check(asm_text):
+    """Every instruction that names a destination register of a hand-issued load must be a hand-issued load itself or
+    come after the kernel's pin (an empty inline-asm statement, which the source places behind the stage-top wait that
+    retires the loads) within its basic block.  Those registers stay live from the loads at kernel start to the kernel's
+    end, so any other mention is a copy or a reuse the loads would race with.  Code ahead of the first such load in the
+    listing (the entry block) is exempt."""
     problems, checked = [], 0
     kernels = re.split(r"\n(?=_ZN3cbo18trsm_strip8_kernel\S*:)", asm_text)[1:]
     for body in kernels:
         name = body.split(":", 1)[0]
         raw = body.split("\n")
-        lines = [l.split(";")[0].rstrip() for l in raw]
-        end = next(i for i, l in enumerate(lines) if "s_endpgm" in l)
-        lines = lines[:end + 1]
-        in_asm, hand = False, set()                       # inline asm is bracketed by ;;#ASMSTART / ;;#ASMEND
-        for i, l in enumerate(raw[:end + 1]):
+        end = next(i for i, l in enumerate(raw) if "s_endpgm" in l)
+        raw = raw[:end + 1]
+        code = [l.split(";")[0].rstrip() for l in raw]
+        in_asm, asm_lines, pins = False, set(), set()      # inline asm is bracketed by ;;#ASMSTART / ;;#ASMEND
+        start = None
+        for i, l in enumerate(raw):
             if "#ASMSTART" in l:
-                in_asm = True
+                in_asm, start = True, i
             elif "#ASMEND" in l:
                 in_asm = False
+                if i == start + 1:
+                    pins.add(i)                            # empty statement: a pin
             elif in_asm:
-                hand.add(i)
-        # the hand-issued loads: "global_load_dwordx2/x4 vDST, v[ADDR], off" inside an inline-asm bracket
-        for i, l in enumerate(lines):
-            m = re.match(r"\s*global_load_dwordx([24]) (v\[\d+:\d+\]), (v\[\d+:\d+\]), off\s*$", l)
-            if not m or i not in hand:
+                asm_lines.add(i)
+        loads = [i for i in sorted(asm_lines) if re.match(r"\s*global_load_dwordx[24] v", code[i])]
+        if not loads:
+            problems.append(f"{name}: no hand-issued loads found")
+            continue
+        dst = set()
+        for i in loads:
+            dst |= registers(code[i].split(",")[0])
+        checked += len(loads)
+        for i in range(loads[0] + 1, len(code)):
+            t = code[i].strip()
+            if i in loads or not t or t.startswith(".") or t.endswith(":") or not (registers(t) & dst):
                 continue
-            dst = registers(m.group(2))
-            # walk forward (straight-line order of the listing) to the first instruction that names a destination register
-            for j in range(i + 1, len(lines)):
-                t = lines[j].strip()
-                if not t or t.startswith(".") or t.endswith(":"):
-                    continue
-                if t.startswith("global_load_dword") and registers(t.split(",")[0]) & dst:
-                    checked += 1                          # untouched up to the next load site of the same register
+            # back towards the start of the straight-line code this instruction is reached through
+            ok = False
+            for b in range(i - 1, -1, -1):
+                tb = code[b].strip()
+                if b in pins:
+                    ok = True
                     break
-                if registers(t) & dst:
-                    checked += 1
-                    # legitimate first uses: after the kernel's own stage-top waits, at the block end
-                    window = [x for x in lines[i + 1:j] if "s_barrier" in x]
-                    waited = any("vmcnt" in x for x in lines[i + 1:j])
-                    if not waited or len(window) < 1:
-                        problems.append(f"{name}: line {j}: '{t}' touches {sorted(registers(t) & dst)} loaded at line {i} "
-                                        f"with no stage-top wait in between")
-                    break
+                if tb.endswith(":") or tb.startswith("s_branch") or tb.startswith("s_setpc"):
+                    break                                  # (a conditional branch is passed: the fall-through block has
+                                                           #  no label, its only predecessor is the code above it)
+            if not ok:
+                problems.append(f"{name}: line {i}: '{t}' names {sorted(registers(t) & dst)}, a register of a hand-issued "
+                                f"load, with no pin before it in its basic block")
     return checked, problems
 
 

@@ -88,6 +88,80 @@ __global__ __launch_bounds__((MODE & 8) ? 512 : 256) void probe(const double *sr
     if (blockIdx.x == 0 && tid == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
 }
 
+// Two independent workgroups per CU (own barriers, own LDS rings of 16-row stages): 4 waves x 4 row tiles each, 32-column
+// strips.  What the sweep could do at M = 16384 instead of one 8-wave workgroup per CU.
+constexpr int kA2 = 16 * kLd, kB2 = 2 * 16 * 16;
+__global__ __launch_bounds__(256) void probe2(const double *src, int64_t ld, double *out, int stages, int skew)
+{
+    __shared__ __align__(16) double lds[3 * (kA2 + kB2)];          // 67,584 B: two workgroups share a CU
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, kq = lane >> 4, half = wave >> 1, cw = wave & 1;
+    for (int i = tid; i < 3 * (kA2 + kB2); i += blockDim.x) lds[i] = 1e-3 * (i & 63);
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr_t)lds;
+    d4 acc[4];
+    for (int t = 0; t < 4; ++t) acc[t] = d4{0, 0, 0, 0};
+    double af[2][4], bf[2];
+    for (int t = 0; t < 4; ++t) af[0][t] = af[1][t] = 1.0 + 1e-9 * lane;
+    bf[0] = bf[1] = 0.5;
+    const double *g = src + (int64_t)(blockIdx.x & 7) * 64 * ld + lane * 2;
+    int buf = 0;
+    if (skew && (blockIdx.x & 1)) __builtin_amdgcn_s_sleep(100);    // start the two workgroups of a CU out of phase
+    for (int s = 0; s < stages; ++s) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        FENCE();
+        const int bnext = (buf >= 1) ? buf - 1 : 2;
+        const double *abase = lds + buf * kA2 + kq * kLd + lc + 64 * half;
+        const double *bbase = lds + 3 * kA2 + buf * kB2 + cw * 256 + kq * 16 + lc;
+        const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + 8u * (unsigned)(bnext * kA2 + wave * 4 * kLd));
+        const double *gs = g + (int64_t)((s & 31) * 16 + wave * 4) * ld;
+        int dma = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const double *an = abase + 4 * ((jj + 1) & 3) * kLd;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[t] = MFMA(af[jj & 1][t], bf[jj & 1], acc[t]);
+                if (t < 2) {
+                    af[(jj + 1) & 1][2 * t] = an[32 * t];
+                    af[(jj + 1) & 1][2 * t + 1] = an[32 * t + 16];
+                } else if (t == 2) {
+                    bf[(jj + 1) & 1] = bbase[4 * ((jj + 1) & 3) * 16];
+                }
+                if (t >= 2 && dma < 5) {
+                    glds16(gs + (int64_t)(dma & 3) * ld, la + 8u * (unsigned)((dma & 3) * kLd));
+                    ++dma;
+                }
+                FENCE();
+            }
+        }
+        buf = (buf == 2) ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    double sum = 0;
+    for (int t = 0; t < 4; ++t) sum += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+    out[(int64_t)blockIdx.x * blockDim.x + tid] = sum + lds[tid];
+}
+
+void run2(const char *name, const double *src, int64_t ld, double *out, int skew)
+{
+    const int stages = 4000, blocks = 512;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(probe2, dim3(blocks), dim3(256), 0, 0, src, ld, out, 20, skew);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(probe2, dim3(blocks), dim3(256), 0, 0, src, ld, out, stages, skew);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)blocks * 4 * stages * 16 * 2048;
+    printf("%-58s %.3f ms  %.1f TF\n", name, ms, flops / ms / 1e9);
+}
+
 template <int MODE>
 void run(const char *name, const double *src, int64_t ld, double *out, unsigned long long *clk)
 {
@@ -129,5 +203,7 @@ int main()
     run<11>("8 waves + LDS reads + DMA", src, ld, out, clk);
     run<13>("8 waves + LDS reads + barrier", src, ld, out, clk);
     run<15>("8 waves + LDS reads + DMA + barrier", src, ld, out, clk);
+    run2("2 workgroups/CU x 4 waves, 16-row stages, everything", src, ld, out, 0);
+    run2("  the same, the two workgroups started out of phase", src, ld, out, 1);
     return 0;
 }
