@@ -78,6 +78,7 @@ struct cbo_ctx {
     bool pipe_half_lds = true;
     double pipe_tail_frac = -1.0;    // CBO_HIP_PIPE_TAIL: rows (fraction) left to the closing left-looking launch; < 0 = automatic
     int n_cu = 256;
+    int64_t fused_fallbacks = 0;     // factorisations repeated with separate launches after a fused launch gave up
     bool sweep_cache = true;         // CBO_HIP_SWEEP_CACHE=0: never reuse a candidate set's q, mu between sweeps
     bool small_sets = true;          // CBO_HIP_SMALL_SETS=0: cbo_acq_sweep_sets always takes the general path
     int sweep_mode = -1;             // CBO_HIP_SWEEP: 0 = always left-looking, 1 = always right-looking, else automatic
@@ -646,6 +647,19 @@ static void enqueue_factor(cbo_gp *g, double jitter)
     }
 }
 
+// Scope of a factorisation's repeat with the separate-launch kernels after a fused launch gave up (kCholFusedTimeout).
+struct FusedFallback {
+    bool on = false;
+    bool active() const { return on; }
+    void engage(cbo_ctx *c)
+    {
+        on = true;
+        ++c->fused_fallbacks;
+        set_panel_form_override(2);
+    }
+    ~FusedFallback() { if (on) set_panel_form_override(0); }
+};
+
 // GPy util.linalg.jitchol after a failed attempt: first mean(diag) * 1e-6, then x10 per retry, at most 5 retries.
 static int next_jitter(cbo_gp *g, int *tries, double *jitter)
 {
@@ -681,13 +695,21 @@ extern "C" int cbo_gp_fit(cbo_gp *g, int *tries_out, double *jitter_out)
     // GPy util.linalg.jitchol: plain attempt, then mean(diag)*1e-6 jitter, x10 per retry, <= 5 retries.
     double jitter = 0.0;
     int tries = 0;
+    FusedFallback fallback;
     for (;;) {
         enqueue_factor(g, jitter);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(c->h_info, g->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (*c->h_info == 0) break;
-        if (*c->h_info == kCholFusedTimeout) return fail(CBO_ERR_HIP, "a fused diagonal + panel launch gave up waiting");
+        if (*c->h_info == kCholFusedTimeout) {
+            // a strip of a fused diagonal + panel launch gave up waiting (see potrf_panel_fused_kernel): the same
+            // attempt again with the separate-launch kernels -- same bits, no protocol between workgroups
+            if (fallback.active())
+                return fail(CBO_ERR_HIP, "a fused diagonal + panel launch gave up waiting, and so did the separate-launch repeat");
+            fallback.engage(c);
+            continue;
+        }
         const int rc = next_jitter(g, &tries, &jitter);
         if (rc != CBO_OK) return rc;
     }
@@ -1405,6 +1427,7 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
     if (pipe.tail_begin > (int)g->n_pad) pipe.tail_begin = (int)g->n_pad;
     double jitter = 0.0;
     int tries = 0;
+    FusedFallback fallback;
     for (;;) {
         // fork: the sweep stream starts after what is queued on the main stream (candidate preparation)
         HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
@@ -1449,7 +1472,12 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
         HIP_TRY(hipMemcpyAsync(c->h_info, g->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (*c->h_info == 0) break;
-        if (*c->h_info == kCholFusedTimeout) return fail(CBO_ERR_HIP, "a fused diagonal + panel launch gave up waiting");
+        if (*c->h_info == kCholFusedTimeout) {                 // as in cbo_gp_fit: the attempt again, separate launches
+            if (fallback.active())
+                return fail(CBO_ERR_HIP, "a fused diagonal + panel launch gave up waiting, and so did the separate-launch repeat");
+            fallback.engage(c);
+            continue;
+        }
         rc = next_jitter(g, &tries, &jitter);
         if (rc != CBO_OK) return rc;
     }

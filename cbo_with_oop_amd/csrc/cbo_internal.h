@@ -136,6 +136,8 @@ constexpr int kCholFlagSlots = 1024;
 constexpr int kCholFusedTimeout = -2147483647 - 1;     // status word when a strip of a fused launch gave up waiting
 void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &events, double *A, int64_t lda,
                      int64_t n_pad, double *invDt, int *info_dev, const SweepPipe *pipe = nullptr);
+// > 0: launch_cholesky of this thread uses that panel form (CBO_HIP_PANEL_FORM's values) whatever the environment says
+void set_panel_form_override(int form);
 // pair p of the pipelined sweep: rows [r0, r0 + klen) of the factor are final on stream `chain`
 void sweep_pipe_pair(const SweepPipe &pipe, hipStream_t chain, const double *A, int64_t lda, const double *invDt,
                      int64_t n_pad, int p, int r0, int klen);

@@ -445,6 +445,19 @@ extern "C" int cbo_diag_small_stamps(unsigned long long *out)
 
 // A store of the factor that a workgroup of the SAME launch may read (the strips of the fused diagonal + panel launch):
 // written through to the coherence point of the device instead of resting in this XCD's L2.
+// Fences of the fused diagonal + panel protocol (see potrf_panel_fused_kernel).  The consumer's ACQUIRE is always there
+// (1-2 % of the chain).  The producer's RELEASE is a build option: LLVM implements an agent-scope release on gfx950 as
+// buffer_wbl2 sc1 -- a write-back of the whole XCD's L2, which at that moment also holds the dirty lines of the bulk
+// trailing update running beside the chain -- and it costs 17 % of the factorisation at 4096 points (1.55 -> 1.82 ms;
+// 31.9 -> 33.8 ms at 16384; A/B on one box, round 3).  The default producer instead relies on what its stores are on
+// this hardware: agent-scope atomic stores (global_store ... sc1, written through to the device's coherence point),
+// retired by s_waitcnt vmcnt(0) before the count is incremented.  -DCBO_FORMAL_RELEASE restores the fence.
+#ifdef CBO_FORMAL_RELEASE
+#define AGENT_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#else
+#define AGENT_RELEASE()
+#endif
+#define AGENT_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 template <bool PUBLISH>
 __device__ __forceinline__ void gstore(double *p, double v)
 {
@@ -526,6 +539,7 @@ __device__ __forceinline__ void diag_worker(Diag2Shared &sh, double *A, int64_t 
     if (PUBLISH && W == jb % 3) {
         // tile jb's inverse (and diagonal factor) are out: flag[1] counts them.  The wait overlaps the rendezvous.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        AGENT_RELEASE();                                       // the count is a release of this wave's stores
         if (lane == 0) __hip_atomic_fetch_add(flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     while (__hip_atomic_load(&sh.xcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 3 * (jb + 1))
@@ -554,6 +568,7 @@ __device__ __forceinline__ void diag_worker(Diag2Shared &sh, double *A, int64_t 
     DSTAMP(W + 1, jb, 3);
     if (PUBLISH) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have arrived
+        AGENT_RELEASE();
         if (lane == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -758,11 +773,25 @@ __global__ __launch_bounds__(256) void panel_trsm_kernel(double *A, int64_t lda,
 // operand registers: no LDS, no barrier, the four waves are independent), x_s = inv(L_ss) r_s, fold it into the
 // tiles below.  The panel solve thus hides behind the 128 pivots of the block; what is left after the block's last
 // interval is one round trip and a sixteenth of the work.  Same chains as panel_solve_tiles: same bits.
-// Forward progress: workgroup 0 never waits for a strip, and a dispatch hands out workgroups in order, so it runs
-// before any strip spins; the spin is bounded all the same (kFusedSpinLimit polls, then the status word reports
-// kFusedTimeout and the launch drains).
+// Ordering.  Producer, per interval: write-through stores (agent-scope atomic stores: global_store sc1, performed at the
+// device's coherence point), s_waitcnt vmcnt(0) (they have been performed), [a RELEASE fence at agent scope when built
+// with -DCBO_FORMAL_RELEASE], the relaxed increment of the interval's count.  Consumer: relaxed polls of the counts;
+// once a count covers what it needs, an ACQUIRE fence at agent scope, then its loads of that data (agent-scope atomic
+// loads: never served from a stale line of this XCD's L2).  With the release fence, count increment and poll form the
+// synchronises-with edge and the two fences extend it to the data: every store a wave made before counting itself in
+// happens-before every load a strip makes after seeing that count -- the language-level argument.  Without it (the
+// default, see AGENT_RELEASE above for what the fence costs) the producer side is a hardware-level argument: the
+// stores were complete at the coherence point before the increment was issued, and the consumer's loads go to that
+// same point, after its acquire.  The count invariant: a worker wave counts itself in once per interval after ALL its
+// stores of the interval, and row tile s needs the three workers' interval-s stores, so "count >= 3 (s + 1)" means
+// row tile s is complete (the inverse of diagonal tile s is one wave's store: its own count, flag[1]).
+// Forward progress rests on an assumption about the hardware, not on the language: a dispatch hands out workgroups in
+// order of their index and workgroup 0 never waits for a strip, so workgroup 0 is resident and running before any
+// strip can spin.  The spin is bounded all the same (`spin_limit` polls, then the status word reports kFusedTimeout,
+// the launch and everything after it in the factorisation drains) and the host then repeats the factorisation with the
+// separate-launch kernels (CBO_HIP_PANEL_FORM=2's), same bits: cbo_gp_fit / cbo_gp_fit_sweep.
 constexpr int kFusedTimeout = kCholFusedTimeout;
-constexpr int kFusedSpinLimit = 1 << 22;
+constexpr int kFusedSpinLimit = 1 << 22;      // default of CBO_HIP_FUSED_SPIN_LIMIT (negative: give up at the first wait)
 
 __device__ __forceinline__ double coherent_load(const double *p)
 {
@@ -771,7 +800,8 @@ __device__ __forceinline__ double coherent_load(const double *p)
 
 __global__ __launch_bounds__(256) void potrf_panel_fused_kernel(double *A, int64_t lda, int r0, int rcol,
                                                                 double *__restrict__ invDt, int *info,
-                                                                double *__restrict__ zvec, int col0, int *flag)
+                                                                double *__restrict__ zvec, int col0, int *flag,
+                                                                int spin_limit)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x;
@@ -815,18 +845,25 @@ __global__ __launch_bounds__(256) void potrf_panel_fused_kernel(double *A, int64
     // one poll refreshes both counts (the two words share a cache line: one round trip)
     auto wait_for = [&](bool want_row, int s) -> bool {
         int spins = 0;
+        if (spin_limit < 0) {                                            // test hook: every strip gives up at once
+            if (lane == 0) atomicCAS(info, 0, kFusedTimeout);
+            return false;
+        }
+        const bool polled = (want_row ? rows_seen : invs_seen) <= s;
         while ((want_row ? rows_seen : invs_seen) <= s) {
             const int f0 = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int f1 = __hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             rows_seen = f0 / 3;
             invs_seen = f1;
             if ((want_row ? rows_seen : invs_seen) > s) break;
-            if (++spins > kFusedSpinLimit || __builtin_nontemporal_load(info) != 0) {
-                if (spins > kFusedSpinLimit && lane == 0) atomicCAS(info, 0, kFusedTimeout);
+            if (++spins > spin_limit || __builtin_nontemporal_load(info) != 0) {
+                if (spins > spin_limit && lane == 0) atomicCAS(info, 0, kFusedTimeout);
                 return false;                                            // uniform: every lane read the same words
             }
             __builtin_amdgcn_s_sleep(2);
         }
+        // what the counts cover is visible to the loads that follow (pairs with the producer's release fences)
+        if (polled) AGENT_ACQUIRE();
         return true;
     };
 #pragma unroll
@@ -869,11 +906,16 @@ __global__ __launch_bounds__(256) void potrf_panel_fused_kernel(double *A, int64
 }
 
 void launch_panel_fused(hipStream_t s, double *A, int64_t lda, int r0, int rcol, double *invDt, int *info, double *zvec,
-                        int n_cols, int *flag, hipEvent_t done = nullptr)
+                        int n_cols, int *flag, int spin_limit, hipEvent_t done = nullptr)
 {
     hipExtLaunchKernelGGL(potrf_panel_fused_kernel, dim3(1u + (unsigned)(n_cols / kStrip)), dim3(256), sizeof(Diag2Shared),
-                          s, nullptr, done, 0, A, lda, r0, rcol, invDt, info, zvec, r0 + 128, flag);
+                          s, nullptr, done, 0, A, lda, r0, rcol, invDt, info, zvec, r0 + 128, flag, spin_limit);
 }
+
+// Set by the host around the repeat of a factorisation whose fused launch gave up (kCholFusedTimeout): the repeat uses
+// the separate-launch kernels whatever CBO_HIP_PANEL_FORM says.
+thread_local int g_panel_form_override = 0;
+void set_panel_form_override(int form) { g_panel_form_override = form; }
 
 void launch_panel_trsm(hipStream_t s, double *A, int64_t lda, int r0, int col0, int n_cols, const double *invDt,
                        const int *skip_if, hipEvent_t done = nullptr)
@@ -1684,7 +1726,10 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
                         (int)sizeof(Diag2Shared));
     // 4: diagonal block + row panel in one launch; 2: separate launches (lean panel kernel, beside a pipelined sweep the
     // half-LDS strip kernel); 3: the lean panel kernel also beside a pipelined sweep; 1: the strip kernel as panel solver
-    static const int panel_form = [] { const char *e = std::getenv("CBO_HIP_PANEL_FORM"); return e ? std::atoi(e) : 4; }();
+    static const int panel_form_env = [] { const char *e = std::getenv("CBO_HIP_PANEL_FORM"); return e ? std::atoi(e) : 4; }();
+    const int panel_form = g_panel_form_override > 0 ? g_panel_form_override : panel_form_env;
+    // polls a strip of a fused launch makes before it gives up (read per factorisation: a test sets it to -1)
+    const int spin_limit = [] { const char *e = std::getenv("CBO_HIP_FUSED_SPIN_LIMIT"); return e ? std::atoi(e) : kFusedSpinLimit; }();
     static const int syrk_gemm_rows = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_ROWS"); return e ? std::atoi(e) : 6144; }();
     static const int syrk_gemm_chunk = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_CHUNK"); return e ? std::atoi(e) : 1; }();
     static const bool syrk_gemm_half = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_KB"); return !(e && std::atoi(e) == 32); }();
@@ -1740,7 +1785,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     for (int k = 0; k < np; k += 2) {
         const int r0 = 128 * k;
         const int n2 = (int)n_pad - r0 - 128;
-        if (fused && n2 > 0) launch_panel_fused(s, A, lda, r0, rcol, invDt, info_dev, zvec, n2, flags + 2 * (r0 / 128));
+        if (fused && n2 > 0) launch_panel_fused(s, A, lda, r0, rcol, invDt, info_dev, zvec, n2, flags + 2 * (r0 / 128), spin_limit);
         else launch_diag(r0);
         if (n2 <= 0) { sweep_rows(r0, 128); break; }
         if (fused) {}
@@ -1760,7 +1805,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         const hipEvent_t ev_panel = (carried && gemm_form) ? events[2 * k] : nullptr;
         const hipEvent_t ev_rows = (carried && !gemm_form) ? events[2 * k] : nullptr;
         if (fused && n3 > 0)
-            launch_panel_fused(s, A, lda, r1, rcol, invDt, info_dev, zvec, n3, flags + 2 * (r1 / 128), ev_panel);
+            launch_panel_fused(s, A, lda, r1, rcol, invDt, info_dev, zvec, n3, flags + 2 * (r1 / 128), spin_limit, ev_panel);
         else launch_diag(r1);
         if (n3 <= 0) { sweep_rows(r0, 256); break; }
         if (fused) {}

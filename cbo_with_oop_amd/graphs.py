@@ -106,6 +106,21 @@ class CoralGraph(_Graph):
         ("N", "T", "D"), ("O", "C", "T"), ("O", "C", "D"), ("C", "T", "D"), ("O", "T", "D"),
     )
     _pomis = _mis
+    # evaluation order of define_sem (CoralGraph.py:148-160) and the regressions' inputs (var_dependencies, :40-50)
+    sem_order = ("N", "L", "TE", "C", "S", "T", "D", "P", "O", "CO", "Y")
+    var_dependencies = OrderedDict([
+        ("Y", ["L", "N", "P", "O", "C", "CO", "TE"]), ("P", ["S", "T", "D", "TE"]), ("O", ["S", "T", "D", "TE"]),
+        ("CO", ["S", "T", "D", "TE"]), ("T", ["S"]), ("D", ["S"]), ("C", ["N", "L", "TE"]), ("S", ["TE"]), ("TE", ["L"]),
+    ])
+
+    @classmethod
+    def define_sem(cls, coefs, intercepts, exogenous):
+        """CoralGraph.define_sem (CoralGraph.py:104-160) from what a reference process holds after its constructor:
+        ``coefs[v]`` / ``intercepts[v]`` = ``self.regressions[v].coef_`` / ``.intercept_`` (:91-94, fitted there on
+        ``true_observations.pkl``, a pickled DataFrame this package does not load) and ``exogenous`` = {"N": draws of
+        ``dist_nutrients_pc1.sample``, "L": draws of ``dist_Light.rvs``} (:96-101), one per Monte-Carlo sample."""
+        from .utils_functions.graph_functions import AdditiveSEM
+        return AdditiveSEM.from_linear(cls.sem_order, cls.var_dependencies, coefs, intercepts, exogenous)
 
 
 class SimplifiedCoralGraph(CoralGraph):

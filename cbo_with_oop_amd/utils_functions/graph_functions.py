@@ -70,12 +70,54 @@ class AdditiveSEM(OrderedDict):
         return sp
 
     def device(self, num_samples=100000, seed=1, context=None):
-        """The resident (noise matrix, model) pair for one (num_samples, seed); cached on the model."""
+        """The resident (noise matrix, model) pair for one (num_samples, seed); cached on the model.  A model that
+        carries its own draws (``from_linear``) ignores ``num_samples`` / ``seed``: the draws ARE the samples."""
         cache = self.__dict__.setdefault("_device", {})
-        key = (int(num_samples), int(seed), id(context))
+        draws = self.__dict__.get("draws")
+        key = ("own", id(context)) if draws is not None else (int(num_samples), int(seed), id(context))
         if key not in cache:
-            cache[key] = DeviceSEM(self, num_samples, seed, context)
+            cache[key] = DeviceSEM(self, num_samples, seed, context, draws=draws)
         return cache[key]
+
+    @classmethod
+    def from_linear(cls, order, parents, coefs, intercepts, exogenous):
+        """A SEM whose endogenous nodes are linear regressions of earlier nodes and whose exogenous nodes are draws the
+        caller made -- the shape of /root/reference/src/graphs/impl/CoralGraph.py:91-160 (``LinearRegression`` per node,
+        :91-94, evaluated as ``regressions[v].predict(parents)`` in ``define_sem``, :104-160; ``N`` and ``L`` drawn from
+        a Gaussian mixture / a gamma fitted to the data, :96-101, :106-110).
+
+        order       node names in evaluation order
+        parents     {node: [parent names]} for the regression nodes (``var_dependencies``, CoralGraph.py:40-50)
+        coefs       {node: coefficients in the order of parents[node]} (``LinearRegression.coef_``)
+        intercepts  {node: float} (``LinearRegression.intercept_``)
+        exogenous   {node: 1-D array of num_samples draws} for the nodes without parents; the reference draws one
+                    value per sample from scipy / sklearn's global generators, so the caller makes them
+
+        A regression node is ``sum_i coef_i * parent_i + intercept``, terms left to right, the intercept last
+        (``X @ coef_ + intercept_``).  The intercept rides in the node's noise slot: the draws matrix the model carries
+        has one column per exogenous node (its draws) and one constant column per regression node."""
+        model = cls()
+        exo = [n for n in order if n not in parents]
+        missing = [n for n in exo if n not in exogenous]
+        if missing:
+            raise ValueError(f"no draws for the exogenous node(s) {missing}")
+        num = {len(np.asarray(exogenous[n]).reshape(-1)) for n in exo}
+        if len(num) != 1:
+            raise ValueError("every exogenous node needs the same number of draws")
+        num_samples = num.pop()
+        cols = []
+        for name in order:
+            if name in parents:
+                c = np.asarray(coefs[name], dtype=np.float64).reshape(-1)
+                if len(c) != len(parents[name]):
+                    raise ValueError(f"node {name!r}: {len(c)} coefficients for {len(parents[name])} parents")
+                model.add(name, [Term(p, "id", 1.0, float(ci)) for p, ci in zip(parents[name], c)], eps=len(cols))
+                cols.append(np.full(num_samples, float(np.asarray(intercepts[name]).reshape(-1)[0])))
+            else:
+                model.add(name, [], eps=len(cols))
+                cols.append(np.asarray(exogenous[name], dtype=np.float64).reshape(-1))
+        model.__dict__["draws"] = np.ascontiguousarray(np.stack(cols, axis=1))
+        return model
 
 
 def reference_noise(num_samples, n_nodes, seed):
@@ -86,12 +128,16 @@ def reference_noise(num_samples, n_nodes, seed):
 class DeviceSEM:
     """cbo_sem handle: the model and its noise matrix on the device."""
 
-    def __init__(self, model, num_samples=100000, seed=1, context=None):
+    def __init__(self, model, num_samples=100000, seed=1, context=None, draws=None):
         self.model = model
         self.names = list(model)
         self.ctx = context or _lib.Context.get()
         self._lib = _lib.load()
-        eps = np.ascontiguousarray(reference_noise(num_samples, len(model), seed))
+        if draws is None:
+            eps = np.ascontiguousarray(reference_noise(num_samples, len(model), seed))
+        else:                                              # the caller's own samples, one row per draw
+            eps = np.ascontiguousarray(draws, dtype=np.float64)
+            num_samples = eps.shape[0]
         self.num_samples = int(num_samples)
         self._spec = model.spec()
         h = ctypes.c_void_p()

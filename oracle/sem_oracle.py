@@ -46,6 +46,28 @@ def toy_graph_sem():
     ])
 
 
+def linear_sem(order, parents, coefs, intercepts):
+    """CoralGraph.define_sem (/root/reference/src/graphs/impl/CoralGraph.py:104-160) for given regressions: a node with
+    parents is ``regressions[v].predict(hstack(parents))`` = parents @ coef_ + intercept_ (:112-146); a node without
+    is the caller's draw for that sample (``dist.sample(1)`` / ``dist.rvs(1)`` there, :106-110), taken from column k of
+    the draws matrix, k = the node's position among the exogenous nodes."""
+    sem, k = OrderedDict(), 0
+    for name in order:
+        if name in parents:
+            ps, c, b = list(parents[name]), np.asarray(coefs[name], dtype=np.float64).reshape(-1), float(intercepts[name])
+
+            def f(e, v, ps=ps, c=c, b=b):
+                acc = c[0] * v[ps[0]]
+                for ci, p in zip(c[1:], ps[1:]):
+                    acc = acc + ci * v[p]
+                return acc + b
+            sem[name] = f
+        else:
+            sem[name] = (lambda e, v, k=k: e[k])
+            k += 1
+    return sem
+
+
 def sample_from_model(sem, fixed, epsilon):
     """One draw (graph_functions.py:8-27 on the mutilated model of :30-45)."""
     values = OrderedDict()
@@ -61,11 +83,12 @@ def compute_interventions_loop(sem, fixed, target="Y", num_samples=100000, seed=
     return float(np.mean(np.asarray(ys, dtype=np.float64)))
 
 
-def compute_interventions(sem, fixed, target="Y", num_samples=100000, seed=1):
+def compute_interventions(sem, fixed, target="Y", num_samples=100000, seed=1, draws=None):
     """Same numbers with the draws stacked: the node functions are elementwise, so passing the noise matrix's
     columns evaluates every draw at once (equal to the loop draw for draw; the mean's summation order is
-    numpy's pairwise one in both)."""
-    eps = np.random.RandomState(seed).randn(num_samples, len(sem))
+    numpy's pairwise one in both).  ``draws``: the caller's own sample matrix instead of the seeded normals."""
+    eps = np.random.RandomState(seed).randn(num_samples, len(sem)) if draws is None else np.asarray(draws, dtype=np.float64)
+    num_samples = eps.shape[0]
     cols = [eps[:, k] for k in range(eps.shape[1])]
     values = OrderedDict()
     for name, f in sem.items():

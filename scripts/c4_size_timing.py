@@ -6,8 +6,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from cbo_with_oop_amd import CandidateGrid, _lib
 from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
-from cbo_with_oop_amd.graphs import SimplifiedCoralGraph, meshgrid_candidates
-box = SimplifiedCoralGraph.bounds(["N", "O", "C"])
+from cbo_with_oop_amd.graphs import CoralGraph, meshgrid_candidates
+box = CoralGraph.bounds(["N", "O", "C"])     # (the ranges this test has used since round 1)
 lo, hi = np.array([b[0] for b in box], float), np.array([b[1] for b in box], float)
 rng = np.random.default_rng(16384)
 X = rng.uniform(lo, hi, (16384, 3))

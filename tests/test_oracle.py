@@ -198,3 +198,25 @@ def test_likelihood_gradients_against_finite_differences():
             wrap = (lambda a: a[0]) if ls.size == 1 else (lambda a: a)
             fd = (lml(lengthscale=wrap(up)) - lml(lengthscale=wrap(dn))) / (2 * h)
             assert d_ls[k] == pytest.approx(fd, rel=1e-6), k
+
+
+def test_refined_mean_with_exact_entries_equals_the_long_double_restatement():
+    """oracle/truth.py:refined_mean(exact_entries=True) -- entries from direct coordinate differences, fp64 Cholesky as
+    the solver, long-double residuals -- reproduces the all-long-double restatement's mean where the fp64 oracle itself
+    cannot (coordinates around 2470 as on the coral graph's T axis: GPy's distance formula loses 1e-9 per entry).  That
+    makes it the arbiter for the mean at sizes where the O(n^3) long-double restatement is not affordable."""
+    from oracle.truth import refined_mean, truth_predict
+    rng = np.random.default_rng(3)
+    for n, shift in ((500, 0.0), (400, 2470.0)):
+        X = rng.uniform(-5, 5, (n, 2)) + shift
+        y = np.cos(X[:, :1]) - np.exp(-(X[:, 1:] - shift) / 20) + 0.1 * rng.standard_normal((n, 1))
+        Xs = rng.uniform(-5, 5, (40, 2)) + shift
+        post = O.fit(X, y)
+        mu, _ = O.predict(post, Xs)
+        tm, _, _ = truth_predict(X, y, Xs, diag_add=1e-10 + 1e-8 + post.jitter)
+        em, _ = refined_mean(post, Xs, exact_entries=True)
+        rm, _ = refined_mean(post, Xs)
+        assert np.max(np.abs(em - tm)) < 1e-7 * np.max(np.abs(y))
+        assert np.max(np.abs(rm - mu)) < 1e-6 * np.max(np.abs(y))          # the oracle's own solve is accurate ...
+        if shift:
+            assert np.max(np.abs(mu - tm)) > 100 * np.max(np.abs(em - tm))  # ... its entries are what differs

@@ -495,8 +495,8 @@ def test_c4_size_chunked_workspace(hip, monkeypatch):
     of a 16384^2 matrix on the host, ~0.5 min)."""
     from cbo_with_oop_amd import CausalExpectedImprovement, _lib
     from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
-    from cbo_with_oop_amd.graphs import SimplifiedCoralGraph, meshgrid_candidates
-    box = SimplifiedCoralGraph.bounds(["N", "O", "C"])
+    from cbo_with_oop_amd.graphs import CoralGraph, meshgrid_candidates
+    box = CoralGraph.bounds(["N", "O", "C"])     # (the ranges this test has used since round 1)
     lo, hi = np.array([b[0] for b in box], float), np.array([b[1] for b in box], float)
     rng = np.random.default_rng(16384)
     X = rng.uniform(lo, hi, (16384, 3))
@@ -579,12 +579,57 @@ for n, noise in ((130, 1e-2), (700, 1e-2), (2300, 1e-3), (1500, 1e-10)):
 print("DIGEST", h.hexdigest())
 """ % ROOT
     digests = {}
-    for form in ("4", "2"):
-        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CBO_HIP_PANEL_FORM=form),
+    # "timeout": the fused launches with every strip giving up at its first wait (CBO_HIP_FUSED_SPIN_LIMIT=-1): the host
+    # repeats each factorisation with the separate-launch kernels inside the same call -- no error, same bits
+    for form, env in (("4", {}), ("2", {"CBO_HIP_PANEL_FORM": "2"}), ("timeout", {"CBO_HIP_FUSED_SPIN_LIMIT": "-1"})):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env),
                              capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         digests[form] = [ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][-1]
-    assert digests["4"] == digests["2"], digests
+    assert digests["4"] == digests["2"] == digests["timeout"], digests
+
+
+def test_chain_launch_forms_give_the_same_bits_at_full_sizes(hip):
+    """The same comparison at BASELINE's sizes, by digest of the factor and of a sweep: 4096 observations (32 panels; also
+    through the overlapped refit + sweep call) and 16384 observations (128 panels, the fused launch with up to 255
+    strips) -- fused, separate launches, and the forced give-up + repeat."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from cbo_with_oop_amd import CausalExpectedImprovement
+from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+h = hashlib.sha256()
+for n in (4096, 16384):
+    rng = np.random.default_rng(n)
+    X = rng.uniform([-5, -5, -5], [5, 20, 5], (n, 3))
+    y = np.sin(X).sum(1, keepdims=True) + 0.1 * rng.standard_normal((n, 1))
+    Xs = rng.uniform([-5, -5, -5], [5, 20, 5], (1024, 3))
+    m = HipGaussianProcess(X, y)
+    L, alpha = m.posterior_state()
+    h.update(np.ascontiguousarray(L).tobytes())
+    h.update(np.ascontiguousarray(alpha).tobytes())
+    del L
+    ei = CausalExpectedImprovement(float(y.min()), "min", m)
+    r = ei.sweep(Xs, want_acq=True, want_posterior=True)
+    f = ei.sweep(Xs, want_acq=True, want_posterior=True, refit=True)          # cbo_gp_fit_sweep (overlapped at 4096)
+    for res in (r, f):
+        for k in ("acq", "var", "mean"):
+            h.update(np.ascontiguousarray(res[k]).tobytes())
+        h.update(str((m.jitter_tries, res["best_idx"])).encode())
+    m.close()
+print("DIGEST", h.hexdigest())
+""" % ROOT
+    digests = {}
+    for form, env in (("4", {}), ("2", {"CBO_HIP_PANEL_FORM": "2"}), ("timeout", {"CBO_HIP_FUSED_SPIN_LIMIT": "-1"})):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env),
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests[form] = [ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][-1]
+    assert digests["4"] == digests["2"] == digests["timeout"], digests
 
 
 def test_optimizer_class_and_quotient_mirror_the_reference_call_sequence(hip):

@@ -71,11 +71,75 @@ def test_spec_packing_and_validation():
         G.AdditiveSEM().add("A", [G.Term("B")])                # reads a node that is not earlier
     with pytest.raises(ValueError):
         G.Term("A", "tanh")
-    assert not hasattr(CoralGraph, "define_sem")               # data-fitted SEM: out of scope, not faked
+    # the coral graph's SEM is linear regressions + caller-made draws: built from coefficients, never from the pickle
+    coefs, ic, exo = _coral_regressions(1000)
+    coral = CoralGraph.define_sem(coefs, ic, exo)
+    sp = coral.spec()
+    assert sp.n_nodes == 11 and list(coral) == list(CoralGraph.sem_order)
+    assert list(sp.term_begin[:12]) == [0, 0, 0, 1, 4, 5, 6, 7, 11, 15, 19, 26]
+    assert list(sp.term_parent[1:4]) == [0, 1, 2]             # C reads N, L, TE
+    assert coral.draws.shape == (1000, 11) and np.all(coral.draws[:, 2] == ic["TE"])
+    assert np.array_equal(coral.draws[:, 0], exo["N"]) and np.array_equal(coral.draws[:, 1], exo["L"])
+    with pytest.raises(ValueError):
+        CoralGraph.define_sem(coefs, ic, {"N": exo["N"]})      # no draws for L
+    with pytest.raises(ValueError):
+        CoralGraph.define_sem(dict(coefs, Y=coefs["Y"][:3]), ic, exo)
     assert G.get_parameter_space({"B": "", "D": ""}, [-5, -5], [4, 5]) == [(-5.0, 4.0), (-5.0, 5.0)]
 
 
+def _coral_regressions(num_samples, seed=0):
+    """Synthetic stand-ins for what a reference process holds after CoralGraph.__init__ (CoralGraph.py:91-101):
+    regression coefficients / intercepts per node and draws of the two exogenous distributions (a three-component
+    Gaussian mixture for N, a gamma for L).  The real coefficients come from true_observations.pkl, a pickled DataFrame
+    that is not loaded here."""
+    rng = np.random.default_rng(seed)
+    coefs = {v: rng.normal(scale=0.5, size=len(p)) for v, p in CoralGraph.var_dependencies.items()}
+    ic = {v: float(rng.normal()) for v in CoralGraph.var_dependencies}
+    comp = rng.integers(0, 3, num_samples)
+    exo = {"N": rng.normal(np.array([-1.0, 0.5, 3.0])[comp], np.array([0.3, 0.8, 0.5])[comp]),
+           "L": 1.5 + rng.gamma(2.0, 0.7, num_samples)}
+    return coefs, ic, exo
+
+
+def test_linear_sem_host_sample_matches_the_restatement():
+    coefs, ic, exo = _coral_regressions(50)
+    model = CoralGraph.define_sem(coefs, ic, exo)
+    sem = S.linear_sem(CoralGraph.sem_order, CoralGraph.var_dependencies, coefs, ic)
+    draws = np.stack([exo["N"], exo["L"]], axis=1)
+    for i in (0, 17, 49):
+        mine = G.sample_from_model(G.intervene_dict(model, T=2460.0), epsilon=model.draws[i])
+        ref = S.sample_from_model(sem, {"T": 2460.0}, draws[i])
+        for k in ref:
+            assert mine[k] == pytest.approx(ref[k], rel=1e-15, abs=1e-300), k
+
+
 # ---- device -----------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_device_target_of_a_linear_regression_sem_with_caller_draws():
+    """f4 for the coral graphs' SEM shape (CoralGraph.py:91-160): multi-parent linear nodes with intercepts, exogenous
+    nodes from caller-generated draws; every exploration-set size of the coral graph, against the restatement."""
+    n = 100000
+    coefs, ic, exo = _coral_regressions(n)
+    model = CoralGraph.define_sem(coefs, ic, exo)
+    sem = S.linear_sem(CoralGraph.sem_order, CoralGraph.var_dependencies, coefs, ic)
+    draws = np.stack([exo["N"], exo["L"]], axis=1)
+    rng = np.random.default_rng(1)
+    for es in (["N"], ["T"], ["O", "C"], ["N", "O", "T"], ["C", "T", "D"]):
+        x = np.array([[rng.uniform(lo, hi) for lo, hi in CoralGraph.bounds(es)]])
+        got = G.compute_interventions(model, {v: "" for v in es}, x)
+        want = S.compute_interventions(sem, dict(zip(es, x[0])), draws=draws)
+        assert got.shape == (1, 1) and got[0, 0] == pytest.approx(want, rel=1e-12), es
+    # observational mean, another target node, a batch of interventions in one launch
+    dev = model.device()
+    assert dev.num_samples == n and model.device(num_samples=5, seed=9) is dev      # the model's own draws are the samples
+    assert dev.target_means([], None)[0, 0] == pytest.approx(S.compute_interventions(sem, {}, draws=draws), rel=1e-12)
+    assert dev.target_means(["S"], [[0.3]], "CO")[0, 0] == pytest.approx(
+        S.compute_interventions(sem, {"S": 0.3}, target="CO", draws=draws), rel=1e-12)
+    vals = np.stack([np.linspace(-2, 5, 40), np.linspace(2, 4, 40)], axis=1)
+    got = dev.target_means(["N", "O"], vals)[:, 0]
+    for i in (0, 13, 39):
+        assert got[i] == pytest.approx(S.compute_interventions(sem, {"N": vals[i, 0], "O": vals[i, 1]}, draws=draws), rel=1e-12)
+
 @pytest.mark.gpu
 def test_device_target_matches_restatement_on_the_reference_draws():
     model, sem = CompleteGraph.define_sem(), S.complete_graph_sem()
