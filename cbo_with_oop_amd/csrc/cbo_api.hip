@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -1503,10 +1504,28 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
 // fitted state alone.  A set whose factorisation meets a non-positive pivot there (jitchol's business), a larger
 // model, or an fp32 model takes the general path: cbo_gp_fit_sweep when the model is not fitted, cbo_acq_sweep
 // otherwise.
-constexpr int kPollSpins = 1 << 15;       // ~0.3 ms of polling a pinned word before falling back to the stream
-// A launch whose result was polled is still "in flight" for the runtime; left unreaped by the hundred they cost one
-// call in a thousand ~70 ms (measured).  The stream is idle after a successful poll: synchronising it is cheap.
+// How long the host polls the pinned result record of a one-launch job before it lets the runtime wait on the stream.
+// Measured (round 3, CBO_HIP_TRACE_SLOW=1): a blocking hipStreamSynchronize behind such a launch returns after the
+// kernel's ~40 us -- except about once in 600-1000 calls, when it returns after 62.75 ms +- 0.03 (a timed wait inside
+// the runtime running out: the completion wake-up was missed, the kernel had long finished).  Round 2 polled for
+// 32768 reads, which is ~10 us, not the 0.3 ms it was meant to be, so nearly every call ended in that blocking wait.
+// The poll is now bounded by the clock: the record of a small job arrives within it and the host never sleeps on the
+// stream; only jobs that really take longer fall through to hipStreamSynchronize.
+constexpr double kPollBudgetUs = 2000.0;
+// A launch whose result was polled is still "in flight" for the runtime: every so many of them the (idle) stream is
+// synchronised so that their completion records are reaped; their signals have completed, the call does not sleep.
 constexpr int kPolledLaunchesPerSync = 256;
+template <class Pred>
+static bool poll_until(Pred done, double budget_us)
+{
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t0 = clk::now();
+    for (;;) {
+        for (int spin = 0; spin < 256; ++spin)
+            if (done()) return true;
+        if (std::chrono::duration<double, std::micro>(clk::now() - t0).count() > budget_us) return done();
+    }
+}
 static bool polled_launch_needs_sync(cbo_ctx *c)
 {
     if (++c->polled_launches < kPolledLaunchesPerSync) return false;
@@ -1602,20 +1621,35 @@ extern "C" int cbo_acq_sweep_sets(int n_sets, cbo_gp *const *gps, cbo_cands *con
         const int ns = (int)small.size();
         if (++c->small_seq == 0) c->small_seq = 1;
         const int seq = c->small_seq;
+        // CBO_HIP_TRACE_SLOW=1: a call that takes more than a millisecond says on stderr where the time went
+        static const bool trace_slow = std::getenv("CBO_HIP_TRACE_SLOW") != nullptr;
+        using clk = std::chrono::steady_clock;
+        const clk::time_point t_begin = trace_slow ? clk::now() : clk::time_point();
+        clk::time_point t_launched, t_polled;
         launch_small_sets(c->stream, c->sets_host, ns, blocks, c->small_scratch, c->small_part_val, c->small_part_idx,
                           c->small_info, c->small_info + c->sets_cap, c->small_out, seq);
         HIP_TRY(hipGetLastError());
-        // the result records arrive in pinned memory, each closed by the call's sequence number: poll them (a few
-        // microseconds sooner than the stream's completion signal) for a few hundred microseconds, then let the
-        // runtime wait (large jobs; and about one call in a thousand, whose submission only a synchronisation completes)
+        if (trace_slow) t_launched = clk::now();
+        // the result records arrive in pinned memory, each closed by the call's sequence number: poll them (kPollBudgetUs),
+        // then let the runtime wait (jobs that really take that long)
         {
-            bool all = false;
-            for (int spin = 0; spin < kPollSpins && !all; ++spin) {
-                all = true;
+            const bool all = poll_until([&] {
                 for (int j = 0; j < ns; ++j)
-                    if (*reinterpret_cast<volatile int *>(&c->small_out[j].seq) != seq) { all = false; break; }
+                    if (*reinterpret_cast<volatile int *>(&c->small_out[j].seq) != seq) return false;
+                return true;
+            }, kPollBudgetUs);
+            if (trace_slow) t_polled = clk::now();
+            const bool reap = polled_launch_needs_sync(c);
+            if (!all || c->profiling || reap) HIP_TRY(hipStreamSynchronize(c->stream));
+            if (trace_slow) {
+                const clk::time_point t_end = clk::now();
+                auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+                if (us(t_begin, t_end) > 1000.0)
+                    std::fprintf(stderr, "[cbo] slow cbo_acq_sweep_sets call #%d: launch %.0f us, poll %.0f us (%s), "
+                                 "synchronise %.0f us (%s)\n", seq, us(t_begin, t_launched), us(t_launched, t_polled),
+                                 all ? "records arrived" : "gave up", us(t_polled, t_end),
+                                 !all ? "after the poll gave up" : reap ? "periodic reap" : "none");
             }
-            if (!all || c->profiling || polled_launch_needs_sync(c)) HIP_TRY(hipStreamSynchronize(c->stream));
             for (int j = 0; j < ns; ++j)
                 if (c->small_out[j].seq != seq) return fail(CBO_ERR_HIP, "multi-set sweep: no result record");
             std::atomic_thread_fence(std::memory_order_acquire);
@@ -1775,9 +1809,7 @@ static int small_lml_gradients(cbo_gp *g, double *lml_out, double *dvariance_out
     const int seq = c->small_seq;
     launch_small_lml(c->stream, st, c->small_scratch, c->small_info, c->lml_out, seq);
     if (hipGetLastError() != hipSuccess) return fail(CBO_ERR_HIP, "small_lml_kernel launch");
-    bool ready = false;
-    for (int spin = 0; spin < kPollSpins && !ready; ++spin)
-        ready = *reinterpret_cast<volatile int *>(&c->lml_out->seq) == seq;
+    const bool ready = poll_until([&] { return *reinterpret_cast<volatile int *>(&c->lml_out->seq) == seq; }, kPollBudgetUs);
     if (!ready || c->profiling || polled_launch_needs_sync(c)) {
         if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(CBO_ERR_HIP, "hipStreamSynchronize");
         if (c->lml_out->seq != seq) return fail(CBO_ERR_HIP, "likelihood kernel: no result record");

@@ -1,5 +1,13 @@
 """BASELINE config 1 shape (toy graph, 50 observations, 200-candidate sweep per set, 2 sets): latency of one
-intervene()-style pass (refit one GP, sweep both sets, pick) on the GPU path and on the CPU oracle."""
+intervene()-style pass (refit one GP, sweep both sets, pick) on the GPU path and on the CPU oracle.
+
+The 50-70 ms outliers of rounds 1-2 (one call in ~1000) were this script's own doing: the CPU-oracle passes leave numpy's
+BLAS pool (one thread per visible core: 256 on the GPU box) spinning, the box's cgroup allows 16 CPUs per 100 ms period
+(/sys/fs/cgroup/cpu.max = 1600000 100000), and the kernel's bandwidth control then freezes EVERY thread of the process
+until the period ends -- including the one timing the library (CBO_HIP_TRACE_SLOW=1 showed the stall inside a plain
+spin on pinned memory, not in any runtime call).  The device timings below therefore run with the BLAS pool limited to one
+thread (threadpoolctl); `--oversubscribe` keeps the pool as it is and shows the stalls again, with the cgroup's
+nr_throttled count before and after."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -37,6 +45,22 @@ def gpu_pass_per_set():
 def device_only():
     """just the multi-set device call (no upload of the intervened set, no host bookkeeping)"""
     return path.compute_best_acquisition_values(best)[1][0][0, 0]
+def throttle_count():
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            if line.startswith("nr_throttled"):
+                return int(line.split()[1])
+    except OSError:
+        pass
+    return None
+from threadpoolctl import threadpool_limits
+_limit = None if "--oversubscribe" in sys.argv else threadpool_limits(limits=1)
+try:
+    print("cgroup cpu.max:", open("/sys/fs/cgroup/cpu.max").read().strip(), "| visible cores:", os.cpu_count(),
+          "| BLAS pool:", "unlimited (--oversubscribe)" if _limit is None else "1 thread")
+except OSError:
+    pass
+thr0 = throttle_count()
 for name, fn in (("gpu path (one launch for all sets)", gpu_pass), ("gpu path, per-set calls", gpu_pass_per_set),
                  ("  of which cbo_acq_sweep_sets + host glue", device_only), ("cpu oracle", cpu_pass)):
     for _ in range(5): fn()
@@ -66,3 +90,6 @@ for _ in range(2000):
 ts = np.array(ts) * 1e6
 print(f"  cbo_acq_sweep_sets alone (2 sets x 200 candidates, 50 observations each): median {np.median(ts):.1f} us, mean "
       f"{ts.mean():.1f} us, max {ts.max():.0f} us over {len(ts)} calls ({int((ts > 1000).sum())} above 1 ms)")
+thr1 = throttle_count()
+if thr0 is not None:
+    print(f"  cgroup periods in which this process group was throttled while the script ran: {thr1 - thr0}")
