@@ -737,11 +737,27 @@ static int ensure_alpha(cbo_gp *g)
 {
     if (g->alpha_ready) return CBO_OK;
     cbo_ctx *c = g->ctx;
+    bool chained;
     {
         PhaseScope ps(c, PH_ALPHA);
-        launch_backsolve(c->stream, g->A, g->lda, g->n_pad, g->invDt, g->alpha);
+        // one launch (a chain of workgroups); the per-block launches where that form does not apply
+        chained = launch_backsolve_chain(c->stream, g->A, g->lda, g->n_pad, g->invDt, g->A + g->n_pad, g->lda,
+                                         g->alpha + g->n_pad, g->alpha, g->info);
+        if (!chained) launch_backsolve(c->stream, g->A, g->lda, g->n_pad, g->invDt, g->alpha);
     }
     HIP_TRY(hipGetLastError());
+    if (chained) {
+        // the chain's polls are bounded: a give-up is in the status word, and the solve is repeated the old way
+        HIP_TRY(hipMemcpyAsync(c->h_info, g->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (*c->h_info != 0) {
+            HIP_TRY(hipMemsetAsync(g->info, 0, sizeof(int), c->stream));
+            ++c->fused_fallbacks;
+            PhaseScope ps(c, PH_ALPHA);
+            launch_backsolve(c->stream, g->A, g->lda, g->n_pad, g->invDt, g->alpha);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     g->alpha_ready = true;
     return CBO_OK;
 }
@@ -1316,14 +1332,26 @@ extern "C" int cbo_gp_append(cbo_gp *g, const double *x_new, double y_new, doubl
     if (rc != CBO_OK) return rc;
     launch_kstar(c->stream, g->X, g->probe->P, 0, g->probe->m_pad, g->h, c->V, ldv, g->n_pad);
     launch_gather_column(c->stream, c->V, ldv, g->n_pad, g->alpha + g->n_pad);      // work vector (alpha's scratch half)
-    launch_forward_vec(c->stream, g->A, g->lda, g->n_pad, g->invDt, g->alpha + g->n_pad, g->lvec);
+    const bool chained = launch_forward_chain(c->stream, g->A, g->lda, g->n_pad, g->invDt, g->alpha + g->n_pad, g->lvec,
+                                              g->info);
+    if (!chained) launch_forward_vec(c->stream, g->A, g->lda, g->n_pad, g->invDt, g->alpha + g->n_pad, g->lvec);
     HIP_TRY(hipGetLastError());
     // l^T z and l^T l by one device reduction (16 bytes come back)
     launch_dot2(c->stream, g->lvec, g->z, g->n, c->part_val);
     HIP_TRY(hipGetLastError());
     double hd[2];
     HIP_TRY(hipMemcpyAsync(hd, c->part_val, sizeof(hd), hipMemcpyDeviceToHost, c->stream));
+    if (chained) HIP_TRY(hipMemcpyAsync(c->h_info, g->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (chained && *c->h_info != 0) {                       // the chain gave up (bounded polls): the per-block launches
+        HIP_TRY(hipMemsetAsync(g->info, 0, sizeof(int), c->stream));
+        ++c->fused_fallbacks;
+        launch_forward_vec(c->stream, g->A, g->lda, g->n_pad, g->invDt, g->alpha + g->n_pad, g->lvec);
+        launch_dot2(c->stream, g->lvec, g->z, g->n, c->part_val);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(hd, c->part_val, sizeof(hd), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     const double h2[2] = {hd[1], hd[0]};                    // {l^T l, l^T z}
     g->alpha_ready = false;                                 // its scratch half was used
     const double kappa = g->h.variance + (causal ? prior_var_new : 0.0) + (g->noise_var + kGpyDiagJitter);

@@ -149,6 +149,13 @@ void launch_backsolve(hipStream_t s, const double *A, int64_t lda, int64_t n_pad
 void launch_forward_vec(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt, double *w,
                         double *out);
 void launch_gather_column(hipStream_t s, const double *V, int64_t ldv, int64_t n_pad, double *dst);
+// one-launch forms (a chain of workgroups, one per 128-row block); false = not applicable, nothing was launched.  `info`
+// is the model's status word: a give-up leaves kCholFusedTimeout in it and the caller
+// repeats the solve with the per-block launches (launch_backsolve_vec / launch_forward_vec) after resetting it.
+bool launch_backsolve_chain(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt,
+                            const double *src, int64_t src_stride, double *work, double *out, int *info);
+bool launch_forward_chain(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt, const double *w,
+                          double *out, int *info);
 void launch_backsolve_vec(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt,
                           const double *src, int64_t src_stride, double *work, double *out);
 // Gradients of the posterior mean and variance w.r.t. the prediction inputs (GPy predictive_gradients), batched:

@@ -1990,6 +1990,245 @@ void launch_forward_vec(hipStream_t s, const double *A, int64_t lda, int64_t n_p
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The two single-vector solves as ONE launch each: a chain of workgroups, one per 128-row block.
+//
+// The per-block launches above cost a launch plus a cold diagonal solve per block (42 us: 5.4 ms for alpha at 16384
+// points).  Here workgroup w owns block g and, in the backward solve, folds alpha_blk into its 128 entries for every
+// blk > g as those become available (the solved block itself is the signal, see chain_wait), then solves its diagonal
+// block and publishes alpha_g.  What the chain waits for per block
+// is: the arrival of alpha_{g+1}, one 128 x 128 fold, the diagonal solve, the publication.  Everything that does not
+// depend on alpha is in place before it arrives: the diagonal block and its 16 x 16 inverses sit in LDS, the block of U
+// for the next fold sits in registers (requested while the previous hand-over is awaited).
+// Same operations in the same order as the per-block kernels (each fold is one subtraction of the same wave-reduced
+// sum, blocks in the same order; the in-block solve is the same code on LDS copies): same bits.
+// Forward progress: block g waits only for blocks solved earlier, and the workgroup index grows in solve order, so under
+// in-order dispatch every producer is resident before its consumers (no need for all workgroups to be co-resident).
+// The polls are bounded; a give-up lands in the status word and the host repeats the solve with the per-block launches.
+constexpr int kVecLd = 129;                      // LDS row stride of the diagonal block: column reads by 128 threads
+
+struct VecChainShared {
+    double Ud[128][kVecLd];                      // U[g, g] (row-major)
+    double inv[8][256];                          // inverses of its 16 x 16 diagonal tiles
+    double zs[128], al[128], ab[128];
+    int abort_flag;
+};
+
+// The solved block IS the signal: the output vector is pre-filled with a sentinel (a NaN payload no computation
+// produces; a computed NaN is stored as the canonical quiet NaN), the producer stores its 128 values as agent-scope
+// atomics, and each of the consumer's first 128 threads polls ITS value until it is no longer the sentinel -- one
+// round trip to the coherence point per hand-over instead of two (count, then data), and no fence: every element is its
+// own atomic object and nothing else is communicated through it.
+constexpr unsigned long long kVecSentinel = 0x7ff8dead0000beefull;
+
+__device__ __forceinline__ bool chain_wait(const double *src, int *info, int spin_limit, VecChainShared &sh)
+{
+    int ok = 1;
+    if (threadIdx.x < 128) {
+        int spins = 0;
+        double v;
+        for (;;) {
+            v = __hip_atomic_load(src + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned long long)__double_as_longlong(v) != kVecSentinel) break;
+            if (spin_limit < 0 || ++spins > spin_limit || ((spins & 63) == 0 && __builtin_nontemporal_load(info) != 0)) { ok = 0; break; }
+        }
+        sh.ab[threadIdx.x] = v;
+    }
+    if (!__syncthreads_and(ok)) {
+        if (threadIdx.x == 0) atomicCAS(info, 0, kFusedTimeout);
+        return false;
+    }
+    return true;
+}
+
+__device__ __forceinline__ void chain_publish(double *dst, const double *vals)
+{
+    if (threadIdx.x < 128) {
+        double v = vals[threadIdx.x];
+        if (v != v) v = __longlong_as_double(0x7ff8000000000000ll);
+        __hip_atomic_store(dst + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ void fill_sentinel_kernel(double *p, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = __longlong_as_double((long long)kVecSentinel);
+}
+
+__global__ __launch_bounds__(256) void backsolve_chain_kernel(const double *__restrict__ A, int64_t lda,
+                                                              const double *__restrict__ invDt, int nb,
+                                                              const double *__restrict__ zt, double *alpha, int *info,
+                                                              int spin_limit)
+{
+    extern __shared__ __align__(16) unsigned char vec_smem[];
+    VecChainShared &sh = *reinterpret_cast<VecChainShared *>(vec_smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = nb - 1 - (int)blockIdx.x;                       // workgroup 0 owns the last block: solved first
+    const int b0 = g * 128;
+    if (tid < 128) sh.zs[tid] = zt[b0 + tid];
+    for (int i = tid; i < 128 * 128; i += 256) sh.Ud[i >> 7][i & 127] = A[(int64_t)(b0 + (i >> 7)) * lda + b0 + (i & 127)];
+    for (int i = tid; i < 8 * 256; i += 256) sh.inv[i >> 8][i & 255] = invDt[(int64_t)(b0 / 16) * 256 + i];
+    // The block of the NEXT fold is always in registers before its alpha arrives: U[g, blk] as wave w's rows w, w+4, ...,
+    // two columns per lane, requested while the previous hand-over is awaited (32 loads in flight, not 32 round trips).
+    d2 un[32];
+    auto request_block = [&](int blk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r)
+            un[r] = *reinterpret_cast<const d2 *>(&A[(int64_t)(b0 + wave + 4 * r) * lda + blk * 128 + 2 * lane]);
+    };
+    if (g + 1 < nb) request_block(nb - 1);
+    __syncthreads();
+    for (int blk = nb - 1; blk > g; --blk) {
+        if (!chain_wait(alpha + blk * 128, info, spin_limit, sh)) return;      // alpha_blk is in sh.ab
+        const double a0 = sh.ab[2 * lane], a1 = sh.ab[2 * lane + 1];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            double acc = fma(un[r][0], a0, un[r][1] * a1);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+            if (lane == 0) sh.zs[wave + 4 * r] -= acc;
+        }
+        if (blk - 1 > g) request_block(blk - 1);
+        __syncthreads();
+    }
+    // the diagonal system, bottom tile first (backsolve_step_kernel's arithmetic on the LDS copies)
+    for (int s = 7; s >= 0; --s) {
+        const int o = 16 * s;
+        if (tid < 64) {
+            const int i = tid >> 2, part = tid & 3;
+            const double *Y = sh.inv[s];
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = fma(Y[i * 16 + 4 * part + k], sh.zs[o + 4 * part + k], acc);
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            if (part == 0) sh.al[o + i] = acc;
+        }
+        __syncthreads();
+        if (tid < o) {
+            double acc = sh.zs[tid];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc = fma(-sh.Ud[tid][o + c], sh.al[o + c], acc);
+            sh.zs[tid] = acc;
+        }
+        __syncthreads();
+    }
+    chain_publish(alpha + b0, sh.al);
+}
+
+__global__ __launch_bounds__(256) void forward_chain_kernel(const double *__restrict__ A, int64_t lda,
+                                                            const double *__restrict__ invDt, int nb,
+                                                            const double *__restrict__ w, double *out, int *info,
+                                                            int spin_limit)
+{
+    extern __shared__ __align__(16) unsigned char vec_smem[];
+    VecChainShared &sh = *reinterpret_cast<VecChainShared *>(vec_smem);
+    const int tid = threadIdx.x;
+    const int g = (int)blockIdx.x;                                // solved in index order
+    const int b0 = g * 128;
+    const int c = tid & 127, half = tid >> 7;
+    if (tid < 128) sh.zs[tid] = w[b0 + tid];
+    for (int i = tid; i < 128 * 128; i += 256) sh.Ud[i >> 7][i & 127] = A[(int64_t)(b0 + (i >> 7)) * lda + b0 + (i & 127)];
+    for (int i = tid; i < 8 * 256; i += 256) sh.inv[i >> 8][i & 255] = invDt[(int64_t)(b0 / 16) * 256 + i];
+    // the block of the NEXT fold, U[blk rows, g columns], in registers before its l_blk arrives: this thread's column,
+    // its half of the 128 rows
+    double un[64];
+    auto request_block = [&](int blk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) un[k] = A[(int64_t)(blk * 128 + 64 * half + k) * lda + b0 + c];
+    };
+    if (g > 0) request_block(0);
+    __syncthreads();
+    for (int blk = 0; blk < g; ++blk) {
+        if (!chain_wait(out + blk * 128, info, spin_limit, sh)) return;        // l_blk is in sh.ab
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) acc = fma(un[k], sh.ab[64 * half + k], acc);
+        if (blk + 1 < g) request_block(blk + 1);
+        if (half == 1) sh.al[c] = acc;                            // (al is free until the diagonal solve)
+        __syncthreads();
+        if (half == 0) sh.zs[c] -= acc + sh.al[c];
+        __syncthreads();
+    }
+    // the diagonal system, top tile first (forward_step_kernel's arithmetic on the LDS copies)
+    for (int s = 0; s < 8; ++s) {
+        const int o = 16 * s;
+        if (tid < 64) {
+            const int i = tid >> 2, part = tid & 3;
+            const double *Y = sh.inv[s];
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = fma(Y[(4 * part + k) * 16 + i], sh.zs[o + 4 * part + k], acc);
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            if (part == 0) sh.al[o + i] = acc;
+        }
+        __syncthreads();
+        if (tid >= o + 16 && tid < 128) {
+            double acc = sh.zs[tid];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc = fma(-sh.Ud[o + k][tid], sh.al[o + k], acc);
+            sh.zs[tid] = acc;
+        }
+        __syncthreads();
+    }
+    chain_publish(out + b0, sh.al);
+}
+
+// CBO_HIP_VEC_SOLVE_FORM=1: the per-block launches.  `info` is the model's status word (0 after a fit).
+static bool vec_chain_enabled(int nb)
+{
+    static const int form = [] { const char *e = std::getenv("CBO_HIP_VEC_SOLVE_FORM"); return e ? std::atoi(e) : 2; }();
+    return form != 1 && nb >= 2;
+}
+static int vec_spin_limit()
+{
+    const char *e = std::getenv("CBO_HIP_FUSED_SPIN_LIMIT");
+    return e ? std::atoi(e) : kFusedSpinLimit;
+}
+
+bool launch_backsolve_chain(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt,
+                            const double *src, int64_t src_stride, double *work, double *out, int *info)
+{
+    const int nb = (int)(n_pad / 128);
+    if (!vec_chain_enabled(nb)) return false;
+    static const bool attr = [] {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(backsolve_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(VecChainShared));
+        hipFuncSetAttribute(reinterpret_cast<const void *>(forward_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(VecChainShared));
+        return true;
+    }();
+    (void)attr;
+    hipLaunchKernelGGL(copy_strided_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, src, src_stride,
+                       n_pad, work);
+    hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, out, n_pad);
+    hipLaunchKernelGGL(backsolve_chain_kernel, dim3(nb), dim3(256), sizeof(VecChainShared), s, A, lda, invDt, nb, work, out,
+                       info, vec_spin_limit());
+    return true;
+}
+
+bool launch_forward_chain(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt, const double *w,
+                          double *out, int *info)
+{
+    const int nb = (int)(n_pad / 128);
+    if (!vec_chain_enabled(nb)) return false;
+    static const bool attr = [] {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(backsolve_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(VecChainShared));
+        hipFuncSetAttribute(reinterpret_cast<const void *>(forward_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(VecChainShared));
+        return true;
+    }();
+    (void)attr;
+    hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, out, n_pad);
+    hipLaunchKernelGGL(forward_chain_kernel, dim3(nb), dim3(256), sizeof(VecChainShared), s, A, lda, invDt, nb, w, out,
+                       info, vec_spin_limit());
+    return true;
+}
+
 // dst[i] = V[i * ldv] for i < n_pad: one column of a row-major workspace as a contiguous vector
 void launch_gather_column(hipStream_t s, const double *V, int64_t ldv, int64_t n_pad, double *dst)
 {

@@ -33,6 +33,7 @@ print(f"append-only step at N={X.shape[0]}, M={Xs.shape[0]}: append {np.median(t
 ref = HipGaussianProcess(X, y)
 full = CausalExpectedImprovement(float(y.min()), "min", ref).sweep(Xs, want_acq=True)
 inc = ei().sweep(grid, want_acq=True)
+sys.stdout.flush()
 print("same winner as a model fitted from scratch:", full["best_idx"] == inc["best_idx"],
       "max |acq diff| / max acq:", float(np.max(np.abs(full["acq"] - inc["acq"])) / full["acq"].max()))
 t0 = time.perf_counter()

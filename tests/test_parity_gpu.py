@@ -575,18 +575,29 @@ for n, noise in ((130, 1e-2), (700, 1e-2), (2300, 1e-3), (1500, 1e-10)):
     for a in (L, alpha, r["acq"], r["var"], r["mean"]):
         h.update(np.ascontiguousarray(a).tobytes())
     h.update(str((m.jitter_tries, r["best_idx"])).encode())
+    # one appended observation: the single-vector forward solve (a chain of workgroups in one launch, or per-block launches)
+    x_new = rng.uniform([-5, -5, -5], [5, 20, 5], (1, 3))
+    appended = m.append(x_new, np.sin(x_new).sum(1, keepdims=True))
+    L2, alpha2 = m.posterior_state()
+    h.update(str(appended).encode())
+    h.update(np.ascontiguousarray(L2).tobytes())
+    h.update(np.ascontiguousarray(alpha2).tobytes())
     m.close()
 print("DIGEST", h.hexdigest())
 """ % ROOT
     digests = {}
-    # "timeout": the fused launches with every strip giving up at its first wait (CBO_HIP_FUSED_SPIN_LIMIT=-1): the host
-    # repeats each factorisation with the separate-launch kernels inside the same call -- no error, same bits
-    for form, env in (("4", {}), ("2", {"CBO_HIP_PANEL_FORM": "2"}), ("timeout", {"CBO_HIP_FUSED_SPIN_LIMIT": "-1"})):
+    # "timeout": every poll of a launch-internal protocol gives up at once (CBO_HIP_FUSED_SPIN_LIMIT=-1: the strips of
+    # the fused diagonal + panel launches, the workgroup chains of the single-vector solves): the host repeats the
+    # factorisation with the separate-launch kernels / the solve with the per-block launches inside the same call -- no
+    # error, same bits.  "per-block": the single-vector solves as one launch per block (CBO_HIP_VEC_SOLVE_FORM=1).
+    variants = (("4", {}), ("2", {"CBO_HIP_PANEL_FORM": "2"}), ("timeout", {"CBO_HIP_FUSED_SPIN_LIMIT": "-1"}),
+                ("per-block", {"CBO_HIP_VEC_SOLVE_FORM": "1"}))
+    for form, env in variants:
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env),
                              capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         digests[form] = [ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][-1]
-    assert digests["4"] == digests["2"] == digests["timeout"], digests
+    assert len(set(digests.values())) == 1, digests
 
 
 def test_chain_launch_forms_give_the_same_bits_at_full_sizes(hip):
@@ -624,12 +635,13 @@ for n in (4096, 16384):
 print("DIGEST", h.hexdigest())
 """ % ROOT
     digests = {}
-    for form, env in (("4", {}), ("2", {"CBO_HIP_PANEL_FORM": "2"}), ("timeout", {"CBO_HIP_FUSED_SPIN_LIMIT": "-1"})):
+    for form, env in (("4", {}), ("2", {"CBO_HIP_PANEL_FORM": "2"}), ("timeout", {"CBO_HIP_FUSED_SPIN_LIMIT": "-1"}),
+                      ("per-block", {"CBO_HIP_VEC_SOLVE_FORM": "1"})):
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env),
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         digests[form] = [ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][-1]
-    assert digests["4"] == digests["2"] == digests["timeout"], digests
+    assert len(set(digests.values())) == 1, digests
 
 
 def test_optimizer_class_and_quotient_mirror_the_reference_call_sequence(hip):
