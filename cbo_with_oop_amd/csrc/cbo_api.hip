@@ -1072,6 +1072,10 @@ static int pipeline_pairs(const cbo_ctx *c, int64_t n_pad, int64_t m_pad)
         if (used_us > budget_us) break;
         ++pairs;
     }
+    // Several rounds of strips per CU and a short chain: the first pair's updates exceed what the chain hides, but they
+    // run at the strip kernel's own efficiency and take a pair of row blocks off the closing launch all the same
+    // (scripts/schedule_scan.py, 2048 x 65536: 5.34 ms with one pair against 5.67 without; profiles/r03_schedule_crossover.txt)
+    if (pairs == 0 && rounds >= 2.0 && nb >= 8 && nb <= 32) pairs = 1;
     return pairs;
 }
 
