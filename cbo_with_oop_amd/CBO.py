@@ -145,24 +145,39 @@ class CBOAcquisitionPath:
             grids = [self.candidate_grid(s) for s in range(self.es_size)]
             return find_next_y_points(self.models, current_best, self.exploration_set, self.costs, self.task, grids,
                                       cache=self._call_cache)
-        from .sharding import NO_CANDIDATE
+        from .sharding import ERROR_CANDIDATE, NO_CANDIDATE
         from .utils_functions.cost_functions import Cost
-        mine = [s for s in range(self.es_size) if mode == "candidates" or s % world == rank]
-        mine = [s for s in mine if not (mode == "candidates" and self.candidate_grid(s).empty_shard)]
-        local = {}
-        if mine:
-            grids = [self.candidate_grid(s) for s in mine]
-            # batch costs are those of the WHOLE grid (a variable cost sums |x| over the batch column)
-            full_cost = {s: float(Cost(self.costs, self.exploration_set[s]).evaluate(self.candidate_grid(s).full_points))
-                         for s in mine}
-            _, ys = find_next_y_points([self.models[s] for s in mine], current_best,
-                                       [self.exploration_set[s] for s in mine], _FixedCosts(full_cost, mine), self.task,
-                                       grids, cache=self._call_cache, raw=True)
-            local = {s: ys[i] for i, s in enumerate(mine)}
+        # A rank that fails (a model that is not positive definite, a device error) must not leave the others blocked in
+        # the exchange: it takes part in every exchange of the trial with an error record (NaN wins every reduction), and
+        # every rank raises once the exchanges are done.
+        local, failure = {}, None
+        try:
+            mine = [s for s in range(self.es_size) if mode == "candidates" or s % world == rank]
+            mine = [s for s in mine if not (mode == "candidates" and self.candidate_grid(s).empty_shard)]
+            if mine:
+                grids = [self.candidate_grid(s) for s in mine]
+                # batch costs are those of the WHOLE grid (a variable cost sums |x| over the batch column)
+                full_cost = {s: float(Cost(self.costs, self.exploration_set[s]).evaluate(self.candidate_grid(s).full_points))
+                             for s in mine}
+                _, ys = find_next_y_points([self.models[s] for s in mine], current_best,
+                                           [self.exploration_set[s] for s in mine], _FixedCosts(full_cost, mine), self.task,
+                                           grids, cache=self._call_cache, raw=True)
+                local = {s: ys[i] for i, s in enumerate(mine)}
+        except Exception as exc:  # noqa: BLE001 -- re-raised below, after the exchanges
+            failure = exc
+        winners, failed_somewhere = [], False
+        for s in range(self.es_size):
+            val, idx = (float("nan"), ERROR_CANDIDATE) if failure is not None else local.get(s, (-np.inf, NO_CANDIDATE))
+            val, idx = self.comm.argmax(val, idx)                       # identical on every rank
+            failed_somewhere = failed_somewhere or idx == ERROR_CANDIDATE
+            winners.append((val, idx))
+        if failure is not None:
+            raise failure
+        if failed_somewhere:
+            raise RuntimeError("compute_best_acquisition_values: another rank failed during this trial's sweep")
         xs, out = [], []
         for s in range(self.es_size):
-            val, idx = local.get(s, (-np.inf, NO_CANDIDATE))
-            val, idx = self.comm.argmax(val, idx)                       # identical on every rank
+            val, idx = winners[s]
             pts = self.grid_points(s)[1]
             x_new = pts[idx][None, :].copy()
             cost = Cost(self.costs, self.exploration_set[s])

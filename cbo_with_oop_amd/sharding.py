@@ -10,7 +10,7 @@ gather + local reduce.
 
 Launch layout: the one ``torch.distributed.run`` / ``mpirun`` produce -- RANK, WORLD_SIZE, LOCAL_RANK in the
 environment.  The 128-byte RCCL id travels from rank 0 to the others through a file in the temporary directory
-(single node; keyed by MASTER_PORT, the launcher's pid and its run id) -- the launcher's own TCP store belongs to
+(single node; a private file keyed by MASTER_PORT, the launcher's pid and run id, the user and the call's number) -- the launcher's own TCP store belongs to
 the launcher.
 
 Exploration sets are a second independent axis (src/CBO.py:249 loops over them): ``CBOAcquisitionPath`` places whole
@@ -49,12 +49,41 @@ def reduce_pairs(vals, idxs):
 
 
 NO_CANDIDATE = np.iinfo(np.int64).max     # index sent by a rank whose shard is empty
+ERROR_CANDIDATE = NO_CANDIDATE - 1        # index sent (with a NaN value, which wins every reduction) by a rank that failed
 ID_BYTES = 128
+_rendezvous_count = [0]                   # from_env calls made by this process: every rank counts the same calls
 
 
-def _id_path():
+def _id_path(generation=0):
+    """The rendezvous file of this launch: temp dir, MASTER_PORT, the launcher's run id and pid, and the number of the
+    from_env call (a second communicator of the same run never reads the first one's id)."""
     tag = "_".join(str(os.environ.get(k, "x")) for k in ("MASTER_PORT", "TORCHELASTIC_RUN_ID"))
-    return os.path.join(tempfile.gettempdir(), f"cbo_comm_{tag}_{os.getppid()}.id")
+    return os.path.join(tempfile.gettempdir(), f"cbo_comm_{tag}_{os.getppid()}_{os.getuid()}_{int(generation)}.id")
+
+
+def _publish_id(path, uid):
+    """Rank 0: the 128 bytes appear atomically (O_EXCL temporary, mode 0600, rename); a leftover of an earlier run that
+    crashed before its unlink is replaced."""
+    tmp = f"{path}.{os.getpid()}.tmp"
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+    try:
+        os.write(fd, uid)
+    finally:
+        os.close(fd)
+    os.replace(tmp, path)
+
+
+def _read_id(path):
+    """Other ranks: only a regular file of exactly 128 bytes that this user owns and nobody else can write."""
+    fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+    try:
+        st = os.fstat(fd)
+        import stat
+        if not stat.S_ISREG(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o022) or st.st_size != ID_BYTES:
+            raise _lib.CboHipError(_lib.CBO_ERR_COMM, f"refusing the communicator id file {path}: not a private 128-byte file of this user")
+        return os.read(fd, ID_BYTES)
+    finally:
+        os.close(fd)
 
 
 class Communicator:
@@ -87,21 +116,18 @@ class Communicator:
             return None
         world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
         ctx = context if context is not None else _lib.Context.get()
-        path = _id_path()
+        _rendezvous_count[0] += 1
+        path = _id_path(_rendezvous_count[0])
         if rank == 0:
             uid = cls.unique_id()
-            tmp = f"{path}.{os.getpid()}.tmp"
-            with open(tmp, "wb") as f:
-                f.write(uid)
-            os.replace(tmp, path)                       # atomic: a reader sees all 128 bytes or no file
+            _publish_id(path, uid)                      # atomic: a reader sees all 128 bytes or no file
         else:
             deadline = time.monotonic() + timeout_s
             while not os.path.exists(path):
                 if time.monotonic() > deadline:
                     raise _lib.CboHipError(_lib.CBO_ERR_COMM, f"rank {rank}: no communicator id at {path}")
                 time.sleep(0.01)
-            with open(path, "rb") as f:
-                uid = f.read()
+            uid = _read_id(path)
         comm = cls(ctx, world, rank, uid)
         comm.barrier()                                   # every rank has read the id
         if rank == 0:

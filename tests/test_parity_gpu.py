@@ -1530,6 +1530,51 @@ def test_path_placement_over_ranks_equals_single_process(hip, world):
         assert np.allclose(vals, single_vals, rtol=1e-13, atol=0)
 
 
+def test_path_failure_on_one_rank_reaches_every_rank(hip, monkeypatch):
+    """Multi-rank CBOAcquisitionPath: a rank whose sweep raises still takes part in every exchange of the trial (with an
+    error record) and re-raises afterwards; a rank that sees another rank's error record raises too -- nobody is left
+    blocked in the all-gather."""
+    from cbo_with_oop_amd import CBO as cbo_module, CBOAcquisitionPath, GaussianProcessType
+    from cbo_with_oop_amd.graphs import ToyGraph
+    from cbo_with_oop_amd.sharding import ERROR_CANDIDATE
+    rng = np.random.default_rng(2)
+    es = ToyGraph.get_exploration_set("MIS")
+    xs = [rng.uniform(-5, 5, (20, 1)), rng.uniform(-5, 20, (20, 1))]
+    ys = [ToyGraph.target_do_x(xs[0]), ToyGraph.target_do_z(xs[1])]
+
+    class Comm:
+        def __init__(self, world, rank, poisoned=False):
+            self.world, self.rank, self.poisoned, self.calls = world, rank, poisoned, []
+
+        def argmax(self, val, idx):
+            self.calls.append((val, idx))
+            return (float("nan"), ERROR_CANDIDATE) if self.poisoned else (val, idx)
+
+    def make(comm):
+        path = CBOAcquisitionPath(GaussianProcessType.NON_CAUSAL_GP, es, ToyGraph.get_cost_structure(1), "min", xs, ys,
+                                  [ToyGraph.bounds(s) for s in es], grid_shapes=[[64], [64]], comm=comm)
+        path.update_all_gaussian_processes()
+        return path
+
+    # this rank fails: both exchanges still happen, with the error record, then the original exception surfaces
+    comm = Comm(2, 0)
+    path = make(comm)
+
+    def boom(*a, **k):
+        raise ValueError("sweep failed on this rank")
+    monkeypatch.setattr(cbo_module, "find_next_y_points", boom)
+    with pytest.raises(ValueError, match="sweep failed on this rank"):
+        path.compute_best_acquisition_values(0.0)
+    assert len(comm.calls) == len(es) and all(i == ERROR_CANDIDATE and np.isnan(v) for v, i in comm.calls)
+    monkeypatch.undo()
+    # another rank failed: this rank's own sweep is fine, the exchange returns the error record
+    comm = Comm(2, 0, poisoned=True)
+    path = make(comm)
+    with pytest.raises(RuntimeError, match="another rank failed"):
+        path.compute_best_acquisition_values(0.0)
+    assert len(comm.calls) == len(es)
+
+
 def test_prediction_gradients_for_a_whole_grid(hip, monkeypatch):
     """cbo_gp_predict_gradients at M = 20480 points (forward sweep + backward substitution through the same strip kernel
     on the reversed factor), ARD lengthscales, against the oracle; then the same with the workspace cut into chunks."""

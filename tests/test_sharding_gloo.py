@@ -72,3 +72,36 @@ def test_more_ranks_than_candidates(tmp_path):
     """Empty shards must not win (their index is the NO_CANDIDATE sentinel)."""
     from cbo_with_oop_amd.sharding import shard_bounds
     assert shard_bounds(2, 4, 3) == (2, 2)
+
+
+def test_rendezvous_file_is_private_atomic_and_per_call(tmp_path, monkeypatch):
+    """The id file of Communicator.from_env: created exclusively with mode 0600 and renamed into place, a different name
+    for every from_env call of a run, and a reader refuses anything that is not a private 128-byte file of this user."""
+    import stat
+    from cbo_with_oop_amd import _lib, sharding
+    monkeypatch.setattr(sharding.tempfile, "gettempdir", lambda: str(tmp_path))
+    monkeypatch.setenv("MASTER_PORT", "29511")
+    p1, p2 = sharding._id_path(1), sharding._id_path(2)
+    assert p1 != p2 and str(os.getppid()) in p1 and p1.startswith(str(tmp_path))
+    uid = bytes(range(128))
+    sharding._publish_id(p1, uid)
+    assert stat.S_IMODE(os.stat(p1).st_mode) == 0o600 and sharding._read_id(p1) == uid
+    sharding._publish_id(p1, uid[::-1])                                  # a leftover is replaced, atomically
+    assert sharding._read_id(p1) == uid[::-1]
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".tmp")]
+    with open(p2, "wb") as f:
+        f.write(b"short")
+    with pytest.raises(_lib.CboHipError):
+        sharding._read_id(p2)
+    os.chmod(p1, 0o666)
+    with pytest.raises(_lib.CboHipError):
+        sharding._read_id(p1)
+
+
+def test_a_failed_rank_wins_every_reduction_with_its_error_record():
+    """A rank that failed contributes (NaN, ERROR_CANDIDATE): NaN is maximal in the library's reduction, so every rank
+    sees the error index and raises instead of waiting for a record that never comes."""
+    from cbo_with_oop_amd.sharding import ERROR_CANDIDATE, NO_CANDIDATE, reduce_pairs
+    val, idx = reduce_pairs([0.3, float("nan"), 0.9], [5, ERROR_CANDIDATE, 77])
+    assert idx == ERROR_CANDIDATE and np.isnan(val)
+    assert ERROR_CANDIDATE != NO_CANDIDATE
