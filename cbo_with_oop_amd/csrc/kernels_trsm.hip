@@ -1101,154 +1101,6 @@ __global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restri
     __builtin_amdgcn_s_barrier();
 }
 
-// The right-looking update with two waves per SIMD (512 threads, KB = 32): trsm_update_kernel's chunk of row blocks and
-// stage pipeline, the rows of a block split over a wave pair as in trsm_strip8_kernel (waves (cw, 0/1) share column group
-// cw's B fragments and own row tiles 0-3 / 4-7).  Same operations per element in the same order: same bits.
-constexpr int kAccMoves8 = kTH * 4;       // global loads (next block's C) or stores (this block's C) per lane and block
-
-__global__ __launch_bounds__(512) void trsm_update8_kernel(const double *__restrict__ U, int64_t ldu, const double *V,
-                                                           int64_t ldv, double *C, int64_t ldc, int k0, int klen,
-                                                           int i0_begin, int i0_end, int chunk_rows, int upper_only,
-                                                           const int *__restrict__ skip_if)
-{
-    if (skip_if && __builtin_nontemporal_load(skip_if) != 0) return;
-    constexpr int KB = 32;
-    using G = StageGeom<KB>;
-    constexpr int kA = G::kA, kB = G::kB, kKS = G::kKS;
-    constexpr int kRows8 = KB / 8, kDma8 = kRows8 + 2;
-    __shared__ __align__(16) double lds[kNBuf * (kA + kB)];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cw = wave & 3, h = wave >> 2;
-    const int lc = lane & 15, kq = lane >> 4;
-    const int64_t colw = (int64_t)blockIdx.x * kStrip + cw * 16;
-    const int ib = i0_begin + (int)blockIdx.y * chunk_rows;
-    const int ie = (ib + chunk_rows < i0_end) ? ib + chunk_rows : i0_end;
-    if (ib >= ie) return;                                              // uniform for the workgroup
-    if (upper_only && (int)blockIdx.x * kStrip + kStrip <= ib) return;  // every column left of every row: lower part
-    const int nst = klen / KB;
-    double *Cc = C + colw + lc;
-    double *ldsB = lds + kNBuf * kA;
-    const unsigned lds_byte0 = lds_byte_address(lds);
-    const double *ug = U + (int64_t)(k0 + wave * kRows8) * ldu + lane * 2;
-    const double *vg = V + (int64_t)(k0 + (lane >> 3) + 16 * h) * ldv + colw + 2 * (lane & 7);
-    const int64_t b_stride = 8 * ldv;
-
-    int ci0 = ib, cj = 0;
-    const double *a_src, *b_src;
-    auto locate = [&]() __attribute__((always_inline)) {
-        const bool past = ci0 >= ie;
-        const int ai0 = past ? ie - kRB : ci0;
-        const int aj = past ? nst - 1 : cj;
-        a_src = ug + (int64_t)(KB * aj) * ldu + ai0;
-        b_src = vg + (int64_t)(KB * aj) * ldv;
-    };
-    auto advance = [&]() __attribute__((always_inline)) {
-        const int wrap = (cj + 1 == nst) ? 1 : 0;
-        ci0 += kRB * wrap;
-        cj = (cj + 1) * (1 - wrap);
-        locate();
-    };
-    auto issue_one = [&](int buf, int i) __attribute__((always_inline)) {
-        if (i < kRows8) {
-            const unsigned la = __builtin_amdgcn_readfirstlane(lds_byte0 + 8u * (unsigned)(buf * kA + (wave * kRows8) * kLdsLd));
-            glds16(a_src + (int64_t)i * ldu, la + 8u * (unsigned)(i * kLdsLd));
-        } else {
-            const unsigned lb = __builtin_amdgcn_readfirstlane(
-                lds_byte0 + 8u * (unsigned)(kNBuf * kA + buf * kB + cw * (KB * 16) + (2 * h) * 128));
-            glds16(b_src + (i - kRows8) * b_stride, lb + 8u * (unsigned)((i - kRows8) * 128));
-        }
-    };
-
-    // acc = -C for this wave's four row tiles
-    d4 acc[kTH], accn[kTH];
-#pragma unroll
-    for (int t = 0; t < kTH; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = -Cc[(int64_t)(ib + 16 * (kTH * h + t) + kq + 4 * r) * ldc];
-
-    locate();
-#pragma unroll
-    for (int i = 0; i < kDma8; ++i) issue_one(0, i);
-    advance();
-#pragma unroll
-    for (int i = 0; i < kDma8; ++i) issue_one(1, i);
-    advance();
-
-    int buf = 0;
-    int boundary = 0;               // as in trsm_update_kernel: stage tops near a block boundary allow the C moves too
-    for (int i0 = ib; i0 < ie; i0 += kRB) {
-        double af[2][kTH], bf[2];
-        bool deferred = false;
-        for (int j = 0; j < nst; ++j) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (boundary) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma8 + kAccMoves8) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma8) : "memory");
-            __builtin_amdgcn_s_barrier();
-            boundary = (boundary > 0) ? boundary - 1 : 0;
-            if (j == 0 && i0 + kRB < ie) {
-                // next block's C, ahead of this stage's DMA in issue order
-#pragma unroll
-                for (int t = 0; t < kTH; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        accn[t][r] = -Cc[(int64_t)(i0 + kRB + 16 * (kTH * h + t) + kq + 4 * r) * ldc];
-                asm volatile("" ::: "memory");
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const int bnext = (buf >= 1) ? buf - 1 : 2;
-            const double *abase = lds + buf * kA + kq * kLdsLd + lc + 64 * h;
-            const double *bbase = ldsB + buf * kB + cw * (KB * 16) + kq * 16 + lc;
-#pragma unroll
-            for (int t = 0; t < kTH; ++t) {
-                if (deferred) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
-                if (t < kTH / 2) {
-                    af[0][2 * t] = abase[32 * t];
-                    af[0][2 * t + 1] = abase[32 * t + 16];
-                } else if (t == kTH / 2) {
-                    bf[0] = bbase[0];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int jj = 0; jj < kKS - 1; ++jj) {
-                const double *an = abase + 4 * (jj + 1) * kLdsLd;
-#pragma unroll
-                for (int t = 0; t < kTH; ++t) {
-                    acc[t] = MFMA_F64(af[jj & 1][t], bf[jj & 1], acc[t]);
-                    if (t < kTH / 2) {
-                        af[(jj + 1) & 1][2 * t] = an[32 * t];
-                        af[(jj + 1) & 1][2 * t + 1] = an[32 * t + 16];
-                    } else if (t == kTH / 2) {
-                        bf[(jj + 1) & 1] = bbase[4 * (jj + 1) * 16];
-                    } else if (jj < kDma8) {
-                        issue_one(bnext, jj);
-                    } else if (jj == kDma8) {
-                        advance();
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            deferred = true;
-            buf = (buf == 2) ? 0 : buf + 1;
-        }
-#pragma unroll
-        for (int t = 0; t < kTH; ++t) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
-#pragma unroll
-        for (int t = 0; t < kTH; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Cc[(int64_t)(i0 + 16 * (kTH * h + t) + kq + 4 * r) * ldc] = -acc[t][r];
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int t = 0; t < kTH; ++t) acc[t] = accn[t];
-        boundary = 2;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
-
 void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const double *invDt, double *V, int64_t ldv,
                         int64_t n, int64_t m_pad, const double *z, double *q, double *mu, bool accumulate,
                         bool half_lds)
@@ -1307,16 +1159,11 @@ void launch_gemm_update(hipStream_t s, const double *U, int64_t ldu, const doubl
     const unsigned chunks = (unsigned)((i0_end - i0_begin + chunk_rows - 1) / chunk_rows);
     const dim3 grid((unsigned)(m_pad / kStrip), chunks);
     const int up = upper_only ? 1 : 0;
-    // CBO_HIP_UPDATE_FORM: 8 = the two-waves-per-SIMD kernel wherever this function is called, 4 = never; default: where
-    // a workgroup has the CU to itself (not half_lds)
-    static const int update_form = [] {
-        const char *e = getenv("CBO_HIP_UPDATE_FORM");
-        return e ? atoi(e) : 0;
-    }();
-    if ((update_form == 8 || (!half_lds && update_form != 4)))
-        hipLaunchKernelGGL(trsm_update8_kernel, grid, dim3(512), 0, s, U, ldu, V, ldv, C, ldc, k0, klen, i0_begin, i0_end,
-                           chunk_rows, up, skip_if);
-    else if (!half_lds)
+    // (A two-waves-per-SIMD form of this kernel, rows split over a wave pair as in trsm_strip8_kernel, was measured in
+    // round 3 and dropped: its K-loops are only 4-8 stages long between C moves, and two independent half-LDS workgroups
+    // per CU hide those block boundaries better -- 16384-point factorisation 32.0 ms with KB = 16 x 2 workgroups,
+    // 37.6-37.9 ms with either full-LDS form; C2 overlapped step 5.73 vs 6.17-6.27 ms.)
+    if (!half_lds)
         hipLaunchKernelGGL(trsm_update_kernel<32>, grid, dim3(256), 0, s, U, ldu, V, ldv, C, ldc, k0, klen, i0_begin,
                            i0_end, chunk_rows, up, skip_if);
     else
