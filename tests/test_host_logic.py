@@ -142,3 +142,32 @@ def test_lockstep_lbfgs_reaches_scipys_optima_in_one_call_per_round():
     # a start already at a bound-constrained optimum stays there
     Xb, Fb = lockstep_lbfgs(lambda X: (X[:, 0], np.tile([1.0, 0.0], (len(X), 1))), np.array([[3.0, 0.0]]), lo, hi)
     assert np.allclose(Xb, [[3.0, 0.0]]) and np.isclose(Fb[0], 3.0)
+
+
+def test_bench_configs_are_the_baseline_shapes_and_shard_as_stated():
+    """bench.py --config c2..c5: BASELINE.json's sizes, the reference's interventional ranges, weak scaling stacks one
+    grid per rank, strong scaling cuts the ONE grid, and an 8-GPU config on fewer ranks keeps 1/8 per rank unless told."""
+    import bench
+    from cbo_with_oop_amd.graphs import CompleteGraph, CoralGraph, SimplifiedCoralGraph
+    from cbo_with_oop_amd.sharding import shard_bounds
+    c = bench.CONFIGS
+    assert (c["c2"]["n_obs"], np.prod(c["c2"]["grid"])) == (4096, 16384)
+    assert (c["c3"]["n_obs"], np.prod(c["c3"]["grid"])) == (8192, 65536)
+    assert (c["c4"]["n_obs"], np.prod(c["c4"]["grid"])) == (16384, 262144) and c["c4"]["dtype"] == "f64"
+    assert (c["c5"]["n_obs"], np.prod(c["c5"]["grid"])) == (16384, 262144) and c["c5"]["dtype"] == "f32"
+    assert c["c3"]["box"] == [tuple(map(float, b)) for b in CompleteGraph.bounds(["B", "D", "E"])]
+    assert c["c4"]["box"] == [tuple(map(float, b)) for b in SimplifiedCoralGraph.bounds(["N", "O", "T"])]
+    assert c["c5"]["box"] == [tuple(map(float, b)) for b in CoralGraph.bounds(["N", "O", "T"])]
+    small = dict(c["c3"], n_obs=64, grid=(8, 4, 4))                       # the same code path on a small stand-in
+    X, y, Xs, grid, note = bench.make_problem(small, 4, "weak", False)
+    assert X.shape == (64, 3) and Xs.shape[0] == 4 * 128 and grid == (8, 4, 16)
+    X, y, Xs, grid, note = bench.make_problem(small, 4, "strong", False)
+    assert Xs.shape[0] == 128 and grid == (8, 4, 4) and "4 contiguous shard" in note
+    assert sum(e - b for b, e in (shard_bounds(128, 4, r) for r in range(4))) == 128
+    eight = dict(c["c4"], n_obs=64, grid=(8, 8, 8))
+    _, _, Xs1, _, note1 = bench.make_problem(eight, 1, "strong", False)
+    _, _, Xs2, _, _ = bench.make_problem(eight, 2, "strong", False)
+    _, _, Xs8, _, _ = bench.make_problem(eight, 8, "strong", False)
+    _, _, Xsf, _, _ = bench.make_problem(eight, 1, "strong", True)
+    assert (Xs1.shape[0], Xs2.shape[0], Xs8.shape[0], Xsf.shape[0]) == (64, 128, 512, 512) and "1/8" in note1
+    assert np.array_equal(Xs1, Xs8[:64])                                   # rank 0's shard of the 8-GPU run
