@@ -790,6 +790,36 @@ def test_bench_exchange_over_rccl_single_rank(hip):
     assert b["n_gpus"] == 1 and "RCCL" in b["config"]["exchange"] and "RCCL" not in a["config"]["exchange"]
 
 
+def test_bench_lines_of_the_other_configs_carry_the_contract(hip):
+    """bench.py --config c1 and --config c3 (a short run each): one JSON line with the contract's fields, the config's own
+    workload string, a roofline object, and -- c1 -- the CPU oracle taking the same decision."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+
+    def line(*args):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), env=env, capture_output=True,
+                             text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+
+    c1 = line("--config", "c1", "--steps", "200")
+    c3 = line("--config", "c3", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--post-steps", "1")
+    for d, cfg in ((c1, "c1"), (c3, "c3")):
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                    "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert key in d, (cfg, key)
+        assert d["config"]["config"] == cfg and d["unit"] == "acquisitions/s" and d["vs_baseline"] is None
+        assert d["roofline"]["bound"] == "mfma" and d["roofline"]["peak"] == 78.6
+    assert c1["config"]["candidates_total"] == 400 and c1["cpu_baseline"]["same_choice"] is True
+    assert c3["scaling"] == "strong" and c3["config"]["candidates_total"] == 65536 and c3["config"]["n_obs"] == 8192
+    assert 0.5 < c3["roofline"]["isolated"]["frac"] < 1.0
+
+
 def test_communicator_through_the_c_abi(hip):
     """cbo_comm_* with one rank (all a one-GPU box can form): both ways of forming the communicator, the arg-max
     exchange, the max reduction, and the empty-shard sentinel."""
