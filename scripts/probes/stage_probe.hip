@@ -20,7 +20,7 @@ __device__ __forceinline__ void glds16(const double *gsrc, unsigned lds_dst)
 }
 constexpr int kLd = 144, kA = 32 * kLd, kB = 4 * 32 * 16;
 
-template <int MODE>
+template <int MODE, int VAR = 0>
 __global__ __launch_bounds__((MODE & 8) ? 512 : 256) void probe(const double *src, int64_t ld, double *out, int stages,
                                                                unsigned long long *clk)
 {
@@ -38,6 +38,7 @@ __global__ __launch_bounds__((MODE & 8) ? 512 : 256) void probe(const double *sr
     double af[2][NT], bf[2];
     for (int t = 0; t < NT; ++t) af[0][t] = af[1][t] = 1.0 + 1e-9 * lane;
     bf[0] = bf[1] = 0.5;
+    double sink = 0.0;
     const double *g = src + (int64_t)(blockIdx.x & 7) * 64 * ld + lane * 2;     // a few MB, L2 resident
     int buf = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -58,11 +59,23 @@ __global__ __launch_bounds__((MODE & 8) ? 512 : 256) void probe(const double *sr
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const double *an = abase + 4 * ((jj + 1) & 7) * kLd;
+            if (VAR == 2 && (MODE & 1)) {                 // all LDS reads of the k-step first
+#pragma unroll
+                for (int t = 0; t < NT / 2; ++t) {
+                    af[(jj + 1) & 1][2 * t] = an[32 * t];
+                    af[(jj + 1) & 1][2 * t + 1] = an[32 * t + 16];
+                }
+                bf[(jj + 1) & 1] = bbase[4 * ((jj + 1) & 7) * 16];
+                FENCE();
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[t] = MFMA(af[jj & 1][t], bf[jj & 1], acc[t]);
-                if (MODE & 1) {
-                    if (t < NT / 2) {
+                if ((MODE & 1) && VAR != 2) {
+                    if (VAR == 3) {                       // reads issued, results never used by an MFMA
+                        if (t < NT / 2) { sink += an[32 * t] + an[32 * t + 16]; }
+                        else if (t == NT / 2) sink += bbase[4 * ((jj + 1) & 7) * 16];
+                    } else if (t < NT / 2) {
                         af[(jj + 1) & 1][2 * t] = an[32 * t];
                         af[(jj + 1) & 1][2 * t + 1] = an[32 * t + 16];
                     } else if (t == NT / 2) {
@@ -73,7 +86,7 @@ __global__ __launch_bounds__((MODE & 8) ? 512 : 256) void probe(const double *sr
                     glds16(gs + (int64_t)(dma % (32 / NW)) * ld, la + 8u * (unsigned)((dma % (32 / NW)) * kLd));
                     ++dma;
                 }
-                FENCE();
+                if (VAR != 1) FENCE();
             }
         }
         buf = (buf == 2) ? 0 : buf + 1;
@@ -84,7 +97,7 @@ __global__ __launch_bounds__((MODE & 8) ? 512 : 256) void probe(const double *sr
     __syncthreads();
     double sum = 0;
     for (int t = 0; t < NT; ++t) sum += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
-    out[(int64_t)blockIdx.x * blockDim.x + tid] = sum + lds[tid];
+    out[(int64_t)blockIdx.x * blockDim.x + tid] = sum + lds[tid] + sink;
     if (blockIdx.x == 0 && tid == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
 }
 
@@ -162,16 +175,16 @@ void run2(const char *name, const double *src, int64_t ld, double *out, int skew
     printf("%-58s %.3f ms  %.1f TF\n", name, ms, flops / ms / 1e9);
 }
 
-template <int MODE>
+template <int MODE, int VAR = 0>
 void run(const char *name, const double *src, int64_t ld, double *out, unsigned long long *clk)
 {
     const int stages = 2000, threads = (MODE & 8) ? 512 : 256, blocks = 256;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(threads), 0, 0, src, ld, out, 20, clk);
+    hipLaunchKernelGGL((probe<MODE, VAR>), dim3(blocks), dim3(threads), 0, 0, src, ld, out, 20, clk);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(threads), 0, 0, src, ld, out, stages, clk);
+    hipLaunchKernelGGL((probe<MODE, VAR>), dim3(blocks), dim3(threads), 0, 0, src, ld, out, stages, clk);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -203,6 +216,11 @@ int main()
     run<11>("8 waves + LDS reads + DMA", src, ld, out, clk);
     run<13>("8 waves + LDS reads + barrier", src, ld, out, clk);
     run<15>("8 waves + LDS reads + DMA + barrier", src, ld, out, clk);
+    run<9, 1>("8 waves + LDS reads, compiler's own order (no fences)", src, ld, out, clk);
+    run<9, 2>("8 waves + LDS reads, reads of a k-step bunched first", src, ld, out, clk);
+    run<9, 3>("8 waves + LDS reads whose results no MFMA uses", src, ld, out, clk);
+    run<15, 1>("8 waves everything, compiler's own order", src, ld, out, clk);
+    run<15, 2>("8 waves everything, reads bunched first", src, ld, out, clk);
     run2("2 workgroups/CU x 4 waves, 16-row stages, everything", src, ld, out, 0);
     run2("  the same, the two workgroups started out of phase", src, ld, out, 1);
     return 0;
