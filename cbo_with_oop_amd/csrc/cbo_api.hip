@@ -433,6 +433,43 @@ extern "C" int cbo_synchronize(cbo_ctx *c)
     return CBO_OK;
 }
 
+#ifdef CBO_DIAG_KNOBS
+// Timing-only (diagnostic build): the LDS-staged update kernel alone, C[klen:n, :] -= U[0:klen, klen:n]^T U[0:klen, :] on
+// an n x n array of noise (upper part only when `upper`), `reps` launches between two events -- the bulk trailing
+// update of a factorisation at a given K (scripts/update_kernel_timing.py).
+__global__ void diag_fill_kernel(double *p, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = 1e-3 * (double)((i * 2654435761u) & 1023u) - 0.5;
+}
+extern "C" int cbo_diag_update_kernel_time(cbo_ctx *c, int n, int klen, int chunk_blocks, int half_lds, int upper, int reps,
+                                           double *ms_out)
+{
+    if (!c || !ms_out) return fail(CBO_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t lda = (int64_t)n + 80;
+    double *A = nullptr;
+    HIP_TRY(hipMalloc(&A, sizeof(double) * (size_t)n * (size_t)lda));
+    hipLaunchKernelGGL(diag_fill_kernel, dim3(4096), dim3(256), 0, c->stream, A, (int64_t)n * lda);
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    launch_gemm_update(c->stream, A, lda, A, lda, A, lda, 0, klen, klen, n, n, chunk_blocks, half_lds != 0, upper != 0, nullptr);
+    HIP_TRY(hipEventRecord(a, c->stream));
+    for (int r = 0; r < reps; ++r)
+        launch_gemm_update(c->stream, A, lda, A, lda, A, lda, 0, klen, klen, n, n, chunk_blocks, half_lds != 0, upper != 0, nullptr);
+    HIP_TRY(hipEventRecord(b, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    *ms_out = (double)ms / reps;
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    hipFree(A);
+    return CBO_OK;
+}
+#endif
+
 extern "C" int cbo_set_profiling(cbo_ctx *c, int enabled)
 {
     if (!c) return fail(CBO_ERR_INVALID, "ctx is NULL");

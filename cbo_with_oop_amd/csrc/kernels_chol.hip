@@ -801,14 +801,16 @@ __device__ __forceinline__ double coherent_load(const double *p)
 __global__ __launch_bounds__(256) void potrf_panel_fused_kernel(double *A, int64_t lda, int r0, int rcol,
                                                                 double *__restrict__ invDt, int *info,
                                                                 double *__restrict__ zvec, int col0, int *flag,
-                                                                int spin_limit)
+                                                                int spin_limit, int strip_base)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (__builtin_nontemporal_load(info) != 0) return;      // an earlier block met a non-positive pivot: abandoned
-    if (blockIdx.x == 0) {
+    // strip_base == 1: workgroup 0 is the diagonal block, workgroups 1.. the strips (one launch); strip_base == 0: a
+    // launch of strips only (no LDS at all), behind a one-workgroup launch of the block (the split form, see launch_panel_fused)
+    if (strip_base == 1 && blockIdx.x == 0) {
         Diag2Shared &sh = *reinterpret_cast<Diag2Shared *>(smem_raw);
         {
             const unsigned s0 = lds_byte_address(&sh.S[0][0]);
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(256) void potrf_panel_fused_kernel(double *A, int64
     }
     // ---- a strip: 16 columns per wave
     const int lc = lane & 15, kq = lane >> 4;
-    double *Ac = A + (int64_t)r0 * lda + col0 + (int64_t)(blockIdx.x - 1) * kStrip + wave * 16 + lc;
+    double *Ac = A + (int64_t)r0 * lda + col0 + (int64_t)((int)blockIdx.x - strip_base) * kStrip + wave * 16 + lc;
     d4 acc[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -905,11 +907,22 @@ __global__ __launch_bounds__(256) void potrf_panel_fused_kernel(double *A, int64
     }
 }
 
+// split: the block as a one-workgroup launch (a whole CU's LDS), then the strips as a launch of their own that needs NO
+// LDS: beside a device full of half-LDS update workgroups (the bulk trailing update of a large factorisation, a
+// pipelined sweep) a strip workgroup then fits the slot any finishing update workgroup leaves, instead of waiting for
+// a CU to drain completely -- 255 strips at 16384 points otherwise wait for the bulk update to end (profiles/r03b_*).
 void launch_panel_fused(hipStream_t s, double *A, int64_t lda, int r0, int rcol, double *invDt, int *info, double *zvec,
-                        int n_cols, int *flag, int spin_limit, hipEvent_t done = nullptr)
+                        int n_cols, int *flag, int spin_limit, hipEvent_t done = nullptr, bool split = false)
 {
-    hipExtLaunchKernelGGL(potrf_panel_fused_kernel, dim3(1u + (unsigned)(n_cols / kStrip)), dim3(256), sizeof(Diag2Shared),
-                          s, nullptr, done, 0, A, lda, r0, rcol, invDt, info, zvec, r0 + 128, flag, spin_limit);
+    if (!split) {
+        hipExtLaunchKernelGGL(potrf_panel_fused_kernel, dim3(1u + (unsigned)(n_cols / kStrip)), dim3(256), sizeof(Diag2Shared),
+                              s, nullptr, done, 0, A, lda, r0, rcol, invDt, info, zvec, r0 + 128, flag, spin_limit, 1);
+        return;
+    }
+    hipLaunchKernelGGL(potrf_panel_fused_kernel, dim3(1u), dim3(256), sizeof(Diag2Shared), s, A, lda, r0, rcol, invDt, info,
+                       zvec, r0 + 128, flag, spin_limit, 1);
+    hipExtLaunchKernelGGL(potrf_panel_fused_kernel, dim3((unsigned)(n_cols / kStrip)), dim3(256), 0, s, nullptr, done, 0, A,
+                          lda, r0, rcol, invDt, info, zvec, r0 + 128, flag, spin_limit, 0);
 }
 
 // Set by the host around the repeat of a factorisation whose fused launch gave up (kCholFusedTimeout): the repeat uses
@@ -1745,7 +1758,8 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     };
     const int np = (int)(n_pad / 128);
     // info_dev[0] is the status word; info_dev[1 + 2p], [2 + 2p] the publication counts of panel p's fused launch
-    const bool fused = panel_form == 4 && 2 * np <= kCholFlagSlots;
+    const bool fused = (panel_form == 4 || panel_form == 5) && 2 * np <= kCholFlagSlots;
+    const bool split = panel_form == 5;
     // (a launch, not hipMemsetAsync: the runtime's fill costs two kernels and ~8 us of marker gaps around each)
     hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(256), 0, s, info_dev, fused ? 1 + 2 * np : 1);
     int *flags = info_dev + 1;
@@ -1769,7 +1783,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     double *zvec = pipe ? pipe->zvec : nullptr;
     // beside a pipelined sweep the panel solves use the half-LDS kernel, which fits next to a sweep workgroup
     const bool half_lds = pipe && pipe->half_lds;
-    const bool lean_panel = ((panel_form == 2 || panel_form == 4) && !pipe) || panel_form == 3;
+    const bool lean_panel = ((panel_form == 2 || panel_form == 4 || panel_form == 5) && !pipe) || panel_form == 3;
     int pair = 0;
     auto sweep_rows = [&](int r0, int klen) {
         if (pipe && r0 < pipe->tail_begin) sweep_pipe_pair(*pipe, s, A, lda, invDt, n_pad, pair++, r0, klen);
@@ -1782,10 +1796,33 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     // pair p to finish, and bulk(p) follows it on the side stream without a gap -- large factorisations are bound by
     // the bulk updates alone, small ones by the chain alone.
     int pending = -1;                      // event index of the bulk update still in flight
+    // Large trailing matrices, groups of two pairs (CBO_HIP_BULK_GROUP=1: pairs only).  The bulk update is the LDS-staged
+    // GEMM kernel, whose rate grows with K (16384 points, upper part: 45-51 TFLOP/s at K = 256, 53-57 at K = 512:
+    // scripts/update_kernel_timing.py), and it accumulates into C sequentially from C's own value, so one K = 512 pass
+    // gives the bits of two K = 256 passes.  Group j = pairs (2j, 2j+1); G_g = the 512 rows of group g:
+    //   side :  [wait pair 2j+1]  bigA(j): G_{j+2} -= group j;  bigB(j): everything below G_{j+2} -= group j   (K = 512)
+    //   chain:  pair 2j;   rows of pair 2j+1 -= pair 2j (rows kernel, as ever);  [wait bigA(j-1)]  near: G_{j+1} -= pair 2j
+    //           pair 2j+1; rows of pair 2j+2 -= pair 2j+1 (rows kernel);  near: rows of pair 2j+3 -= pair 2j+1
+    // -- every row still receives the pairs in order, each through the kernel that applied it before (rows kernel for
+    // the pair right above, GEMM kernel otherwise): the factor is bit-identical to the pairs-only schedule.  The chain
+    // only ever waits for bigA (512 rows, first on the side stream after the previous bigB), so bigB(j) has the whole
+    // chain of group j+1 to finish and bigB(j+1) follows it without a gap.  The near updates (K = 256, 512 + 256 rows
+    // per group) are the price: they run on the chain stream beside the bulk update.  Groups are used while both
+    // pairs' bulk updates would take the GEMM form anyway; the last ~6000 rows go pair by pair as before.
+    static const int bulk_group = [] { const char *e = std::getenv("CBO_HIP_BULK_GROUP"); return e ? std::atoi(e) : 2; }();
+    static const bool group_split = [] { const char *e = std::getenv("CBO_HIP_GROUP_SPLIT"); return !(e && std::atoi(e) == 0); }();
+    bool second_of_group = false;          // this pair closes a group whose first pair went without a bulk update
+    int pending_big_a = -1;                // event index of the last bigA
     for (int k = 0; k < np; k += 2) {
         const int r0 = 128 * k;
         const int n2 = (int)n_pad - r0 - 128;
-        if (fused && n2 > 0) launch_panel_fused(s, A, lda, r0, rcol, invDt, info_dev, zvec, n2, flags + 2 * (r0 / 128), spin_limit);
+        const int n3_pair = (int)n_pad - r0 - 256;                   // rows below this pair
+        const bool first_of_group = !second_of_group && bulk_group == 2 && (fused || lean_panel) && syrk_rows_form == 2 &&
+                                    n3_pair - 512 >= syrk_gemm_rows && n3_pair - 512 >= 512;
+        const bool grouped = first_of_group || second_of_group;
+        // beside a bulk update that fills the device the strips go as an LDS-free launch of their own (launch_panel_fused)
+        const bool split_now = split || (grouped && group_split && panel_form == 4);
+        if (fused && n2 > 0) launch_panel_fused(s, A, lda, r0, rcol, invDt, info_dev, zvec, n2, flags + 2 * (r0 / 128), spin_limit, nullptr, split_now);
         else launch_diag(r0);
         if (n2 <= 0) { sweep_rows(r0, 128); break; }
         if (fused) {}
@@ -1802,10 +1839,10 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         const bool gemm_form = bulk && n3 - 256 >= syrk_gemm_rows;
         // the event the side stream waits for completes WITH the launch it follows (no marker packet on the chain)
         const bool carried = bulk && (fused || lean_panel) && syrk_rows_form == 2;
-        const hipEvent_t ev_panel = (carried && gemm_form) ? events[2 * k] : nullptr;
+        const hipEvent_t ev_panel = (carried && gemm_form && !first_of_group) ? events[2 * k] : nullptr;
         const hipEvent_t ev_rows = (carried && !gemm_form) ? events[2 * k] : nullptr;
         if (fused && n3 > 0)
-            launch_panel_fused(s, A, lda, r1, rcol, invDt, info_dev, zvec, n3, flags + 2 * (r1 / 128), spin_limit, ev_panel);
+            launch_panel_fused(s, A, lda, r1, rcol, invDt, info_dev, zvec, n3, flags + 2 * (r1 / 128), spin_limit, ev_panel, split_now);
         else launch_diag(r1);
         if (n3 <= 0) { sweep_rows(r0, 256); break; }
         if (fused) {}
@@ -1814,6 +1851,34 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         launch_trsm_strips(s, A + (int64_t)r1 * lda + r1, lda, invDt + (int64_t)(r1 / 16) * 256,
                            A + (int64_t)r1 * lda + r1 + 128, lda, 128, n3, nullptr, nullptr, nullptr, false, half_lds);
         sweep_rows(r0, 256);
+        if (first_of_group) {
+            // pair 2j of a group: the next pair's rows on the chain as ever, then the rest of the next group's rows
+            launch_syrk_rows(s, A, lda, r0, 256, n3, rcol, info_dev, 256, nullptr);
+            if (pending_big_a >= 0) hipStreamWaitEvent(s, events[pending_big_a], 0);
+            launch_gemm_update(s, A, lda, A, lda, A, lda, r0, 256, r0 + 512, r0 + 1024, n_pad + kRhsCols, syrk_gemm_chunk,
+                               syrk_gemm_half, true, info_dev);
+            second_of_group = true;
+            continue;
+        }
+        if (second_of_group) {
+            // pair 2j+1: the group's bulk update (K = 512) on the side stream, first the rows the chain needs next
+            hipStreamWaitEvent(side, events[2 * k], 0);
+            const int a_end = (r0 + 1280 < (int)n_pad) ? r0 + 1280 : (int)n_pad;
+            launch_gemm_update(side, A, lda, A, lda, A, lda, r0 - 256, 512, r0 + 768, a_end, n_pad + kRhsCols, syrk_gemm_chunk,
+                               syrk_gemm_half, true, info_dev);
+            hipEventRecord(events[2 * k - 3], side);
+            pending_big_a = 2 * k - 3;
+            if (a_end < (int)n_pad)
+                launch_gemm_update(side, A, lda, A, lda, A, lda, r0 - 256, 512, a_end, (int)n_pad, n_pad + kRhsCols,
+                                   syrk_gemm_chunk, syrk_gemm_half, true, info_dev);
+            hipEventRecord(events[2 * k + 1], side);
+            pending = 2 * k + 1;
+            launch_syrk_rows(s, A, lda, r0, 256, n3, rcol, info_dev, 256, nullptr);
+            launch_gemm_update(s, A, lda, A, lda, A, lda, r0, 256, r0 + 512, r0 + 768, n_pad + kRhsCols, syrk_gemm_chunk,
+                               syrk_gemm_half, true, info_dev);
+            second_of_group = false;
+            continue;
+        }
         // both panels against everything below them: the bulk (below the next pair) on the side stream, the next
         // pair's own rows on this stream after the previous pair's bulk update of the same rows.  A large bulk update
         // bounds the factorisation, so it starts as soon as the panels are solved and the rows kernel runs beside its

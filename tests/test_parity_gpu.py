@@ -590,8 +590,10 @@ print("DIGEST", h.hexdigest())
     # the fused diagonal + panel launches, the workgroup chains of the single-vector solves): the host repeats the
     # factorisation with the separate-launch kernels / the solve with the per-block launches inside the same call -- no
     # error, same bits.  "per-block": the single-vector solves as one launch per block (CBO_HIP_VEC_SOLVE_FORM=1).
-    variants = (("4", {}), ("2", {"CBO_HIP_PANEL_FORM": "2"}), ("timeout", {"CBO_HIP_FUSED_SPIN_LIMIT": "-1"}),
-                ("per-block", {"CBO_HIP_VEC_SOLVE_FORM": "1"}))
+    # "split": the block as a one-workgroup launch and the strips as an LDS-free launch behind it (CBO_HIP_PANEL_FORM=5,
+    # what large factorisations use beside their bulk updates), forced at every size.
+    variants = (("4", {"CBO_HIP_PANEL_FORM": "4"}), ("2", {"CBO_HIP_PANEL_FORM": "2"}), ("split", {"CBO_HIP_PANEL_FORM": "5"}),
+                ("timeout", {"CBO_HIP_FUSED_SPIN_LIMIT": "-1"}), ("per-block", {"CBO_HIP_VEC_SOLVE_FORM": "1"}))
     for form, env in variants:
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env),
                              capture_output=True, text=True, timeout=300)
@@ -635,8 +637,12 @@ for n in (4096, 16384):
 print("DIGEST", h.hexdigest())
 """ % ROOT
     digests = {}
-    for form, env in (("4", {}), ("2", {"CBO_HIP_PANEL_FORM": "2"}), ("timeout", {"CBO_HIP_FUSED_SPIN_LIMIT": "-1"}),
-                      ("per-block", {"CBO_HIP_VEC_SOLVE_FORM": "1"})):
+    for form, env in (("auto", {}), ("4", {"CBO_HIP_PANEL_FORM": "4"}), ("2", {"CBO_HIP_PANEL_FORM": "2"}),
+                      ("split", {"CBO_HIP_PANEL_FORM": "5"}), ("timeout", {"CBO_HIP_FUSED_SPIN_LIMIT": "-1"}),
+                      ("per-block", {"CBO_HIP_VEC_SOLVE_FORM": "1"}),
+                      # the bulk trailing updates pair by pair (K = 256) instead of in groups of two pairs (K = 512 on the
+                      # side stream, the next group's rows brought up to date on the chain): same bits by construction
+                      ("pairs", {"CBO_HIP_BULK_GROUP": "1"})):
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env),
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
