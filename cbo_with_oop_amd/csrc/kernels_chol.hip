@@ -458,6 +458,11 @@ extern "C" int cbo_diag_small_stamps(unsigned long long *out)
 #define AGENT_RELEASE()
 #endif
 #define AGENT_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+// The chain's kernels share SIMDs with the bulk update's (and a pipelined sweep's) MFMA waves: their instructions go first.
+#ifndef CBO_CHAIN_PRIO
+#define CBO_CHAIN_PRIO 3
+#endif
+#define CHAIN_PRIORITY() __builtin_amdgcn_s_setprio(CBO_CHAIN_PRIO)
 template <bool PUBLISH>
 __device__ __forceinline__ void gstore(double *p, double v)
 {
@@ -804,6 +809,7 @@ __global__ __launch_bounds__(256) void potrf_panel_fused_kernel(double *A, int64
                                                                 int spin_limit, int strip_base)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    CHAIN_PRIORITY();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1533,6 +1539,7 @@ __global__ __launch_bounds__(256) void syrk_kernel(double *A, int64_t lda, int r
 __global__ __launch_bounds__(256) void syrk_rows_kernel(double *A, int64_t lda, int r0, int n1, int c0, int nt, int rcol,
                                                         const int *__restrict__ skip_if)
 {
+    CHAIN_PRIORITY();
     if (__builtin_nontemporal_load(skip_if) != 0) return;
     const int tj = blockIdx.x, ti = blockIdx.y;                  // 64-column tile, 32-row tile (4 of them)
     const int tid = threadIdx.x;
@@ -1674,18 +1681,46 @@ void sweep_pipe_pair(const SweepPipe &pipe, hipStream_t chain, const double *A, 
     const int below = r0 + klen;
     if (below >= (int)n_pad) return;
     const int first_end = (below + 256 < (int)n_pad) ? below + 256 : (int)n_pad;
-    if (p > 0) hipStreamWaitEvent(pipe.stream, pipe_event(2, p - 1), 0);
-    if (pipe.mark) pipe.mark(pipe.user, pipe.stream, 1, 2.0 * (double)klen * (double)(first_end - below) * m);
-    launch_trsm_update(pipe.stream, A, lda, pipe.V, pipe.ldv, r0, klen, below, first_end, cols, pipe.chunk_blocks,
-                       pipe.half_lds);
-    if (pipe.mark) pipe.mark(pipe.user, pipe.stream, 0, 0.0);
-    hipStreamWaitEvent(pipe.bulk, pipe_event(1, p), 0);
-    if (first_end < (int)n_pad) {
-        if (pipe.mark) pipe.mark(pipe.user, pipe.bulk, 1, 2.0 * (double)klen * (double)((int)n_pad - first_end) * m);
-        launch_trsm_update(pipe.bulk, A, lda, pipe.V, pipe.ldv, r0, klen, first_end, (int)n_pad, cols,
-                           pipe.chunk_blocks, pipe.half_lds);
-        if (pipe.mark) pipe.mark(pipe.user, pipe.bulk, 0, 0.0);
+    auto update = [&](hipStream_t st, int k0, int kl, int i0, int i1) {
+        if (i0 >= i1) return;
+        if (pipe.mark) pipe.mark(pipe.user, st, 1, 2.0 * (double)kl * (double)(i1 - i0) * m);
+        launch_trsm_update(st, A, lda, pipe.V, pipe.ldv, k0, kl, i0, i1, cols, pipe.chunk_blocks, pipe.half_lds);
+        if (pipe.mark) pipe.mark(pipe.user, st, 0, 0.0);
+    };
+    // Groups of two pairs, as in launch_cholesky's bulk updates (and for the same reason: the update kernel's rate grows
+    // with K and it accumulates sequentially into C, so one K = 512 pass has the bits of two K = 256 passes).  Group
+    // j = pairs (2j, 2j+1), G_g = the 512 rows of group g:
+    //   stream: sd(2j);   first: rows of pair 2j+1 -= pair 2j;  [wait restA(j-1)]  near: G_{j+1} -= pair 2j
+    //           sd(2j+1); first: rows of pair 2j+2 -= pair 2j+1;                   near: rows of pair 2j+3 -= pair 2j+1
+    //   bulk  : [wait sd(2j+1)]  restA(j): G_{j+2} -= group j;  restB(j): everything below -= group j    (K = 512)
+    // A pair whose partner is not in the pipeline (the last of an odd count, a 128-row remainder) goes alone as before.
+    // The caller decides (pipe.group): groups pay where the bulk stream is the pipeline's bottleneck (a round of strips
+    // or more per CU); with few strips the pairs schedule starts its updates a pair earlier and wins
+    // (profiles/r03_schedule_crossover.txt).
+    const int full_pairs = ((pipe.tail_begin < (int)n_pad) ? pipe.tail_begin : (int)n_pad) / 256;
+    const bool grouped = pipe.group && !pipe.lower_tri && klen == 256 && (p | 1) < full_pairs;
+    if (grouped && (p & 1) == 0) {
+        update(pipe.stream, r0, 256, below, first_end);
+        if (p >= 2) hipStreamWaitEvent(pipe.stream, pipe_event(2, p - 2), 0);        // restA of the previous group
+        update(pipe.stream, r0, 256, r0 + 512, (r0 + 1024 < (int)n_pad) ? r0 + 1024 : (int)n_pad);
+        return;
     }
+    if (grouped) {
+        update(pipe.stream, r0, 256, below, first_end);
+        update(pipe.stream, r0, 256, r0 + 512, (r0 + 768 < (int)n_pad) ? r0 + 768 : (int)n_pad);
+        hipStreamWaitEvent(pipe.bulk, pipe_event(1, p), 0);
+        const int a0 = (r0 + 768 < (int)n_pad) ? r0 + 768 : (int)n_pad;
+        const int a1 = (r0 + 1280 < (int)n_pad) ? r0 + 1280 : (int)n_pad;
+        update(pipe.bulk, r0 - 256, 512, a0, a1);
+        hipEventRecord(pipe_event(2, p - 1), pipe.bulk);                             // restA
+        update(pipe.bulk, r0 - 256, 512, a1, (int)n_pad);
+        hipEventRecord(pipe_event(2, p), pipe.bulk);                                 // restB: what a successor waits for
+        return;
+    }
+    if (p > 0) hipStreamWaitEvent(pipe.stream, pipe_event(2, p - 1), 0);
+    update(pipe.stream, r0, klen, below, first_end);
+    hipStreamWaitEvent(pipe.bulk, pipe_event(1, p), 0);
+    update(pipe.bulk, r0, klen, first_end, (int)n_pad);
     hipEventRecord(pipe_event(2, p), pipe.bulk);
 }
 
