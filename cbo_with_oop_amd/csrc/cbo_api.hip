@@ -1047,7 +1047,7 @@ static SweepPipe make_pipe(cbo_gp *g, double *V, int64_t ldv, int64_t cols, doub
     pipe.events = &c->pipe_events;
     pipe.mark = pipe_mark; pipe.user = c;
     pipe.tail_begin = (int)g->n_pad;                     // no tail unless the caller sets one
-    pipe.group = false;
+    pipe.group = 0;
     return pipe;
 }
 
@@ -1494,11 +1494,13 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
         if (rc != CBO_OK) return rc;
     }
     SweepPipe pipe = make_pipe(g, Vws, ldv, k->m_pad, c->q, c->mu);
-    // updates in groups of two pairs where the bulk stream bounds the pipeline (CBO_HIP_PIPE_GROUP: 1 never, 3 always)
-    static const int pipe_group_env = [] { const char *e = std::getenv("CBO_HIP_PIPE_GROUP"); return e ? std::atoi(e) : 2; }();
-    pipe.group = pipe_group_env == 3 || (pipe_group_env == 2 && k->m_pad / kStrip >= c->n_cu && g->n_pad >= 4096);
+    // updates in groups of pairs where the bulk stream bounds the pipeline (CBO_HIP_PIPE_GROUP: 1 = never, G >= 2 = groups
+    // of G pairs whatever the shape; default: automatic)
+    static const int pipe_group_env = [] { const char *e = std::getenv("CBO_HIP_PIPE_GROUP"); return e ? std::atoi(e) : 0; }();
+    pipe.group = pipe_group_env >= 2 ? pipe_group_env : (pipe_group_env == 0 && k->m_pad / kStrip >= c->n_cu && g->n_pad >= 4096) ? 2 : 0;
     int pairs = pipeline_pairs(c, g->n_pad, k->m_pad);
-    if (pipe.group && c->pipe_tail_frac < 0.0 && (pairs & 1) && pairs >= 3 && pairs * 256 < (int)g->n_pad) pairs -= 1;   // whole groups
+    if (pipe.group >= 2 && c->pipe_tail_frac < 0.0 && pairs >= pipe.group && pairs * 256 < (int)g->n_pad)
+        pairs -= pairs % pipe.group;                                                    // whole groups
     pipe.tail_begin = pairs * 256;
     if (pipe.tail_begin > (int)g->n_pad) pipe.tail_begin = (int)g->n_pad;
     double jitter = 0.0;

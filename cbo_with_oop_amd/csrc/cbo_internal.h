@@ -125,7 +125,7 @@ struct SweepPipe {
     bool half_lds;                       // 16-row stages (two workgroups per CU) for every kernel of the pipeline
     bool lower_tri;                      // the right-hand sides are lower triangular (identity: V = L^-1), so rows
                                          // [r0, r0+klen) only reach columns < r0+klen: launch just those strips
-    bool group;                          // updates in groups of two pairs (K = 512 on `bulk`), see sweep_pipe_pair
+    int group;                           // G >= 2: updates in groups of G pairs (K = 256 G on `bulk`), see sweep_pipe_pair
     int tail_begin;                      // rows from here on (a multiple of 256; n_pad = none) are left to ONE
                                          // left-looking strip launch once the factorisation is complete
     std::vector<hipEvent_t> *events;     // factorisation -> sweep dependencies, grown on demand

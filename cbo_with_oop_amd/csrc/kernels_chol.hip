@@ -1687,33 +1687,33 @@ void sweep_pipe_pair(const SweepPipe &pipe, hipStream_t chain, const double *A, 
         launch_trsm_update(st, A, lda, pipe.V, pipe.ldv, k0, kl, i0, i1, cols, pipe.chunk_blocks, pipe.half_lds);
         if (pipe.mark) pipe.mark(pipe.user, st, 0, 0.0);
     };
-    // Groups of two pairs, as in launch_cholesky's bulk updates (and for the same reason: the update kernel's rate grows
-    // with K and it accumulates sequentially into C, so one K = 512 pass has the bits of two K = 256 passes).  Group
-    // j = pairs (2j, 2j+1), G_g = the 512 rows of group g:
-    //   stream: sd(2j);   first: rows of pair 2j+1 -= pair 2j;  [wait restA(j-1)]  near: G_{j+1} -= pair 2j
-    //           sd(2j+1); first: rows of pair 2j+2 -= pair 2j+1;                   near: rows of pair 2j+3 -= pair 2j+1
-    //   bulk  : [wait sd(2j+1)]  restA(j): G_{j+2} -= group j;  restB(j): everything below -= group j    (K = 512)
-    // A pair whose partner is not in the pipeline (the last of an odd count, a 128-row remainder) goes alone as before.
-    // The caller decides (pipe.group): groups pay where the bulk stream is the pipeline's bottleneck (a round of strips
-    // or more per CU); with few strips the pairs schedule starts its updates a pair earlier and wins
+    // Groups of G pairs, as in launch_cholesky's bulk updates (and for the same reason: the update kernel's rate grows
+    // with K -- 0.68 of the fp64 MFMA peak at K = 256, 0.76 at 512, 0.83 at 1024 -- and it accumulates sequentially into
+    // C, so one K = 256 G pass has the bits of G passes of K = 256).  Group j = pairs [G j, G j + G), G_g = the rows of
+    // group g:
+    //   stream: after sd(p), p in group j:  first: rows of pair p+1 -= pair p;
+    //                                       near:  the rows from pair p+2 to the end of G_{j+1} -= pair p     (K = 256)
+    //           (the first near of a group waits for restA of the group before)
+    //   bulk  : [wait sd of the group's last pair]  restA(j): G_{j+2} -= group j;  restB(j): everything below -= group j
+    // A pair whose group is not entirely in the pipeline (the remainder of the count, a 128-row remainder) goes alone as
+    // before.  The caller decides (pipe.group = G): groups pay where the bulk stream is the pipeline's bottleneck (a
+    // round of strips or more per CU); with few strips the pairs schedule starts its updates earlier and wins
     // (profiles/r03_schedule_crossover.txt).
+    const int G = pipe.group;
     const int full_pairs = ((pipe.tail_begin < (int)n_pad) ? pipe.tail_begin : (int)n_pad) / 256;
-    const bool grouped = pipe.group && !pipe.lower_tri && klen == 256 && (p | 1) < full_pairs;
-    if (grouped && (p & 1) == 0) {
-        update(pipe.stream, r0, 256, below, first_end);
-        if (p >= 2) hipStreamWaitEvent(pipe.stream, pipe_event(2, p - 2), 0);        // restA of the previous group
-        update(pipe.stream, r0, 256, r0 + 512, (r0 + 1024 < (int)n_pad) ? r0 + 1024 : (int)n_pad);
-        return;
-    }
+    const bool grouped = G >= 2 && !pipe.lower_tri && klen == 256 && (p / G + 1) * G <= full_pairs;
     if (grouped) {
+        const int j = p / G, i = p % G;
+        const int next_end = (256 * G * (j + 2) < (int)n_pad) ? 256 * G * (j + 2) : (int)n_pad;     // end of G_{j+1}
         update(pipe.stream, r0, 256, below, first_end);
-        update(pipe.stream, r0, 256, r0 + 512, (r0 + 768 < (int)n_pad) ? r0 + 768 : (int)n_pad);
+        if (i == 0 && j >= 1) hipStreamWaitEvent(pipe.stream, pipe_event(2, G * (j - 1)), 0);      // restA of the group before
+        update(pipe.stream, r0, 256, r0 + 512, next_end);
+        if (i < G - 1) return;
         hipStreamWaitEvent(pipe.bulk, pipe_event(1, p), 0);
-        const int a0 = (r0 + 768 < (int)n_pad) ? r0 + 768 : (int)n_pad;
-        const int a1 = (r0 + 1280 < (int)n_pad) ? r0 + 1280 : (int)n_pad;
-        update(pipe.bulk, r0 - 256, 512, a0, a1);
-        hipEventRecord(pipe_event(2, p - 1), pipe.bulk);                             // restA
-        update(pipe.bulk, r0 - 256, 512, a1, (int)n_pad);
+        const int a1 = (256 * G * (j + 3) < (int)n_pad) ? 256 * G * (j + 3) : (int)n_pad;           // end of G_{j+2}
+        update(pipe.bulk, 256 * G * j, 256 * G, next_end, a1);
+        hipEventRecord(pipe_event(2, G * j), pipe.bulk);                             // restA (the first pair's slot)
+        update(pipe.bulk, 256 * G * j, 256 * G, a1, (int)n_pad);
         hipEventRecord(pipe_event(2, p), pipe.bulk);                                 // restB: what a successor waits for
         return;
     }
