@@ -75,7 +75,7 @@ struct cbo_ctx {
     std::vector<hipEvent_t> pipe_events;      // factorisation -> sweep dependencies
     hipEvent_t ev_join = nullptr, ev_join2 = nullptr, ev_fork = nullptr;
     hipEvent_t region_a = nullptr, region_b = nullptr;
-    int pipe_chunk_blocks = 2;
+    int pipe_chunk_blocks = 1;        // row blocks per update workgroup (CBO_HIP_PIPE_CHUNK; 1 since the updates go in K = 512 groups: profiles/r03_schedule_crossover.txt)
     bool pipe_half_lds = true;
     double pipe_tail_frac = -1.0;    // CBO_HIP_PIPE_TAIL: rows (fraction) left to the closing left-looking launch; < 0 = automatic
     int n_cu = 256;
