@@ -21,4 +21,16 @@ timeout -k 10 200 python3 scripts/vec_solve_timing.py > $OUT/vec_solve_timing.tx
 timeout -k 10 200 python3 scripts/append_step_timing.py > $OUT/append_step_timing.txt 2>&1; echo "append rc=$?"
 timeout -k 10 300 python3 scripts/complete_graph_cbo_loop.py 20 > $OUT/loop.txt 2>&1; timeout -k 10 300 python3 scripts/complete_graph_cbo_loop.py 20 --optimize >> $OUT/loop.txt 2>&1; echo "loop rc=$?"
 timeout -k 10 120 ./scripts/probes/stage_probe > $OUT/stage_probe.txt 2>&1; echo "probe rc=$?"
+# second half of the round: the schedules with grouped updates, the 16384-point factorisation pair by pair and in groups
+timeout -k 10 900 python3 scripts/schedule_scan.py > $OUT/schedule_crossover.txt 2>&1; echo "schedule scan rc=$?"
+for g in 1 2; do
+  rm -rf $OUT/tl16_g$g
+  CBO_HIP_BULK_GROUP=$g timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl16_g$g -- python3 scripts/chol_timing.py 16384 > $OUT/tl16_g$g.log 2>&1; echo "chol trace group=$g rc=$?"
+  python3 scripts/chol_timeline.py $(ls -t $OUT/tl16_g$g/*/*kernel_trace.csv | head -1) > $OUT/chol_timeline_16384_group$g.txt
+done
+CBO_HIP_BULK_GROUP=1 timeout -k 10 200 python3 scripts/chol_timing.py 8192 16384 > $OUT/chol_timing_pairs.txt 2>&1; echo "chol pairs rc=$?"
+CBO_HIP_PIPE_GROUP=1 CBO_HIP_PIPE_CHUNK=2 timeout -k 10 300 python3 bench.py --cpu-sample 0 --post-steps 0 > $OUT/bench_default_pairs.json 2> $OUT/bench_default_pairs.err; echo "bench pairs rc=$?"
+rm -rf $OUT/step_trace; timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/step_trace -- python3 bench.py --steps 6 --warmup 2 --cpu-sample 0 --post-steps 0 > $OUT/step_trace.log 2>&1; echo "step trace rc=$?"
+python3 scripts/step_timeline.py $(ls -t $OUT/step_trace/*/*kernel_trace.csv | head -1) > $OUT/step_timeline.txt
+CBO_HIP_ALLOW_DIAG=1 CBO_HIP_LIB=$GRAFT_REPO_ROOT/cbo_with_oop_amd/libcbo_hip_diag.so timeout -k 10 300 python3 scripts/update_kernel_timing.py 16384 8192 > $OUT/update_kernel_timing.txt 2>&1; echo "update kernel rc=$?"
 for d in default sequential f32 c3; do cp $OUT/prof_$d/*/*kernel_stats.csv $OUT/kernel_stats_$d.csv; done
