@@ -72,6 +72,16 @@ extern "C" int cbo_diag_trsm_fine(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trsm_fine), sizeof(unsigned long long) * 4 * 16);
 }
+// Timing-only: every workgroup of the last trsm_update_kernel launch leaves [start, end, hw id | xcc id << 32] (s_memtime), and
+// workgroup (7, gridDim.y / 2) its stage tops: scripts/update_kernel_stamps.py
+__device__ unsigned long long g_upd_wg[3 * 65536];
+__device__ unsigned long long g_upd_stage[128];
+extern "C" int cbo_diag_upd_stamps(unsigned long long *wg, unsigned long long *stage)
+{
+    int rc = (int)hipMemcpyFromSymbol(wg, HIP_SYMBOL(g_upd_wg), sizeof(unsigned long long) * 3 * 65536);
+    if (rc == 0) rc = (int)hipMemcpyFromSymbol(stage, HIP_SYMBOL(g_upd_stage), sizeof(unsigned long long) * 128);
+    return rc;
+}
 extern "C" int cbo_diag_trsm_stamps(unsigned long long *out, int n)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trsm_stamps), sizeof(unsigned long long) * (size_t)n);   // 8 per stage
@@ -962,6 +972,15 @@ __global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restri
     __shared__ __align__(16) double lds[kNBuf * (kA + kB)];
 
     const int tid = threadIdx.x;
+#ifdef CBO_DIAG_KNOBS
+    const unsigned long long upd_t0 = __builtin_amdgcn_s_memtime();
+    const int upd_id = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const bool upd_probe = tid == 0 && blockIdx.x == 7 && blockIdx.y == gridDim.y / 2;
+    int upd_k = 0;
+#define UPD_STAMP() do { if (upd_probe && upd_k < 128) g_upd_stage[upd_k++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define UPD_STAMP() do { } while (0)
+#endif
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lc = lane & 15, kq = lane >> 4;
@@ -1017,6 +1036,7 @@ __global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] = -Cc[(int64_t)(ib + 16 * t + kq + 4 * r) * ldc];
 
+    UPD_STAMP();                                    // [0] C tile in registers
     locate();
 #pragma unroll
     for (int part = 0; part < kParts; ++part) issue_part(0, part);
@@ -1024,6 +1044,7 @@ __global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restri
 #pragma unroll
     for (int part = 0; part < kParts; ++part) issue_part(1, part);
     advance();
+    UPD_STAMP();                                    // [1] two stages of DMA issued
 
     int buf = 0;
     // vmcnt bookkeeping (in-order retirement): at the top of a stage this wave's DMA of the stage must have
@@ -1039,6 +1060,7 @@ __global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restri
             if (boundary) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma + kAccMoves) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma) : "memory");
             __builtin_amdgcn_s_barrier();
+            UPD_STAMP();                            // [2 + stage] stage top passed
             boundary = (boundary > 0) ? boundary - 1 : 0;
             if (j == 0 && i0 + kRB < ie) {
                 // next block's C, ahead of this stage's DMA in issue order
@@ -1088,17 +1110,31 @@ __global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restri
         }
 #pragma unroll
         for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
+        UPD_STAMP();                                // block's last MFMAs issued
 #pragma unroll
         for (int t = 0; t < kT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) Cc[(int64_t)(i0 + 16 * t + kq + 4 * r) * ldc] = -acc[t][r];
         asm volatile("" ::: "memory");
+        UPD_STAMP();                                // stores issued
 #pragma unroll
         for (int t = 0; t < kT; ++t) acc[t] = accn[t];
         boundary = 2;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#ifdef CBO_DIAG_KNOBS
+    UPD_STAMP();                                    // drained
+    if (tid == 0 && upd_id < 65536) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_upd_wg[3 * upd_id] = upd_t0;
+        g_upd_wg[3 * upd_id + 1] = __builtin_amdgcn_s_memtime();
+        g_upd_wg[3 * upd_id + 2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+    }
+#endif
+#undef UPD_STAMP
 }
 
 void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const double *invDt, double *V, int64_t ldv,
