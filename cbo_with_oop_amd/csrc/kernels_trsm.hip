@@ -72,13 +72,14 @@ extern "C" int cbo_diag_trsm_fine(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trsm_fine), sizeof(unsigned long long) * 4 * 16);
 }
-// Timing-only: every workgroup of the last trsm_update_kernel launch leaves [start, end, hw id | xcc id << 32] (s_memtime), and
+// Timing-only: every workgroup of the last trsm_update_kernel launch leaves [start, end, hw id | xcc id << 32, start, end in
+// s_memrealtime's 100 MHz] (s_memtime runs at the shader clock), and
 // workgroup (7, gridDim.y / 2) its stage tops: scripts/update_kernel_stamps.py
-__device__ unsigned long long g_upd_wg[3 * 65536];
+__device__ unsigned long long g_upd_wg[5 * 65536];
 __device__ unsigned long long g_upd_stage[128];
 extern "C" int cbo_diag_upd_stamps(unsigned long long *wg, unsigned long long *stage)
 {
-    int rc = (int)hipMemcpyFromSymbol(wg, HIP_SYMBOL(g_upd_wg), sizeof(unsigned long long) * 3 * 65536);
+    int rc = (int)hipMemcpyFromSymbol(wg, HIP_SYMBOL(g_upd_wg), sizeof(unsigned long long) * 5 * 65536);
     if (rc == 0) rc = (int)hipMemcpyFromSymbol(stage, HIP_SYMBOL(g_upd_stage), sizeof(unsigned long long) * 128);
     return rc;
 }
@@ -974,6 +975,7 @@ __global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restri
     const int tid = threadIdx.x;
 #ifdef CBO_DIAG_KNOBS
     const unsigned long long upd_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long upd_r0 = __builtin_amdgcn_s_memrealtime();
     const int upd_id = (int)(blockIdx.y * gridDim.x + blockIdx.x);
     const bool upd_probe = tid == 0 && blockIdx.x == 7 && blockIdx.y == gridDim.y / 2;
     int upd_k = 0;
@@ -1129,9 +1131,11 @@ __global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restri
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_upd_wg[3 * upd_id] = upd_t0;
-        g_upd_wg[3 * upd_id + 1] = __builtin_amdgcn_s_memtime();
-        g_upd_wg[3 * upd_id + 2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+        g_upd_wg[5 * upd_id] = upd_t0;
+        g_upd_wg[5 * upd_id + 1] = __builtin_amdgcn_s_memtime();
+        g_upd_wg[5 * upd_id + 2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+        g_upd_wg[5 * upd_id + 3] = upd_r0;
+        g_upd_wg[5 * upd_id + 4] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
 #undef UPD_STAMP

@@ -16,10 +16,10 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 ms = ctypes.c_double()
 _lib.check(f(ctx.handle, n, K, chunk, 1, 0, 1, ctypes.byref(ms)))
-wg = (ctypes.c_ulonglong * (3 * 65536))(); st = (ctypes.c_ulonglong * 128)()
+wg = (ctypes.c_ulonglong * (5 * 65536))(); st = (ctypes.c_ulonglong * 128)()
 lib.cbo_diag_upd_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 assert lib.cbo_diag_upd_stamps(wg, st) == 0
-w = np.frombuffer(wg, dtype=np.uint64).reshape(65536, 3)
+w = np.frombuffer(wg, dtype=np.uint64).reshape(65536, 5)
 strips, chunks = n // 64, (n - K + 128 * chunk - 1) // (128 * chunk)
 nwg = min(strips * chunks, 65536)
 w = w[:nwg]
@@ -42,7 +42,10 @@ stages = (K // 16) * chunk
 print(f"n={n} K={K} chunk={chunk}: {ms.value:.3f} ms per launch (events), {nwg} workgroups of {stages} stages")
 print(f"workgroup lifetime (ticks): median {np.median(life):.0f}, p10 {np.percentile(life, 10):.0f}, p90 {np.percentile(life, 90):.0f}; "
       f"MFMA work of its waves {stages * 2048} cycles -> two resident workgroups use {2 * stages * 2048 / np.median(life):.3f} of the matrix pipe while both are there")
-print(f"sum of lifetimes / (512 slots x launch time) = {life.sum() / 512 / (ms.value * 1e3):.0f} ticks per us if no slot were ever empty")
+real = (w[:, 4].astype(np.int64) - w[:, 3].astype(np.int64)).astype(np.float64)          # 100 MHz
+clock = life.sum() / real.sum() * 100.0
+print(f"shader clock over the workgroups' lifetimes: {clock:.0f} MHz (s_memtime ticks per s_memrealtime tick x 100 MHz)")
+print(f"slot occupancy: sum of lifetimes / (512 slots x launch time) = {real.sum() / 100.0 / 512 / (ms.value * 1e3):.3f}")
 s = np.frombuffer(st, dtype=np.uint64).astype(np.int64)
 s = s[s > 0]
 if len(s) > 3:
