@@ -920,6 +920,45 @@ def test_three_schedules_give_the_same_bits(hip, monkeypatch, n, m, d):
     np.testing.assert_allclose(out[2]["var"], var, rtol=1e-5, atol=1e-10)
 
 
+def test_grouped_pipeline_gives_the_same_bits_at_the_headline_shape(hip):
+    """BASELINE config 2's shape (4096 observations, 16384 candidates) through cbo_gp_fit_sweep with the pipelined sweep's
+    updates pair by pair (CBO_HIP_PIPE_GROUP=1), in groups of two pairs (the automatic choice there: K = 512 on the bulk
+    stream), of three and of four pairs, with an odd split (a remainder pair behind the groups), and as the two plain calls
+    (no overlap, left-looking): the update kernel accumulates into V sequentially, so every grouping gives the same bits."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from cbo_with_oop_amd import CandidateGrid, CausalExpectedImprovement
+from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+rng = np.random.default_rng(42)
+X = rng.uniform([-5, -5, -5], [5, 20, 5], (4096, 3))
+y = np.sin(X).sum(1, keepdims=True) + 0.1 * rng.standard_normal((4096, 1))
+Xs = rng.uniform([-5, -5, -5], [5, 20, 5], (16384, 3))
+m = HipGaussianProcess(X, y, fit=False)
+g = CandidateGrid(Xs, m)
+r = CausalExpectedImprovement(float(y.min()), "min", m).sweep(g, cost=1.5, want_acq=True, want_posterior=True, refit=True)
+h = hashlib.sha256()
+for k in ("acq", "var", "mean"):
+    h.update(np.ascontiguousarray(r[k]).tobytes())
+h.update(str(r["best_idx"]).encode())
+h.update(np.ascontiguousarray(m.posterior_state()[0]).tobytes())
+print("DIGEST", h.hexdigest())
+""" % ROOT
+    digests = {}
+    for name, env in (("auto", {}), ("pairs", {"CBO_HIP_PIPE_GROUP": "1"}), ("three", {"CBO_HIP_PIPE_GROUP": "3"}),
+                      ("four", {"CBO_HIP_PIPE_GROUP": "4"}), ("odd split", {"CBO_HIP_PIPE_TAIL": "0.6875"}),
+                      ("two calls", {"CBO_HIP_OVERLAP": "0"})):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env),
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests[name] = [ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][-1]
+    assert len(set(digests.values())) == 1, digests
+
+
 def test_schedule_selection(hip):
     """Automatic choice: few strips at a large N go right-looking, full rounds of strips stay left-looking
     (checked through the launch count the timers report)."""
