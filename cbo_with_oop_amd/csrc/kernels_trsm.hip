@@ -72,6 +72,13 @@ extern "C" int cbo_diag_trsm_fine(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trsm_fine), sizeof(unsigned long long) * 4 * 16);
 }
+// Timing-only: every workgroup of the last trsm_strip8_kernel launch leaves its lifetime in shader cycles (s_memtime) and in
+// s_memrealtime's 100 MHz ticks: the shader clock under the kernel (scripts/strip_scaling.py prints it in a diagnostic build)
+__device__ unsigned long long g_strip_clock[2 * 4096];
+extern "C" int cbo_diag_strip_clock(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_strip_clock), sizeof(unsigned long long) * 2 * 4096);
+}
 // Timing-only: every workgroup of the last trsm_update_kernel launch leaves [start, end, hw id | xcc id << 32, start, end in
 // s_memrealtime's 100 MHz] (s_memtime runs at the shader clock), and
 // workgroup (7, gridDim.y / 2) its stage tops: scripts/update_kernel_stamps.py
@@ -488,6 +495,7 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
     // 256 = stage stamps on (they perturb the run: the stamp stores are not in the stage-top accounting)
     const int dmask = accumulate >> 8;
     accumulate &= 1;
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #else
     constexpr int dmask = 0;
 #endif
@@ -940,6 +948,12 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
         q_out[colw + lc] = qtot;
         mu_out[colw + lc] = mtot;
     }
+#ifdef CBO_DIAG_KNOBS
+    if (tid == 0 && blockIdx.x < 4096) {
+        g_strip_clock[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk_t0;
+        g_strip_clock[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
