@@ -1255,23 +1255,14 @@ static int check_sweep_args(const cbo_gp *g, const cbo_cands *k, int task)
 }
 
 // EI / cost and arg-max from q, mu (already on the device), results to the host
-static int finish_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task, double ei_jitter, double cost,
-                        double *acq_out, double *mean_out, double *var_out, double *best_val, int64_t *best_idx)
+// The epilogue of a sweep from q = sum V^2 and mu = V^T z: variance, mean, EI / cost, arg-max, and the copies to the host.
+// enqueue_finish only queues (cbo_gp_fit_sweep queues it behind the closing launch, ahead of its one synchronisation:
+// the factorisation's status and the winner come back together); complete_finish reads the winner after the stream has
+// been synchronised.
+static int enqueue_finish(cbo_gp *g, cbo_cands *k, double y_best, int task, double ei_jitter, double cost, double *acq_out,
+                          double *mean_out, double *var_out, const double *q_src, const double *mu_src)
 {
     cbo_ctx *c = g->ctx;
-    // keep q, mu with the candidates (two small device copies): the next sweep of an unchanged model skips the
-    // substitution altogether
-    const bool cached = k->fit_stamp != 0 && k->fit_stamp == g->fit_stamp;
-    if (!cached && c->sweep_cache) {
-        if (!k->q) {
-            HIP_TRY(hipMalloc(&k->q, sizeof(double) * k->cap_m_pad));
-            HIP_TRY(hipMalloc(&k->mu, sizeof(double) * k->cap_m_pad));
-        }
-        HIP_TRY(hipMemcpyAsync(k->q, c->q, sizeof(double) * k->m_pad, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(k->mu, c->mu, sizeof(double) * k->m_pad, hipMemcpyDeviceToDevice, c->stream));
-        k->fit_stamp = g->fit_stamp;
-    }
-    const double *q_src = cached ? k->q : c->q, *mu_src = cached ? k->mu : c->mu;
     const bool causal = g->X.sv != nullptr;
     AcqParams p;
     p.variance = g->h.variance; p.noise_var = g->noise_var; p.y_best = y_best; p.ei_jitter = ei_jitter; p.cost = cost;
@@ -1290,10 +1281,37 @@ static int finish_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task, double
     if (acq_out) HIP_TRY(hipMemcpyAsync(acq_out, c->acq, sizeof(double) * k->m, hipMemcpyDeviceToHost, c->stream));
     if (mean_out) HIP_TRY(hipMemcpyAsync(mean_out, c->mean, sizeof(double) * k->m, hipMemcpyDeviceToHost, c->stream));
     if (var_out) HIP_TRY(hipMemcpyAsync(var_out, c->var, sizeof(double) * k->m, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CBO_OK;
+}
+
+static void complete_finish(cbo_ctx *c, double *best_val, int64_t *best_idx)
+{
     if (best_val) *best_val = *c->h_best_val;
     if (best_idx) *best_idx = *c->h_best_idx;
     if (c->profiling) c->timers.n_sweep += 1;
+}
+
+static int finish_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task, double ei_jitter, double cost,
+                        double *acq_out, double *mean_out, double *var_out, double *best_val, int64_t *best_idx)
+{
+    cbo_ctx *c = g->ctx;
+    // keep q, mu with the candidates (two small device copies): the next sweep of an unchanged model skips the
+    // substitution altogether
+    const bool cached = k->fit_stamp != 0 && k->fit_stamp == g->fit_stamp;
+    if (!cached && c->sweep_cache) {
+        if (!k->q) {
+            HIP_TRY(hipMalloc(&k->q, sizeof(double) * k->cap_m_pad));
+            HIP_TRY(hipMalloc(&k->mu, sizeof(double) * k->cap_m_pad));
+        }
+        HIP_TRY(hipMemcpyAsync(k->q, c->q, sizeof(double) * k->m_pad, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(k->mu, c->mu, sizeof(double) * k->m_pad, hipMemcpyDeviceToDevice, c->stream));
+        k->fit_stamp = g->fit_stamp;
+    }
+    const double *q_src = cached ? k->q : c->q, *mu_src = cached ? k->mu : c->mu;
+    int rc = enqueue_finish(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, q_src, mu_src);
+    if (rc != CBO_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    complete_finish(c, best_val, best_idx);
     return CBO_OK;
 }
 
@@ -1493,7 +1511,20 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
         rc = own_solution_buffer(g, k, &Vws, &ldv);
         if (rc != CBO_OK) return rc;
     }
-    SweepPipe pipe = make_pipe(g, Vws, ldv, k->m_pad, c->q, c->mu);
+    // q = sum V^2 and mu = V^T z go straight to the candidates' own copies when those are kept (the next sweep of the
+    // unchanged model starts from them): no device copies between the closing launch and the acquisition kernel
+    double *qbuf = c->q, *mubuf = c->mu;
+    if (c->sweep_cache) {
+        if (!k->q) {
+            HIP_TRY(hipMalloc(&k->q, sizeof(double) * k->cap_m_pad));
+            HIP_TRY(hipMalloc(&k->mu, sizeof(double) * k->cap_m_pad));
+        }
+        qbuf = k->q;
+        mubuf = k->mu;
+        k->fit_stamp = 0;                                  // not valid until this call has succeeded
+    }
+    const bool speculate = qbuf == k->q;
+    SweepPipe pipe = make_pipe(g, Vws, ldv, k->m_pad, qbuf, mubuf);
     // updates in groups of pairs where the bulk stream bounds the pipeline (CBO_HIP_PIPE_GROUP: 1 = never, G >= 2 = groups
     // of G pairs whatever the shape; default: automatic)
     static const int pipe_group_env = [] { const char *e = std::getenv("CBO_HIP_PIPE_GROUP"); return e ? std::atoi(e) : 0; }();
@@ -1514,8 +1545,8 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
             PhaseScope ps(c, PH_KSTAR, c->sweep_stream);
             launch_kstar(c->sweep_stream, g->X, k->P, 0, k->m_pad, g->h, Vws, ldv, g->n_pad);
         }
-        HIP_TRY(hipMemsetAsync(c->q, 0, sizeof(double) * k->m_pad, c->sweep_stream));
-        HIP_TRY(hipMemsetAsync(c->mu, 0, sizeof(double) * k->m_pad, c->sweep_stream));
+        HIP_TRY(hipMemsetAsync(qbuf, 0, sizeof(double) * k->m_pad, c->sweep_stream));
+        HIP_TRY(hipMemsetAsync(mubuf, 0, sizeof(double) * k->m_pad, c->sweep_stream));
         {
             PhaseScope ps(c, PH_KXX);
             launch_kxx(c->stream, g->X, g->h, g->noise_var + kGpyDiagJitter, jitter, g->A, g->lda, g->n_pad);
@@ -1547,6 +1578,12 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
         HIP_TRY(hipEventRecord(c->ev_join2, c->bulk_stream));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
         HIP_TRY(hipGetLastError());
+        // the epilogue rides behind the closing launch on the assumption that the factorisation succeeded (it reads q, mu
+        // where the sweep left them); an attempt that failed is repeated and its epilogue's outputs are overwritten
+        if (speculate) {
+            rc = enqueue_finish(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, qbuf, mubuf);
+            if (rc != CBO_OK) return rc;
+        }
         HIP_TRY(hipMemcpyAsync(c->h_info, g->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (*c->h_info == 0) break;
@@ -1569,6 +1606,11 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
     if (tries_out) *tries_out = tries;
     if (jitter_out) *jitter_out = jitter;
     if (Vws != c->V) { k->v_stamp = g->fit_stamp; k->v_rows = g->n; }
+    if (qbuf == k->q) k->fit_stamp = g->fit_stamp;         // the candidates' q, mu are this fit's
+    if (speculate) {
+        complete_finish(c, best_val, best_idx);
+        return CBO_OK;
+    }
     return finish_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
 }
 
