@@ -1260,7 +1260,8 @@ static int check_sweep_args(const cbo_gp *g, const cbo_cands *k, int task)
 // the factorisation's status and the winner come back together); complete_finish reads the winner after the stream has
 // been synchronised.
 static int enqueue_finish(cbo_gp *g, cbo_cands *k, double y_best, int task, double ei_jitter, double cost, double *acq_out,
-                          double *mean_out, double *var_out, const double *q_src, const double *mu_src)
+                          double *mean_out, double *var_out, const double *q_src, const double *mu_src,
+                          bool with_status = false)
 {
     cbo_ctx *c = g->ctx;
     const bool causal = g->X.sv != nullptr;
@@ -1273,11 +1274,11 @@ static int enqueue_finish(cbo_gp *g, cbo_cands *k, double y_best, int task, doub
         launch_acq(c->stream, q_src, mu_src, causal ? k->pm : nullptr, causal ? k->pv : nullptr, k->m, p,
                    mean_out ? c->mean : nullptr, var_out ? c->var : nullptr, acq_out ? c->acq : nullptr, c->part_val,
                    c->part_idx, k->index_offset, nb);
-        launch_argmax_final(c->stream, c->part_val, c->part_idx, nb, c->best_val, c->best_idx);
+        // the winner (and, behind a factorisation, its status word) goes straight to pinned host memory
+        launch_argmax_final(c->stream, c->part_val, c->part_idx, nb, c->h_best_val, c->h_best_idx,
+                            with_status ? g->info : nullptr, with_status ? c->h_info : nullptr);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(c->h_best_val, c->best_val, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_best_idx, c->best_idx, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     if (acq_out) HIP_TRY(hipMemcpyAsync(acq_out, c->acq, sizeof(double) * k->m, hipMemcpyDeviceToHost, c->stream));
     if (mean_out) HIP_TRY(hipMemcpyAsync(mean_out, c->mean, sizeof(double) * k->m, hipMemcpyDeviceToHost, c->stream));
     if (var_out) HIP_TRY(hipMemcpyAsync(var_out, c->var, sizeof(double) * k->m, hipMemcpyDeviceToHost, c->stream));
@@ -1581,10 +1582,11 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
         // the epilogue rides behind the closing launch on the assumption that the factorisation succeeded (it reads q, mu
         // where the sweep left them); an attempt that failed is repeated and its epilogue's outputs are overwritten
         if (speculate) {
-            rc = enqueue_finish(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, qbuf, mubuf);
+            rc = enqueue_finish(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, qbuf, mubuf, true);
             if (rc != CBO_OK) return rc;
+        } else {
+            HIP_TRY(hipMemcpyAsync(c->h_info, g->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         }
-        HIP_TRY(hipMemcpyAsync(c->h_info, g->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (*c->h_info == 0) break;
         if (*c->h_info == kCholFusedTimeout) {                 // as in cbo_gp_fit: the attempt again, separate launches

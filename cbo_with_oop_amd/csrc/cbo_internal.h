@@ -229,7 +229,7 @@ void launch_acq(hipStream_t s, const double *q, const double *mu, const double *
                 const AcqParams &p, double *mean_out, double *var_out, double *acq_out, double *part_val,
                 int64_t *part_idx, int64_t index_offset, int n_blocks);
 void launch_argmax_final(hipStream_t s, const double *part_val, const int64_t *part_idx, int n, double *best_val,
-                         int64_t *best_idx);
+                         int64_t *best_idx, const int *status_src = nullptr, int *status_dst = nullptr);
 int acq_blocks_for(int64_t m);
 // out[g] = mean of in[g*group .. (g+1)*group)
 void launch_group_mean(hipStream_t s, const double *in, int64_t n_groups, int64_t group, double *out);

@@ -60,10 +60,14 @@ __global__ __launch_bounds__(256) void acq_kernel(const double *__restrict__ q, 
     if (p.want_ei) block_argmax(bv, bi, &part_val[blockIdx.x], &part_idx[blockIdx.x]);
 }
 
+// best_val / best_idx may be pinned host memory (the sweep's epilogue writes the winner where the host reads it: no copy
+// operation behind the kernel); status_src -> status_dst carries a factorisation's status word the same way.
 __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restrict__ part_val,
                                                            const int64_t *__restrict__ part_idx, int n,
-                                                           double *__restrict__ best_val, int64_t *__restrict__ best_idx)
+                                                           double *__restrict__ best_val, int64_t *__restrict__ best_idx,
+                                                           const int *__restrict__ status_src, int *__restrict__ status_dst)
 {
+    if (status_src && threadIdx.x == 0) *status_dst = __builtin_nontemporal_load(status_src);
     double bv = -INFINITY;
     int64_t bi = kNoIndex;
     for (int i = threadIdx.x; i < n; i += blockDim.x)
@@ -185,9 +189,10 @@ void launch_acq(hipStream_t s, const double *q, const double *mu, const double *
 }
 
 void launch_argmax_final(hipStream_t s, const double *part_val, const int64_t *part_idx, int n, double *best_val,
-                         int64_t *best_idx)
+                         int64_t *best_idx, const int *status_src, int *status_dst)
 {
-    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, s, part_val, part_idx, n, best_val, best_idx);
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, s, part_val, part_idx, n, best_val, best_idx, status_src,
+                       status_dst);
 }
 
 // ---- append-only trial step --------------------------------------------------------------------------------
