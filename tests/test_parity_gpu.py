@@ -1011,6 +1011,38 @@ def test_overlapped_refit_sweep_jitter_ladder_and_chunking(hip, monkeypatch):
     small.close()
 
 
+def test_overlapped_refit_sweep_repeats_a_failed_attempt(hip, monkeypatch):
+    """cbo_gp_fit_sweep at a size where it really overlaps (1152 observations), on a matrix whose first attempt is not
+    positive definite (duplicate rows, a slightly negative effective diagonal add): the acquisition epilogue is queued
+    behind the closing launch before the host has seen the factorisation's status, so the failed attempt's epilogue runs on
+    garbage and must leave nothing behind -- the call repeats with jitchol's jitter and returns what fit + sweep return."""
+    import warnings
+    from cbo_with_oop_amd import CandidateGrid, CausalExpectedImprovement
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    rng = np.random.default_rng(77)
+    X = rng.uniform(-3, 3, (576, 2))
+    X = np.vstack([X, X])                                    # exact duplicates -> singular K
+    y = np.sin(X.sum(1, keepdims=True)) + 0.01 * rng.standard_normal((len(X), 1))
+    Xs = rng.uniform(-3, 3, (3000, 2))
+    ctx = forced_context(monkeypatch, CBO_HIP_OVERLAP=1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        plain = HipGaussianProcess(X, y, noise_var=-1e-8 - 1e-9, context=ctx)
+        assert plain.jitter_tries >= 1
+        a = CausalExpectedImprovement(float(y.min()), "min", plain).sweep(Xs, want_acq=True, want_posterior=True)
+        lazy = HipGaussianProcess(X, y, noise_var=-1e-8 - 1e-9, context=ctx, fit=False)
+        grid = CandidateGrid(Xs, lazy, context=ctx)
+        ei = CausalExpectedImprovement(float(y.min()), "min", lazy)
+        b = ei.sweep(grid, want_acq=True, want_posterior=True, refit=True)
+        c = ei.sweep(grid, want_acq=True, want_posterior=True)            # the unchanged model: from the cached q, mu
+    assert (lazy.jitter_tries, lazy.jitter) == (plain.jitter_tries, plain.jitter)
+    for r in (b, c):
+        assert r["best_idx"] == a["best_idx"] and r["best_val"] == a["best_val"]
+        for key in ("acq", "mean", "var"):
+            assert np.array_equal(r[key], a[key]), key
+    grid.close(); lazy.close(); plain.close(); ctx.close()
+
+
 def test_deferred_refit_is_transparent(hip):
     """set_data(fit=False) / create(fit=False): the next sweep refits overlapped, any other consumer fits first;
     results equal the eager path; a not-PD model raises at that use."""
