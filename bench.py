@@ -32,8 +32,9 @@ Workloads (--config; every BASELINE.json config has a line):
        is the same thing.
 
 usage: python bench.py [--config c1..c5] [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--full-grid]
-       (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...  -- the launcher only
-        provides RANK / WORLD_SIZE / LOCAL_RANK; the communicator is RCCL through the C-ABI)
+       (N > 1: either under python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ... -- the launcher
+        only provides RANK / WORLD_SIZE / LOCAL_RANK -- or as a plain `python bench.py --gpus N`, which then starts its
+        own N rank processes as children (self_launch); the communicator is RCCL through the C-ABI either way)
 """
 import argparse
 import ctypes
@@ -212,6 +213,7 @@ def bench_small_sets(args):
                                       "(BASELINE.json configs[0]); step = rebuild the intervened set's model + one "
                                       "cbo_acq_sweep_sets call (every set factored and swept in ONE launch) + pick",
                           "config": "c1", "n_obs": n, "candidates_total": n_sets * m, "sets": n_sets,
+                          "rccl_ranks": comm.size()[0] if comm is not None else 0,
                           "parallelism": f"replicas x{world} (every rank runs the whole pass)"},
                "winner": {"set": int(choice[1]), "acq": float(vals[choice[1]][0, 0])},
                "kernel_sources_sha": kernel_sources_sha(),
@@ -250,6 +252,73 @@ def bench_small_sets(args):
         comm.close()
 
 
+def self_launch(n_ranks, argv=None, timeout_s=None):
+    """`python bench.py --gpus N` with no launcher around it: start N rank processes of this same command as CHILDREN
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, what torch.distributed.run would
+    set), hand rank 0's standard output through (its one JSON line), send the other ranks' output to stderr, and return the
+    worst exit code.  The launcher itself never imports the library or initialises the GPU (a process that has must not
+    exec or fork workers on this pool); the ranks form their RCCL communicator among themselves (sharding.Communicator:
+    the 128-byte id travels through a private file keyed by this launcher's pid and MASTER_PORT)."""
+    import socket
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                LOCAL_WORLD_SIZE=str(n_ranks))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between processes on this driver
+    procs = []
+    for r in range(n_ranks):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr, stderr=None))
+    deadline = None if timeout_s is None else time.monotonic() + timeout_s
+    worst, failed_at = 0, None
+    try:
+        live = list(procs)
+        while live:
+            for p in list(live):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                live.remove(p)
+                if rc != 0:
+                    worst = worst or rc
+                    failed_at = failed_at or time.monotonic()
+            if live:
+                # a rank that died leaves the others in a collective: give them a minute, then stop exactly them
+                if (failed_at and time.monotonic() - failed_at > 60) or (deadline and time.monotonic() > deadline):
+                    for p in live:
+                        p.terminate()
+                    for p in live:
+                        try:
+                            p.wait(10)
+                        except subprocess.TimeoutExpired:
+                            p.kill()
+                    worst = worst or 124
+                    break
+                time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return worst
+
+
+def dry_rank_report(cfg, world, rank, local_rank, scaling, full_grid):
+    """CBO_BENCH_DRY_RANKS=1 (tests/test_host_logic.py): a rank says what it was launched as and which shard of which
+    problem it would sweep, without loading libcbo_hip.so or touching a GPU."""
+    from cbo_with_oop_amd.sharding import shard_bounds
+    X, y, Xs, grid, note = make_problem(cfg, world, scaling, full_grid)
+    begin, end = shard_bounds(Xs.shape[0], world, rank)
+    print(json.dumps({"dry_rank": rank, "world": world, "local_rank": local_rank, "shard": [int(begin), int(end)],
+                      "candidates_total": int(Xs.shape[0]), "n_obs": int(X.shape[0]), "scaling": scaling,
+                      "master": [os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")],
+                      "launcher_pid": os.getppid(), "lib_loaded": "cbo_with_oop_amd._lib" in sys.modules and
+                      sys.modules["cbo_with_oop_amd._lib"]._lib is not None}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -273,6 +342,11 @@ def main():
     args = ap.parse_args()
     if args.config is None:
         args.config = "c5" if args.dtype == "f32" else "c2"
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("CBO_BENCH_SELF_LAUNCH") == "1"):
+        # a plain `python bench.py --gpus N`: this process becomes the launcher (it has not loaded libcbo_hip.so and
+        # never touches the GPU) and starts one fresh rank process per GPU (CBO_BENCH_SELF_LAUNCH=1: also for N = 1, so
+        # that a one-GPU box can exercise the launcher and a one-rank RCCL communicator)
+        sys.exit(self_launch(args.gpus))
     if args.config == "c1":
         return bench_small_sets(args)
     cfg = CONFIGS[args.config]
@@ -289,10 +363,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-        args.gpus = world
+    args.gpus = world                                      # (a plain run with --gpus N > 1 became N ranks in main())
+    if os.environ.get("CBO_BENCH_DRY_RANKS"):
+        return dry_rank_report(cfg, world, rank, local_rank, scaling, args.full_grid)
 
     from cbo_with_oop_amd import CandidateGrid, CausalExpectedImprovement, _lib
     from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
@@ -396,6 +469,7 @@ def main():
             "config": args.config, "n_obs": n_obs, "candidates_total": int(total_cands), "grid": list(grid),
             "candidates_per_gpu": int(-(-total_cands // world)),
             "step_mode": step_mode, "exchange": exchange,
+            "rccl_ranks": comm.size()[0] if comm is not None else 0,     # what the communicator itself reports
             "parallelism": f"candidate shards x{world}, replicated posterior"}
         out["winner"] = {"index": int(winner[1]), "acq": float(winner[0])}
         out["kernel_sources_sha"] = kernel_sources_sha()

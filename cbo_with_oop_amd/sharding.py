@@ -137,6 +137,12 @@ class Communicator:
                 pass
         return comm
 
+    def size(self):
+        """(world, rank) as the RCCL communicator itself reports them (``cbo_comm_size``)."""
+        w, r = ctypes.c_int(0), ctypes.c_int(-1)
+        _lib.check(self._lib.cbo_comm_size(self._handle, ctypes.byref(w), ctypes.byref(r)))
+        return w.value, r.value
+
     def argmax(self, best_val, best_idx):
         bv, bi = ctypes.c_double(0.0), ctypes.c_int64(-1)
         _lib.check(self._lib.cbo_comm_argmax(self._handle, float(best_val), int(best_idx), ctypes.byref(bv),

@@ -171,3 +171,45 @@ def test_bench_configs_are_the_baseline_shapes_and_shard_as_stated():
     _, _, Xsf, _, _ = bench.make_problem(eight, 1, "strong", True)
     assert (Xs1.shape[0], Xs2.shape[0], Xs8.shape[0], Xsf.shape[0]) == (64, 128, 512, 512) and "1/8" in note1
     assert np.array_equal(Xs1, Xs8[:64])                                   # rank 0's shard of the 8-GPU run
+
+
+def _run_bench(args, extra_env, timeout=300):
+    import subprocess
+    import sys
+    env = dict(os.environ, **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), env=env, capture_output=True,
+                          text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_bench_starts_its_own_ranks_for_a_plain_multi_gpu_invocation():
+    """`python bench.py --gpus 2 --config c3` with no launcher around it (the form the driver uses): the process becomes
+    the launcher, two rank processes are its children with the launcher's environment contract (RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR = 127.0.0.1, one MASTER_PORT), each takes its contiguous shard of the fixed grid
+    (src/CBO.py:237-260 is the loop being sharded), rank 0's line is the launcher's standard output, and nothing has loaded
+    the library (CBO_HIP_LIB points nowhere: a load would have raised)."""
+    import json
+    out = _run_bench(["--gpus", "2", "--config", "c3"], {"CBO_BENCH_DRY_RANKS": "1", "CBO_HIP_LIB": "/nonexistent/libcbo_hip.so"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    r0 = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    r1 = [json.loads(ln) for ln in out.stderr.splitlines() if ln.startswith("{")]
+    assert len(r0) == 1 and len(r1) == 1                          # rank 0 alone owns stdout
+    a, b = r0[0], r1[0]
+    assert (a["dry_rank"], a["local_rank"], a["world"]) == (0, 0, 2) and (b["dry_rank"], b["local_rank"], b["world"]) == (1, 1, 2)
+    assert a["master"] == b["master"] and a["master"][0] == "127.0.0.1" and int(a["master"][1]) > 0
+    assert a["launcher_pid"] == b["launcher_pid"]                  # the rendezvous file's key (sharding._id_path)
+    assert a["shard"] == [0, 32768] and b["shard"] == [32768, 65536] and a["candidates_total"] == 65536
+    assert a["n_obs"] == 8192 and a["scaling"] == "strong" and not a["lib_loaded"] and not b["lib_loaded"]
+    # four ranks of the 8-GPU config: every rank keeps the 1/8 shard it has on 8 GPUs
+    out = _run_bench(["--gpus", "4", "--config", "c4"], {"CBO_BENCH_DRY_RANKS": "1", "CBO_HIP_LIB": "/nonexistent/libcbo_hip.so"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    shards = sorted(json.loads(ln)["shard"] for ln in (out.stdout + out.stderr).splitlines() if ln.startswith("{"))
+    assert shards == [[32768 * r, 32768 * (r + 1)] for r in range(4)]
+
+
+def test_bench_launcher_reports_the_worst_exit_code_of_its_ranks():
+    """A rank that cannot load the library fails loudly (no CPU fallback) and the launcher's exit code says so."""
+    out = _run_bench(["--gpus", "2", "--config", "c3", "--steps", "1"], {"CBO_HIP_LIB": "/nonexistent/libcbo_hip.so"})
+    assert out.returncode != 0
+    assert "libcbo_hip.so not found" in out.stderr and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

@@ -794,6 +794,16 @@ def test_bench_exchange_over_rccl_single_rank(hip):
     b = json.loads([l for l in launched.stdout.splitlines() if l.startswith("{")][-1])
     assert a["winner"] == b["winner"]
     assert b["n_gpus"] == 1 and "RCCL" in b["config"]["exchange"] and "RCCL" not in a["config"]["exchange"]
+    assert b["config"]["rccl_ranks"] == 1 and a["config"]["rccl_ranks"] == 0
+    # the self-launch form (what a plain `python bench.py --gpus N` does for N > 1; CBO_BENCH_SELF_LAUNCH=1 takes that
+    # path with the one rank a one-GPU box can hold): bench.py is its own launcher, the rank is its child
+    own = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common,
+                         env=dict(env, CBO_BENCH_SELF_LAUNCH="1"), capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert own.returncode == 0, own.stderr[-2000:]
+    lines = [l for l in own.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    c = json.loads(lines[0])
+    assert c["winner"] == a["winner"] and c["n_gpus"] == 1 and c["config"]["rccl_ranks"] == 1
 
 
 def test_bench_lines_of_the_other_configs_carry_the_contract(hip):
