@@ -148,8 +148,7 @@ class CBOAcquisitionPath:
         from .sharding import ERROR_CANDIDATE, NO_CANDIDATE
         from .utils_functions.cost_functions import Cost
         # A rank that fails (a model that is not positive definite, a device error) must not leave the others blocked in
-        # the exchange: it takes part in every exchange of the trial with an error record (NaN wins every reduction), and
-        # every rank raises once the exchanges are done.
+        # an exchange: every rank takes part in one failure-flag exchange per trial and all of them raise when it is set.
         local, failure = {}, None
         try:
             mine = [s for s in range(self.es_size) if mode == "candidates" or s % world == rank]
@@ -165,7 +164,19 @@ class CBOAcquisitionPath:
                 local = {s: ys[i] for i, s in enumerate(mine)}
         except Exception as exc:  # noqa: BLE001 -- re-raised below, after the exchanges
             failure = exc
+        # One explicit flag per trial says whether any rank failed (cbo_comm_max_f64 of 0 / 1): it is not encoded in the
+        # arg-max payload, where a healthy rank's genuine NaN acquisition (NaN is maximal, lowest index wins) could beat an
+        # error record and leave the ranks disagreeing about whether to go on.  Every rank raises when it is set, before any
+        # arg-max exchange.  (A communicator without ``max`` -- a caller's own object with only world / rank / argmax --
+        # keeps the error record in the payload.)
+        flag = getattr(self.comm, "max", None)
         winners, failed_somewhere = [], False
+        if flag is not None:
+            failed_somewhere = float(flag(1.0 if failure is not None else 0.0)) > 0.0
+            if failure is not None:
+                raise failure
+            if failed_somewhere:
+                raise RuntimeError("compute_best_acquisition_values: another rank failed during this trial's sweep")
         for s in range(self.es_size):
             val, idx = (float("nan"), ERROR_CANDIDATE) if failure is not None else local.get(s, (-np.inf, NO_CANDIDATE))
             val, idx = self.comm.argmax(val, idx)                       # identical on every rank

@@ -1259,9 +1259,18 @@ static int check_sweep_args(const cbo_gp *g, const cbo_cands *k, int task)
 // enqueue_finish only queues (cbo_gp_fit_sweep queues it behind the closing launch, ahead of its one synchronisation:
 // the factorisation's status and the winner come back together); complete_finish reads the winner after the stream has
 // been synchronised.
+// the per-candidate vectors of the epilogue to the caller's host buffers (queued; the caller synchronises)
+static int copy_posterior_out(cbo_ctx *c, const cbo_cands *k, double *acq_out, double *mean_out, double *var_out)
+{
+    if (acq_out) HIP_TRY(hipMemcpyAsync(acq_out, c->acq, sizeof(double) * k->m, hipMemcpyDeviceToHost, c->stream));
+    if (mean_out) HIP_TRY(hipMemcpyAsync(mean_out, c->mean, sizeof(double) * k->m, hipMemcpyDeviceToHost, c->stream));
+    if (var_out) HIP_TRY(hipMemcpyAsync(var_out, c->var, sizeof(double) * k->m, hipMemcpyDeviceToHost, c->stream));
+    return CBO_OK;
+}
+
 static int enqueue_finish(cbo_gp *g, cbo_cands *k, double y_best, int task, double ei_jitter, double cost, double *acq_out,
                           double *mean_out, double *var_out, const double *q_src, const double *mu_src,
-                          bool with_status = false)
+                          bool with_status = false, bool copy_out = true)
 {
     cbo_ctx *c = g->ctx;
     const bool causal = g->X.sv != nullptr;
@@ -1279,9 +1288,7 @@ static int enqueue_finish(cbo_gp *g, cbo_cands *k, double y_best, int task, doub
                             with_status ? g->info : nullptr, with_status ? c->h_info : nullptr);
     }
     HIP_TRY(hipGetLastError());
-    if (acq_out) HIP_TRY(hipMemcpyAsync(acq_out, c->acq, sizeof(double) * k->m, hipMemcpyDeviceToHost, c->stream));
-    if (mean_out) HIP_TRY(hipMemcpyAsync(mean_out, c->mean, sizeof(double) * k->m, hipMemcpyDeviceToHost, c->stream));
-    if (var_out) HIP_TRY(hipMemcpyAsync(var_out, c->var, sizeof(double) * k->m, hipMemcpyDeviceToHost, c->stream));
+    if (copy_out) return copy_posterior_out(c, k, acq_out, mean_out, var_out);
     return CBO_OK;
 }
 
@@ -1528,7 +1535,12 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
     SweepPipe pipe = make_pipe(g, Vws, ldv, k->m_pad, qbuf, mubuf);
     // updates in groups of pairs where the bulk stream bounds the pipeline (CBO_HIP_PIPE_GROUP: 1 = never, G >= 2 = groups
     // of G pairs whatever the shape; default: automatic)
-    static const int pipe_group_env = [] { const char *e = std::getenv("CBO_HIP_PIPE_GROUP"); return e ? std::atoi(e) : 0; }();
+    // (groups beyond 4 pairs -- K = 1024 -- are not covered by the tests: clamped)
+    static const int pipe_group_env = [] {
+        const char *e = std::getenv("CBO_HIP_PIPE_GROUP");
+        const int v = e ? std::atoi(e) : 0;
+        return v < 0 ? 0 : (v > 4 ? 4 : v);
+    }();
     pipe.group = pipe_group_env >= 2 ? pipe_group_env : (pipe_group_env == 0 && k->m_pad / kStrip >= c->n_cu && g->n_pad >= 4096) ? 2 : 0;
     int pairs = pipeline_pairs(c, g->n_pad, k->m_pad);
     if (pipe.group >= 2 && c->pipe_tail_frac < 0.0 && pairs >= pipe.group && pairs * 256 < (int)g->n_pad)
@@ -1579,10 +1591,12 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
         HIP_TRY(hipEventRecord(c->ev_join2, c->bulk_stream));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
         HIP_TRY(hipGetLastError());
-        // the epilogue rides behind the closing launch on the assumption that the factorisation succeeded (it reads q, mu
-        // where the sweep left them); an attempt that failed is repeated and its epilogue's outputs are overwritten
+        // the epilogue's KERNELS ride behind the closing launch on the assumption that the factorisation succeeded (they
+        // read q, mu where the sweep left them, and write device scratch and the pinned winner record only); the caller's
+        // acq / mean / var buffers are written after the status word is known to be good (below): on an error return --
+        // CBO_ERR_NOT_PD after the ladder is exhausted -- they are left untouched, as the two-call sequence leaves them
         if (speculate) {
-            rc = enqueue_finish(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, qbuf, mubuf, true);
+            rc = enqueue_finish(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, qbuf, mubuf, true, false);
             if (rc != CBO_OK) return rc;
         } else {
             HIP_TRY(hipMemcpyAsync(c->h_info, g->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1610,6 +1624,11 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
     if (Vws != c->V) { k->v_stamp = g->fit_stamp; k->v_rows = g->n; }
     if (qbuf == k->q) k->fit_stamp = g->fit_stamp;         // the candidates' q, mu are this fit's
     if (speculate) {
+        if (acq_out || mean_out || var_out) {
+            rc = copy_posterior_out(c, k, acq_out, mean_out, var_out);
+            if (rc != CBO_OK) return rc;
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
         complete_finish(c, best_val, best_idx);
         return CBO_OK;
     }

@@ -1388,14 +1388,13 @@ size_t small_sets_scratch_doubles(int n_sets, int blocks_per_set) { return (size
 void launch_small_sets(hipStream_t s, const cbo_small_set *sets, int n_sets, int blocks_per_set, double *scratch,
                        double *part_val, int64_t *part_idx, int *info, int *ticket, cbo_small_result *out, int seq)
 {
-    static bool once = [] {
+    // per call, on the current device (several devices in one process: see vec_chain_opt_in); only the instantiation used
+    if (n_sets <= kSmallByValue)
         hipFuncSetAttribute(reinterpret_cast<const void *>(small_sets_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmallShared));
+    else
         hipFuncSetAttribute(reinterpret_cast<const void *>(small_sets_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmallShared));
-        return true;
-    }();
-    (void)once;
     SmallSetArgs args{};
     const dim3 grid((unsigned)blocks_per_set, (unsigned)n_sets);
     // Few candidate blocks per set (the reference's 100-200 candidates): every workgroup factors its set's model itself,
@@ -2289,25 +2288,33 @@ static int vec_spin_limit()
     return e ? std::atoi(e) : kFusedSpinLimit;
 }
 
+// ~151 KB of dynamic LDS needs the opt-in ON THE CURRENT DEVICE: done per call (cheap), as launch_cholesky does, so that
+// every device of a process that drives several (cbo_comm_init_all) is covered -- a function-local static would cover
+// only the device that was current at the first call.  false: the runtime refused, take the per-block launches.
+static bool vec_chain_opt_in()
+{
+    const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void *>(backsolve_chain_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(VecChainShared));
+    const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void *>(forward_chain_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(VecChainShared));
+    if (a == hipSuccess && b == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+}
+
 bool launch_backsolve_chain(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt,
                             const double *src, int64_t src_stride, double *work, double *out, int *info)
 {
     const int nb = (int)(n_pad / 128);
     if (!vec_chain_enabled(nb)) return false;
-    static const bool attr = [] {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(backsolve_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)sizeof(VecChainShared));
-        hipFuncSetAttribute(reinterpret_cast<const void *>(forward_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)sizeof(VecChainShared));
-        return true;
-    }();
-    (void)attr;
+    if (!vec_chain_opt_in()) return false;
     hipLaunchKernelGGL(copy_strided_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, src, src_stride,
                        n_pad, work);
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, out, n_pad);
     hipLaunchKernelGGL(backsolve_chain_kernel, dim3(nb), dim3(256), sizeof(VecChainShared), s, A, lda, invDt, nb, work, out,
                        info, vec_spin_limit());
-    return true;
+    // a launch the runtime refused (nothing ran): the caller takes the per-block launches, which fill `out` themselves
+    return hipGetLastError() == hipSuccess;
 }
 
 bool launch_forward_chain(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt, const double *w,
@@ -2315,18 +2322,11 @@ bool launch_forward_chain(hipStream_t s, const double *A, int64_t lda, int64_t n
 {
     const int nb = (int)(n_pad / 128);
     if (!vec_chain_enabled(nb)) return false;
-    static const bool attr = [] {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(backsolve_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)sizeof(VecChainShared));
-        hipFuncSetAttribute(reinterpret_cast<const void *>(forward_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)sizeof(VecChainShared));
-        return true;
-    }();
-    (void)attr;
+    if (!vec_chain_opt_in()) return false;
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, out, n_pad);
     hipLaunchKernelGGL(forward_chain_kernel, dim3(nb), dim3(256), sizeof(VecChainShared), s, A, lda, invDt, nb, w, out,
                        info, vec_spin_limit());
-    return true;
+    return hipGetLastError() == hipSuccess;          // (forward_chain_kernel leaves `w` untouched: the fallback can still use it)
 }
 
 // dst[i] = V[i * ldv] for i < n_pad: one column of a row-major workspace as a contiguous vector

@@ -1207,8 +1207,9 @@ void launch_gemm_update(hipStream_t s, const double *U, int64_t ldu, const doubl
                         bool half_lds, bool upper_only, const int *skip_if)
 {
     if (i0_begin >= i0_end || m_pad <= 0 || klen <= 0) return;
-    // klen is 128 or 256 (a multiple of the 32-row stage and at least two stages, which the vmcnt bookkeeping
-    // assumes), the row range a multiple of 128
+    // klen: a multiple of the stage height KB (16 or 32) and at least two stages, which the vmcnt bookkeeping assumes --
+    // 128 or 256 for a panel (pair), 512 for the bulk groups of launch_cholesky, 256 G for the groups of a pipelined sweep
+    // (G = 2..4, cbo_gp_fit_sweep clamps CBO_HIP_PIPE_GROUP to that); the row range a multiple of 128
     const int chunk_rows = chunk_blocks * kRB;
     const unsigned chunks = (unsigned)((i0_end - i0_begin + chunk_rows - 1) / chunk_rows);
     const dim3 grid((unsigned)(m_pad / kStrip), chunks);

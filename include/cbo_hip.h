@@ -224,7 +224,8 @@ int cbo_acq_sweep(cbo_gp *gp, cbo_cands *cands, double y_best, int task, double 
  * sweep's substitution advances panel by panel on a second stream while the factorisation's chain of short
  * kernels runs.  This is the pair of calls CBO.intervene() makes for the set it has just intervened on
  * (src/Monitor.py:160 set_data -> refit; src/CBO.py:250-257 find_next_y_point).  Same outputs as the two calls
- * in sequence.  tries_out / jitter_out as in cbo_gp_fit (may be NULL). */
+ * in sequence, also on failure: on a non-OK return (CBO_ERR_NOT_PD once jitchol's ladder is exhausted) acq_out /
+ * mean_out / var_out / best_val / best_idx are left untouched.  tries_out / jitter_out as in cbo_gp_fit (may be NULL). */
 int cbo_gp_fit_sweep(cbo_gp *gp, cbo_cands *cands, double y_best, int task, double ei_jitter, double cost,
                      double *acq_out, double *mean_out, double *var_out, double *best_val,
                      int64_t *best_idx, int *tries_out, double *jitter_out);

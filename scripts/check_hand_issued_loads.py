@@ -2,7 +2,9 @@
 issued by inline asm, so the compiler does not know their results arrive later.  That is only sound if no instruction
 touches a destination register between the load and the point where the kernel has waited for it (the block end, first
 use: v_xor / v_mov / ds_write).  This script compiles the file to ISA and verifies exactly that, for both instantiations.
-usage: python scripts/check_hand_issued_loads.py  (exit code 0 = ok); also run by tests/test_abi.py"""
+usage: python scripts/check_hand_issued_loads.py [device-assembly.s]  (exit code 0 = ok).  With a path (what
+cbo_with_oop_amd/csrc/Makefile does for the product AND the DIAG=1 object, on the assembly that becomes the object) it
+checks that file; without, it compiles the source itself (CHECK_DIAG=1: with -DCBO_DIAG_KNOBS); also run by tests/test_abi.py"""
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -72,12 +74,17 @@ def check(asm_text):
 
 
 def main():
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "k.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
-                               "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(SRC), "-S", "--cuda-device-only",
-                               SRC, "-o", out], stderr=subprocess.DEVNULL)
-        checked, problems = check(open(out).read())
+    if len(sys.argv) > 1:
+        # the Makefile's form: the device assembly of the very compilation that becomes the object (-save-temps=obj)
+        checked, problems = check(open(sys.argv[1]).read())
+    else:
+        flags = ["-DCBO_DIAG_KNOBS"] if os.environ.get("CHECK_DIAG") else []
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "k.s")
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950"] + flags +
+                                  ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(SRC), "-S",
+                                   "--cuda-device-only", SRC, "-o", out], stderr=subprocess.DEVNULL)
+            checked, problems = check(open(out).read())
     print(f"checked {checked} hand-issued load sites; {len(problems)} problem(s)")
     for p in problems:
         print("  ", p)

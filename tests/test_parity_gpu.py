@@ -1667,6 +1667,15 @@ def test_path_failure_on_one_rank_reaches_every_rank(hip, monkeypatch):
             self.calls.append((val, idx))
             return (float("nan"), ERROR_CANDIDATE) if self.poisoned else (val, idx)
 
+    class FlagComm(Comm):                       # a sharding.Communicator has max(): the failure travels as its own flag
+        def __init__(self, world, rank, poisoned=False):
+            super().__init__(world, rank, poisoned)
+            self.flags = []
+
+        def max(self, value):
+            self.flags.append(value)
+            return 1.0 if self.poisoned else value
+
     def make(comm):
         path = CBOAcquisitionPath(GaussianProcessType.NON_CAUSAL_GP, es, ToyGraph.get_cost_structure(1), "min", xs, ys,
                                   [ToyGraph.bounds(s) for s in es], grid_shapes=[[64], [64]], comm=comm)
@@ -1690,6 +1699,24 @@ def test_path_failure_on_one_rank_reaches_every_rank(hip, monkeypatch):
     with pytest.raises(RuntimeError, match="another rank failed"):
         path.compute_best_acquisition_values(0.0)
     assert len(comm.calls) == len(es)
+    # with the explicit flag (the real communicator): ONE flag exchange, then every rank raises before any arg-max exchange
+    # -- a healthy rank's genuine NaN acquisition can no longer outvote an error record
+    comm = FlagComm(2, 0)
+    path = make(comm)
+    monkeypatch.setattr(cbo_module, "find_next_y_points", boom)
+    with pytest.raises(ValueError, match="sweep failed on this rank"):
+        path.compute_best_acquisition_values(0.0)
+    assert comm.flags == [1.0] and comm.calls == []
+    monkeypatch.undo()
+    comm = FlagComm(2, 0, poisoned=True)
+    path = make(comm)
+    with pytest.raises(RuntimeError, match="another rank failed"):
+        path.compute_best_acquisition_values(0.0)
+    assert comm.flags == [0.0] and comm.calls == []
+    comm = FlagComm(2, 0)                       # nobody failed: the flag exchange, then one arg-max exchange per set
+    path = make(comm)
+    path.compute_best_acquisition_values(0.0)
+    assert comm.flags == [0.0] and len(comm.calls) == len(es)
 
 
 def test_prediction_gradients_for_a_whole_grid(hip, monkeypatch):
