@@ -1,7 +1,7 @@
 """What the parity tests actually enforce, measured per golden fixture on the GPU: relative error of the
 HIP path and of the fp64 oracle against the 80-bit arbiter, the bound the tests apply (rtol + slack x oracle error),
 and the HIP-vs-oracle difference, for posterior mean (shifted by 3 max|y| as in the test), variance and acquisition.
-usage: python scripts/tolerance_report.py"""
+usage: python scripts/tolerance_report.py [--large]   (--large adds the 16384-observation configs c4 / c5 on bench.py's data)"""
 import os
 import sys
 import warnings
@@ -53,3 +53,35 @@ for name in FIXTURES:
     out.append(f" {'same' if res['best_idx'] == int(f['best_idx']) else 'DIFFERS'}")
     print("".join(out))
     m.close()
+
+if "--large" in sys.argv:
+    # The two 16384-observation configurations on bench.py's own data (a 257-candidate subsample of the rank's shard).  The
+    # 80-bit restatement is not affordable there; the arbiter of the mean is oracle/truth.py:refined_mean (exact kernel
+    # entries, iterative refinement with long-double residuals), the acquisition is taken from the arbiter's mean and the
+    # oracle's variance, and the variance is quoted against the oracle itself.
+    import bench
+    from oracle.truth import refined_mean
+    print()
+    print(f"{'config (device path)':26s} {'tries':>5s} | {'mean / max|y|: dev-arb':>22s} {'oracle-arb':>10s} {'dev-oracle':>10s} |"
+          f" {'var: dev-oracle abs':>19s} {'rel':>9s} | {'acq / max|acq|: dev-arb':>23s} {'oracle-arb':>10s} | argmax")
+    for cname in ("c4", "c5"):
+        X, y, Xs, grid, note = bench.make_problem(bench.CONFIGS[cname], 1, "strong", False)
+        y_best, cost = float(y.min()), 3.0
+        post = O.fit(X, y)
+        sub = np.arange(0, Xs.shape[0], 128)
+        acq, _, _, mu, var = O.acquisition_sweep(post, Xs[sub], y_best, cost=cost)
+        tm, _ = refined_mean(post, Xs[sub], exact_entries=True)
+        acq_t = O.expected_improvement(tm, var, y_best, "min", 0.0) / cost
+        scale = np.max(np.abs(y))
+        for dtype in (("f64",) if cname == "c4" else ("f64", "f32")):
+            m = HipGaussianProcess(X, y, dtype=dtype)
+            res = CausalExpectedImprovement(y_best, "min", m).sweep(Xs, cost=cost, want_acq=True, want_posterior=True)
+            amax = np.max(np.abs(res["acq"]))
+            o_best = int(sub[np.argmax(acq[:, 0])])
+            d_best = int(sub[np.argmax(res["acq"][sub, 0])])
+            print(f"{cname + ' bench data (' + dtype + ')':26s} {m.jitter_tries:5d} | {np.max(np.abs(res['mean'][sub] - tm)) / scale:22.2e} "
+                  f"{np.max(np.abs(mu - tm)) / scale:10.2e} {np.max(np.abs(res['mean'][sub] - mu)) / scale:10.2e} | "
+                  f"{np.max(np.abs(res['var'][sub] - var)):19.2e} {np.max(np.abs(res['var'][sub] - var) / var):9.2e} | "
+                  f"{np.max(np.abs(res['acq'][sub] - acq_t)) / amax:23.2e} {np.max(np.abs(acq - acq_t)) / amax:10.2e} | "
+                  f"{'same' if o_best == d_best else 'DIFFERS'} (on the subsample)")
+            m.close()
