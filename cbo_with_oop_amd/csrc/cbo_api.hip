@@ -705,15 +705,17 @@ static int next_jitter(cbo_gp *g, int *tries, double *jitter)
         // diag of Ky as assembled (jitter-free): variance + v_i + (noise + 1e-8); the kernel's own
         // diagonal differs from this only when zero_diag is off and |x|^2 rounds differently from
         // x.x, i.e. by O(1e-16) relative -- irrelevant for a 1e-6 * mean(diag) jitter.
-        double sum = 0.0;
+        // (summed in extended precision and rounded once: numpy's pairwise diagA.mean() is exact for n equal entries,
+        //  a sequential double sum of 16384 of them is 4e-13 off)
+        long double sum = 0.0L;
         bool nonpos = false;
         for (int64_t i = 0; i < g->n; ++i) {
             const double dv = g->h.variance + (g->h_pv.empty() ? 0.0 : g->h_pv[i]) + (g->noise_var + kGpyDiagJitter);
             if (!(dv > 0.0)) nonpos = true;
-            sum += dv;
+            sum += (long double)dv;
         }
         if (nonpos) return fail(CBO_ERR_NONPOS_DIAG, "not pd: non-positive diagonal elements");
-        *jitter = sum / (double)g->n * 1e-6;
+        *jitter = (double)(sum / (long double)g->n) * 1e-6;
     } else {
         *jitter *= 10.0;
     }

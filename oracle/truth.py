@@ -111,3 +111,37 @@ def refined_mean(post, Xs, mXs=None, vXs=None, iterations=4, exact_entries=False
     if mXs is not None:
         mean = mean + np.asarray(mXs, dtype=np.float64).reshape(-1, 1)
     return mean, np.asarray(alpha, dtype=np.float64)
+
+
+def refined_variance(post, Xs, vXs=None, iterations=4, include_noise=True):
+    """Posterior variance at a FEW points for the exact-arithmetic kernel on the oracle's inputs (entries from direct
+    coordinate differences, the fit's diagonal add and jitter): kss - k*^T Ky^-1 k* with Ky w = k* solved by iterative
+    refinement (fp64 Cholesky factor as the solver, long-double residuals) and the final inner product in long double.
+    The arbiter of the variance at sizes where the all-long-double restatement (gp_truth_predict) is not affordable;
+    O(n^2 m) long-double work per iteration, so keep m small (tens).  Plain RBF models only.  Test infrastructure only."""
+    from scipy.linalg import lapack
+    from . import gp_oracle as O
+    assert post.vX is None, "plain RBF models only"
+    Xs = np.ascontiguousarray(Xs, dtype=np.float64)
+    K = _exact_rbf(post.X, post.X, post.variance, post.lengthscale)
+    K[np.diag_indices_from(K)] += post.noise_var + O.GPY_DIAG_JITTER + post.jitter
+    L, info = lapack.dpotrf(K, lower=1, clean=0, overwrite_a=0)
+    assert info == 0, info
+    Kx = _exact_rbf(post.X, Xs, post.variance, post.lengthscale)
+    kl = Kx.astype(np.longdouble)
+    w0, info = lapack.dpotrs(L, Kx, lower=1)
+    assert info == 0
+    w = w0.astype(np.longdouble)
+    block = 1024
+    for _ in range(iterations):
+        res = np.empty_like(kl)
+        for i in range(0, K.shape[0], block):
+            res[i:i + block] = kl[i:i + block] - K[i:i + block].astype(np.longdouble) @ w
+        d, info = lapack.dpotrs(L, np.asarray(res, dtype=np.float64), lower=1)
+        assert info == 0
+        w = w + d.astype(np.longdouble)
+    var = np.longdouble(post.variance) - np.sum(kl * w, axis=0)
+    var = np.maximum(var, np.longdouble(O.GPY_VAR_CLIP))
+    if include_noise:
+        var = var + np.longdouble(post.noise_var)
+    return np.asarray(var, dtype=np.float64)[:, None]

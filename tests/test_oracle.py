@@ -220,3 +220,24 @@ def test_refined_mean_with_exact_entries_equals_the_long_double_restatement():
         assert np.max(np.abs(rm - mu)) < 1e-6 * np.max(np.abs(y))          # the oracle's own solve is accurate ...
         if shift:
             assert np.max(np.abs(mu - tm)) > 100 * np.max(np.abs(em - tm))  # ... its entries are what differs
+
+
+def test_refined_variance_equals_the_long_double_restatement():
+    """oracle/truth.py:refined_variance -- exact kernel entries, Ky w = k* by iterative refinement with long-double
+    residuals, kss - k*^T w in long double -- reproduces the all-long-double restatement's variance to 1e-7 relative (the
+    kernel entries themselves are fp64: 1e-16 absolute next to variances of 5e-9) where
+    the fp64 oracle's own variance is orders of magnitude further off (coordinates around 2350 as on the simplified coral
+    graph's T axis).  The arbiter of the variance for BASELINE config 4 at its real size."""
+    from oracle.truth import refined_variance, truth_predict
+    rng = np.random.default_rng(5)
+    for n, shift in ((400, 0.0), (400, 2350.0)):
+        X = rng.uniform(-4, 4, (n, 2)) + shift
+        y = np.cos(X[:, :1]) - np.exp(-(X[:, 1:] - shift) / 20) + 0.1 * rng.standard_normal((n, 1))
+        Xs = rng.uniform(-4, 4, (12, 2)) + shift
+        post = O.fit(X, y)
+        _, var = O.predict(post, Xs)
+        _, tv, _ = truth_predict(X, y, Xs, diag_add=1e-10 + 1e-8 + post.jitter)
+        rv = refined_variance(post, Xs)
+        assert np.max(np.abs(rv - tv) / tv) < 1e-7, np.max(np.abs(rv - tv) / tv)
+        if shift:
+            assert np.max(np.abs(var - tv) / tv) > 100 * np.max(np.abs(rv - tv) / tv)

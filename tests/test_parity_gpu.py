@@ -533,9 +533,9 @@ def test_c4_bench_problem_against_oracle_and_arbiter(hip):
     grid), through the call the bench times (cbo_gp_fit_sweep; above 12288 rows it does not overlap).  The model is the one
     the reference builds at src/GaussianProcessFactory.py:57-60.  On this data Ky is not positive definite as assembled:
     jitchol's first retry is exercised on every fit (asserted).  The oracle (dpotrf of a 16384^2 matrix on the host, twice)
-    checks a 257-candidate subsample plus the device's top candidates: variance at rtol 1e-5 + the 1e-13 absolute floor of
-    test_c4_size_chunked_workspace; mean and acquisition by the arbiter rule of tests/conftest.py with
-    oracle/truth.py:refined_mean (exact kernel entries, iterative refinement with long-double residuals) as the arbiter --
+    checks a 257-candidate subsample plus the device's top candidates: mean, variance and acquisition by the arbiter rule of
+    tests/conftest.py (device error <= 1e-5 + 8 x the oracle's own) with oracle/truth.py:refined_mean / refined_variance
+    (exact kernel entries, iterative refinement with long-double residuals) as the arbiter --
     at T ~ 2350 GPy's |x|^2 + |x'|^2 - 2 x.x' loses 1e-9 of every entry, which jitchol's 1e-6 jitter under 16384 points
     turns into 1e-3 of the mean in oracle and device alike; identical arg-max, or a tie within 1e-12."""
     import bench
@@ -550,15 +550,31 @@ def test_c4_bench_problem_against_oracle_and_arbiter(hip):
     assert not m.stale and int(np.argmax(res["acq"][:, 0])) == res["best_idx"]
     post = O.fit(X, y)
     assert m.jitter_tries == post.tries and post.tries >= 1, (m.jitter_tries, post.tries)      # the retry IS exercised
-    assert m.jitter == post.jitter
+    assert np.isclose(m.jitter, post.jitter, rtol=1e-12, atol=0.0), (m.jitter, post.jitter)
     top = np.argsort(-res["acq"][:, 0], kind="stable")[:64]
     sub = np.unique(np.concatenate([np.arange(0, 32768, 128), top]))
     acq, _, _, mu, var = O.acquisition_sweep(post, Xs[sub], y_best, cost=cost)
     problems = []
-    bad = np.abs(res["var"][sub] - var) > 1e-5 * var + 1e-13
+    # Variance.  Two faithful fp64 evaluations of GPy's formula differ here by far more than 1e-5: its |x|^2 + |x'|^2 - 2 x.x'
+    # carries 1e-9 of absolute error per kernel entry at T ~ 2350 (which entry gets which error depends on the order of the
+    # three coordinate products), and Ky^-1 has norm 1e6 under jitchol's 1e-6 jitter.  So the variance goes by the arbiter
+    # rule too: on 16 candidates (the device's winner among them) the arbiter is the exact-entry kernel solved by iterative
+    # refinement in long double (oracle/truth.py:refined_variance, pinned against the 80-bit restatement in
+    # tests/test_oracle.py), and the device may be off by 1e-5 relative plus 8 x the oracle's own error; on the whole
+    # subsample the device stays within 1e-5 relative + 16 x that measured error of the oracle (absolute).
+    from oracle.truth import refined_variance
+    arb = np.unique(np.concatenate([[int(np.searchsorted(sub, res["best_idx"]))], np.linspace(0, sub.size - 1, 15).astype(int)]))
+    tv = refined_variance(post, Xs[sub[arb]])
+    oracle_verr = np.max(np.abs(var[arb] - tv))
+    dev_verr = np.max(np.abs(res["var"][sub[arb]] - tv))
+    print(f"config-4 var: |oracle - arbiter| {oracle_verr:.3e}, |device - arbiter| {dev_verr:.3e}, |device - oracle| "
+          f"{np.max(np.abs(res['var'][sub] - var)):.3e}, variances {np.min(var):.2e} .. {np.max(var):.2e}")
+    if np.any(np.abs(res["var"][sub[arb]] - tv) > 1e-5 * tv + 8.0 * oracle_verr):
+        problems.append(f"var: |device - arbiter| {dev_verr:.3e} > 1e-5 * var + 8 * {oracle_verr:.3e}")
+    bad = np.abs(res["var"][sub] - var) > 1e-5 * var + 1e-13 + 16.0 * oracle_verr
     if np.any(bad):
-        problems.append(f"var vs oracle: {int(bad.sum())} of {sub.size} beyond rtol 1e-5 + 1e-13, worst "
-                        f"{np.max(np.abs(res['var'][sub] - var) / var):.3e}")
+        problems.append(f"var vs oracle: {int(bad.sum())} of {sub.size} beyond rtol 1e-5 + 16 * {oracle_verr:.3e}, worst "
+                        f"{np.max(np.abs(res['var'][sub] - var)):.3e}")
     tm, _ = refined_mean(post, Xs[sub], exact_entries=True)
     scale = np.max(np.abs(y))
     oracle_err, dev_err = np.max(np.abs(mu - tm)), np.max(np.abs(res["mean"][sub] - tm))
@@ -567,7 +583,10 @@ def test_c4_bench_problem_against_oracle_and_arbiter(hip):
     if dev_err > 1e-5 * scale + 8.0 * oracle_err:
         problems.append(f"mean: |device - arbiter| {dev_err:.3e} > 1e-5 * {scale:.2f} + 8 * {oracle_err:.3e}")
     amax = np.max(np.abs(res["acq"]))
-    acq_t = O.expected_improvement(tm, var, y_best, "min", 0.0) / cost         # the arbiter's mean, the oracle's variance
+    # acquisition: from the arbiter's mean and, where it exists (the 16 candidates), the arbiter's variance
+    var_t = var.copy()
+    var_t[arb] = tv
+    acq_t = O.expected_improvement(tm, var_t, y_best, "min", 0.0) / cost
     oracle_acq_err, dev_acq_err = np.max(np.abs(acq - acq_t)), np.max(np.abs(res["acq"][sub] - acq_t))
     print(f"config-4 acq: |oracle - arbiter| {oracle_acq_err:.3e}, |device - arbiter| {dev_acq_err:.3e}, max|acq| {amax:.3e}")
     if dev_acq_err > 1e-5 * amax + 8.0 * oracle_acq_err:
