@@ -133,8 +133,6 @@ struct cbo_gp {
     double noise_var = 0.0;
     double *A = nullptr;             // [n_pad][lda] Ky -> U, rhs strip at column n_pad
     double *invDt = nullptr;         // [n_pad/16][16][16]
-    double *Winv = nullptr;          // [n_pad/128][128][128] W^T = inv(U[b,b]) per 128-row block, and per block whether the
-    int *wflag = nullptr;            // strip kernels multiply by it (models of more than one block only; see block_inverse_kernel)
     double *alpha = nullptr;         // [2*n_pad]
     double *z = nullptr;             // [n_pad] contiguous copy of L^-1 r
     int *info = nullptr;
@@ -534,8 +532,7 @@ static void free_gp_data(cbo_gp *g)
 {
     hipFree(g->X.xs); hipFree(g->X.sq); hipFree(g->X.sv); hipFree(g->X.pm); hipFree(g->X.pv);
     hipFree(g->raw); hipFree(g->y); hipFree(g->A); hipFree(g->invDt); hipFree(g->alpha); hipFree(g->z); hipFree(g->lvec);
-    hipFree(g->Uf); hipFree(g->invF); hipFree(g->T); hipFree(g->invT); hipFree(g->Winv); hipFree(g->wflag);
-    g->Winv = nullptr; g->wflag = nullptr;
+    hipFree(g->Uf); hipFree(g->invF); hipFree(g->T); hipFree(g->invT);
     g->Uf = g->invF = nullptr; g->f32_stamp = 0;
     g->T = g->invT = nullptr; g->t_stamp = 0;
     g->X = PointSet{};
@@ -567,12 +564,6 @@ static int upload_gp_data(cbo_gp *g, int64_t n, const double *X, const double *y
         HIP_TRY(hipMalloc(&g->y, sizeof(double) * n_pad));
         HIP_TRY(hipMalloc(&g->A, sizeof(double) * n_pad * g->lda));
         HIP_TRY(hipMalloc(&g->invDt, sizeof(double) * (n_pad / 16) * 256));
-        // one-block models (every model the reference builds) keep the substitution form: the one-launch multi-set kernel
-        // (small_sets_kernel) solves them that way and the two paths give the same bits
-        if (n_pad > kPadN && block_inverse_kappa_max() > 0.0) {
-            HIP_TRY(hipMalloc(&g->Winv, sizeof(double) * (size_t)n_pad * 128));
-            HIP_TRY(hipMalloc(&g->wflag, sizeof(int) * (size_t)(n_pad / 128)));
-        }
         HIP_TRY(hipMalloc(&g->alpha, sizeof(double) * 2 * n_pad));
         HIP_TRY(hipMalloc(&g->z, sizeof(double) * n_pad));
         HIP_TRY(hipMalloc(&g->lvec, sizeof(double) * n_pad));
@@ -691,7 +682,6 @@ static void enqueue_factor(cbo_gp *g, double jitter)
     {
         PhaseScope ps(c, PH_CHOL);
         launch_cholesky(c->stream, c->side_stream, c->chol_events, g->A, g->lda, g->n_pad, g->invDt, g->info);
-        launch_block_inverses(c->stream, g->A, g->lda, 0, (int)(g->n_pad / 128), g->invDt, g->Winv, g->wflag, g->info);
     }
 }
 
@@ -1052,8 +1042,6 @@ static SweepPipe make_pipe(cbo_gp *g, double *V, int64_t ldv, int64_t cols, doub
     SweepPipe pipe{};
     pipe.stream = c->sweep_stream;
     pipe.bulk = c->bulk_stream;
-    pipe.Winv = g->Winv; pipe.wflag = g->wflag;
-    pipe.inverses_ready = true;                          // a fitted model's; cbo_gp_fit_sweep produces them on the way
     pipe.V = V; pipe.ldv = ldv; pipe.m_pad = cols;
     pipe.zvec = g->z; pipe.q = q; pipe.mu = mu;
     pipe.chunk_blocks = c->pipe_chunk_blocks;
@@ -1244,8 +1232,8 @@ static int enqueue_posterior(cbo_gp *g, cbo_cands *k, bool want_f64_solution = f
         }
         {
             PhaseScope ps(c, PH_TRSM);
-            launch_trsm_strips(c->stream, g->A, g->lda, g->invDt, g->Winv, g->wflag, Vws, ldv, g->n_pad, cols, g->z,
-                               c->q + c0, c->mu + c0);
+            launch_trsm_strips(c->stream, g->A, g->lda, g->invDt, Vws, ldv, g->n_pad, cols, g->z, c->q + c0,
+                               c->mu + c0);
         }
         if (c->profiling) {
             c->timers.n_trsm_launches += 1;
@@ -1444,8 +1432,6 @@ extern "C" int cbo_gp_append(cbo_gp *g, const double *x_new, double y_new, doubl
     HIP_TRY(hipMemcpyAsync(g->raw + g->n * g->d, x_new, sizeof(double) * g->d, hipMemcpyHostToDevice, c->stream));
     launch_append_commit(c->stream, g->A, g->lda, g->n, g->n_pad, g->lvec, 1, d, zn, g->z, g->lvec, g->X, g->probe->P,
                          prior_mean_new, prior_var_new, g->y, y_new, g->invDt);
-    // the block that gained the row has a new inverse (and possibly a new flag)
-    launch_block_inverses(c->stream, g->A, g->lda, (int)(g->n / 128), 1, g->invDt, g->Winv, g->wflag, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (causal) g->h_pv.push_back(prior_var_new);
@@ -1549,7 +1535,6 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
     }
     const bool speculate = qbuf == k->q;
     SweepPipe pipe = make_pipe(g, Vws, ldv, k->m_pad, qbuf, mubuf);
-    pipe.inverses_ready = false;                           // this call factors: the block inverses follow pair by pair
     // updates in groups of pairs where the bulk stream bounds the pipeline (CBO_HIP_PIPE_GROUP: 1 = never, G >= 2 = groups
     // of G pairs whatever the shape; default: automatic)
     // (groups beyond 4 pairs -- K = 1024 -- are not covered by the tests: clamped)
@@ -1588,8 +1573,6 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
             // timing-only: factor first, then the same right-looking sweep launches with nothing beside them
             if (std::getenv("CBO_DBG_PIPE_SERIAL")) {
                 launch_cholesky(c->stream, c->side_stream, c->chol_events, g->A, g->lda, g->n_pad, g->invDt, g->info);
-                launch_block_inverses(c->stream, g->A, g->lda, 0, (int)(g->n_pad / 128), g->invDt, g->Winv, g->wflag, g->info);
-                pipe.inverses_ready = true;
                 hipMemcpy2DAsync(g->z, sizeof(double), g->A + g->n_pad, sizeof(double) * g->lda, sizeof(double),
                                  (size_t)g->n_pad, hipMemcpyDeviceToDevice, c->stream);
                 int pr = 0;
@@ -2022,7 +2005,7 @@ extern "C" int cbo_gp_lml_gradients(cbo_gp *g, double *lml_out, double *dvarianc
         rc = enqueue_right_looking(g, c->V, ldv, n_pad, c->q, c->mu, true);
         if (rc != CBO_OK) return rc;
     } else {
-        launch_trsm_strips(c->stream, g->A, g->lda, g->invDt, g->Winv, g->wflag, c->V, ldv, n_pad, n_pad, g->z, c->q, c->mu);
+        launch_trsm_strips(c->stream, g->A, g->lda, g->invDt, c->V, ldv, n_pad, n_pad, g->z, c->q, c->mu);
     }
     // -Ky^-1 = -(L^-1)^T L^-1: rows [k0, k0+256) of L^-1 only reach columns < k0+256, so pair p touches the
     // leading (k0+256)^2 block; upper part only
@@ -2119,12 +2102,9 @@ extern "C" int cbo_gp_predict_gradients(cbo_gp *g, int64_t m, const double *Xs, 
     for (int64_t c0 = 0; c0 < k->m_pad; c0 += chunk) {
         const int64_t cols = (k->m_pad - c0 < chunk) ? (k->m_pad - c0) : chunk;
         launch_kstar(c->stream, g->X, k->P, c0, cols, g->h, c->V, ldv, g->n_pad);
-        launch_trsm_strips(c->stream, g->A, g->lda, g->invDt, g->Winv, g->wflag, c->V, ldv, g->n_pad, cols, nullptr, nullptr,
-                           nullptr);
+        launch_trsm_strips(c->stream, g->A, g->lda, g->invDt, c->V, ldv, g->n_pad, cols, nullptr, nullptr, nullptr);
         launch_reverse_rows(c->stream, c->V, ldv, g->n_pad, cols, c->W, ldv);
-        // (the reversed factor has no block inverses of its own: substitution form)
-        launch_trsm_strips(c->stream, g->T, g->lda, g->invT, nullptr, nullptr, c->W, ldv, g->n_pad, cols, nullptr, nullptr,
-                           nullptr);
+        launch_trsm_strips(c->stream, g->T, g->lda, g->invT, c->W, ldv, g->n_pad, cols, nullptr, nullptr, nullptr);
         launch_pred_gradients(c->stream, g->X, g->n_pad, k->P, c0, cols, m, g->h, g->inv_ls_dev, g->alpha, c->W, ldv,
                               dmean, dvar);
     }

@@ -117,9 +117,6 @@ int f32_debug_mask();      // the F32_DBG mask this library was built with (0 in
 struct SweepPipe {
     hipStream_t stream;                  // in-panel solves + the update of the next panel pair's rows
     hipStream_t bulk;                    // the updates of everything below that
-    double *Winv;                        // explicit inverses of the diagonal blocks and their flags, produced pair by
-    int *wflag;                          // pair on `stream` ahead of the pair's in-panel solve (nullptr: not used)
-    bool inverses_ready;                 // a finished fit has left them behind: nothing to produce
     double *V;
     int64_t ldv, m_pad;
     double *zvec;                        // contiguous copy of z, written panel by panel by the diagonal kernel
@@ -147,8 +144,6 @@ void sweep_pipe_pair(const SweepPipe &pipe, hipStream_t chain, const double *A, 
                      int64_t n_pad, int p, int r0, int klen);
 void sweep_pipe_tail(const SweepPipe &pipe, hipStream_t chain, const double *A, int64_t lda, const double *invDt,
                      int64_t n_pad, int pairs_done);
-void sweep_pipe_inverses(const SweepPipe &pipe, hipStream_t chain, const double *A, int64_t lda, const double *invDt,
-                         int r0, int klen);
 // alpha = U^-1 z  (z = first rhs column of A).
 void launch_backsolve(hipStream_t s, const double *A, int64_t lda, int64_t n_pad, const double *invDt, double *alpha);
 // out = L^-1 w for one contiguous n_pad vector (w is destroyed): the forward counterpart, one launch per block
@@ -180,17 +175,9 @@ void launch_expand_interventions(hipStream_t s, const double *observed, int64_t 
                                  const int *iv_index, int64_t m, double *raw);
 
 // V <- L^-1 V on m_pad columns (64-column strips); optional q[c] = sum_i V[i][c]^2, mu[c] = sum_i V[i][c] z[i].
-// Winv / wflag: explicit inverses of the 128 x 128 diagonal blocks (W^T of block b at Winv + b * 128 * 128) and, per
-// block, whether the in-block solve multiplies by it (1) or substitutes over the 16 x 16 inverses of invDt (0); both
-// nullptr: substitution everywhere.  All three advance together with U when a caller passes a sub-problem.
-void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const double *invDt, const double *Winv,
-                        const int *wflag, double *V, int64_t ldv, int64_t n, int64_t m_pad, const double *z, double *q,
-                        double *mu, bool accumulate = false, bool half_lds = false);
-// W^T = inv(U[blk, blk]) and the flag of `count` consecutive 128-row blocks starting at block `first` (kernels_chol.hip);
-// kappa_max: blocks with max|W| * max|U_blk| above it keep the substitution form (flag 0)
-void launch_block_inverses(hipStream_t s, const double *A, int64_t lda, int first, int count, const double *invDt,
-                           double *Winv, int *wflag, const int *skip_if);
-double block_inverse_kappa_max();
+void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const double *invDt, double *V, int64_t ldv,
+                        int64_t n, int64_t m_pad, const double *z, double *q, double *mu, bool accumulate = false,
+                        bool half_lds = false);
 // C[i0_begin:i0_end, :] -= U[k0:k0+klen, i0_begin:i0_end]^T V[k0:k0+klen, :]  (C and V share the workspace V)
 void launch_trsm_update(hipStream_t s, const double *U, int64_t ldu, double *V, int64_t ldv, int k0, int klen,
                         int i0_begin, int i0_end, int64_t m_pad, int chunk_blocks, bool half_lds = true);

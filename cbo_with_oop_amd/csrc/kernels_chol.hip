@@ -945,110 +945,6 @@ void launch_panel_trsm(hipStream_t s, double *A, int64_t lda, int r0, int col0, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Explicit inverses of the 128 x 128 diagonal blocks of the factor, W_b = L[b,b]^-1, for the inverse form of the strip
-// kernels' in-block solve (kernels_trsm.hip: x = W r is 144 independent MFMAs per column group where the substitution is
-// 8 dependent steps).  One workgroup per block: the block goes to LDS, column tile ct of the identity goes through the
-// tile solve of the row panel (panel_solve_tiles: the substitution over the 16 x 16 inverses, so every column of W is
-// as accurate as a substitution makes it), and the solved tiles are written transposed -- W^T = inv(U[b,b]), row-major
-// 128 x 128 with explicit zeros below the diagonal: rows of W^T are what the strip kernels' DMA ring fetches.
-// The flag: multiplying by an explicit inverse is only as accurate as the inverse is small -- the error of W r is
-// eps |W| |r| where a substitution's is eps |L^-1| |L| |x|, and on the reference's dense 1-D / 2-D sets at 1e-10 noise
-// (pivots at the 1e-8 floor, |W| ~ 1e4) that loses up to 50x in the posterior variance
-// (scripts/probes/block_inverse_accuracy.py).  So a block takes the inverse form only if kappa = max|W_b| max|U_b| is at
-// most kappa_max (CBO_HIP_BLOCK_INV_KAPPA, default 2000: every block of the d = 3 configurations, kappa <= ~800 there);
-// other blocks keep the substitution and with it the bits and the accuracy of rounds 1-3.
-__global__ __launch_bounds__(256) void block_inverse_kernel(const double *__restrict__ A, int64_t lda, int first,
-                                                            const double *__restrict__ invDt, double *__restrict__ Winv,
-                                                            int *__restrict__ wflag, double kappa_max,
-                                                            const int *__restrict__ skip_if)
-{
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    PanelShared &sh = *reinterpret_cast<PanelShared *>(smem_raw);
-    __shared__ double red[2][4];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lc = lane & 15, kq = lane >> 4;
-    const int blk = first + (int)blockIdx.x;
-    const int r0 = 128 * blk;
-    if (skip_if && __builtin_nontemporal_load(skip_if) != 0) {       // an abandoned factorisation: nothing to invert
-        if (tid == 0) wflag[blk] = 0;
-        return;
-    }
-    {
-        const unsigned s0 = lds_byte_address(&sh.U[0][0]);
-        const double *g = A + (int64_t)(r0 + wave * 32) * lda + r0 + lane * 2;
-#pragma unroll 8
-        for (int p = 0; p < 32; ++p) {
-            if (lane >= 8 * ((wave * 32 + p) >> 4))          // upper triangle only (by 16-column tiles)
-                glds16(g + (int64_t)p * lda, __builtin_amdgcn_readfirstlane(s0 + 8u * (unsigned)((wave * 32 + p) * kDiagLd)));
-        }
-    }
-    double iv[8][4];
-    const double *inv = invDt + (int64_t)(r0 / 16) * 256 + kq * 16 + lc;
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) iv[s][kk] = inv[s * 256 + 64 * kk];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // max |U| over the block's upper triangle (a NaN sticks)
-    double maxu = 0.0, maxw = 0.0;
-    auto take = [](double &m, double v) { v = fabs(v); m = (v > m || v != v) ? v : m; };
-    for (int idx = tid; idx < 128 * 128; idx += 256) {
-        const int i = idx >> 7, j = idx & 127;
-        if (j >= i) take(maxu, sh.U[i][j]);
-    }
-    double *Wb = Winv + (int64_t)blk * (128 * 128);
-    for (int ct = wave; ct < 8; ct += 4) {
-        d4 acc[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[t][r] = (t == ct && kq + 4 * r == lc) ? 1.0 : 0.0;
-        double *Wc = Wb + (int64_t)(16 * ct + lc) * 128 + kq;          // W^T[16 ct + lc][row]: column lc of the solved tile
-        panel_solve_tiles(&sh.U[kq][lc], acc, iv, 8, [&](int s2, const d4 &x) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                Wc[16 * s2 + 4 * r] = x[r];
-                take(maxw, x[r]);
-            }
-        });
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ou = __shfl_xor(maxu, off), ow = __shfl_xor(maxw, off);
-        maxu = (ou > maxu || ou != ou) ? ou : maxu;
-        maxw = (ow > maxw || ow != ow) ? ow : maxw;
-    }
-    if (lane == 0) { red[0][wave] = maxu; red[1][wave] = maxw; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 4; ++w) {
-            maxu = (red[0][w] > maxu || red[0][w] != red[0][w]) ? red[0][w] : maxu;
-            maxw = (red[1][w] > maxw || red[1][w] != red[1][w]) ? red[1][w] : maxw;
-        }
-        wflag[blk] = (maxu * maxw <= kappa_max) ? 1 : 0;               // (false for a NaN)
-    }
-}
-
-double block_inverse_kappa_max()
-{
-    static const double k = [] { const char *e = std::getenv("CBO_HIP_BLOCK_INV_KAPPA"); return e ? std::atof(e) : 2000.0; }();
-    return k;
-}
-
-void launch_block_inverses(hipStream_t s, const double *A, int64_t lda, int first, int count, const double *invDt,
-                           double *Winv, int *wflag, const int *skip_if)
-{
-    if (count <= 0 || Winv == nullptr) return;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(block_inverse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)sizeof(PanelShared));
-    hipLaunchKernelGGL(block_inverse_kernel, dim3((unsigned)count), dim3(256), sizeof(PanelShared), s, A, lda, first, invDt,
-                       Winv, wflag, block_inverse_kappa_max(), skip_if);
-}
-
-// ------------------------------------------------------------------------------------------------
 // Small models, many sets, ONE launch (the reference's own operating point: N = 10..50 observations per exploration
 // set, S = 2..25 sets, /root/reference/src/ArgumentParser.py:18,25, src/CBO.py:237-260).  At that size every kernel of
 // the general path is launch latency: K(X,X), eight chain launches, K*, the strip solve, the epilogue, a stream
@@ -1292,31 +1188,19 @@ __global__ __launch_bounds__(256) void small_sets_kernel(const SmallSetArgs byva
     __syncthreads();
 
     SSTAMP(5);
-    // ---- V = L^-1 K*, q = sum V^2, mu = V^T z: the strip kernels' order -- lane partials over tiles 0-3 and over tiles
-    // 4-7 apart, each reduced over the four lane groups, total = lower + upper
-    double qacc = 0.0, macc = 0.0, qaccl = 0.0, maccl = 0.0;
+    // ---- V = L^-1 K*, q = sum V^2, mu = V^T z (lane partials, then over the four lane groups: the strip kernel's order)
+    double qacc = 0.0, macc = 0.0;
     panel_solve_tiles(&sh.blk.S[kq][lc], acc, iv, tiles, [&](int s, const d4 &x) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (s < 4) {
-                qacc = fma(x[r], x[r], qacc);
-                macc = fma(x[r], zr[s][r], macc);
-            } else {
-                qaccl = fma(x[r], x[r], qaccl);
-                maccl = fma(x[r], zr[s][r], maccl);
-            }
+            qacc = fma(x[r], x[r], qacc);
+            macc = fma(x[r], zr[s][r], macc);
         }
     });
     qacc += __shfl_xor(qacc, 16);
     qacc += __shfl_xor(qacc, 32);
     macc += __shfl_xor(macc, 16);
     macc += __shfl_xor(macc, 32);
-    qaccl += __shfl_xor(qaccl, 16);
-    qaccl += __shfl_xor(qaccl, 32);
-    maccl += __shfl_xor(maccl, 16);
-    maccl += __shfl_xor(maccl, 32);
-    qacc = (0.0 + qaccl) + qacc;
-    macc = (0.0 + maccl) + macc;
 
     SSTAMP(6);
     // ---- epilogue and the workgroup's arg-max
@@ -1787,13 +1671,8 @@ void sweep_pipe_pair(const SweepPipe &pipe, hipStream_t chain, const double *A, 
     const double m = (double)cols;
     hipEventRecord(pipe_event(0, p), chain);
     hipStreamWaitEvent(pipe.stream, pipe_event(0, p), 0);
-    // the pair's block inverses first (unless a finished fit left them behind): the in-panel solve reads their flags
-    if (pipe.Winv && !pipe.inverses_ready)
-        launch_block_inverses(pipe.stream, A, lda, r0 / 128, klen / 128, invDt, pipe.Winv, pipe.wflag, nullptr);
     if (pipe.mark) pipe.mark(pipe.user, pipe.stream, 1, (double)klen * (double)klen * m);
     launch_trsm_strips(pipe.stream, A + (int64_t)r0 * lda + r0, lda, invDt + (int64_t)(r0 / 16) * 256,
-                       pipe.Winv ? pipe.Winv + (int64_t)(r0 / 128) * (128 * 128) : nullptr,
-                       pipe.Winv ? pipe.wflag + r0 / 128 : nullptr,
                        pipe.V + (int64_t)r0 * pipe.ldv, pipe.ldv, klen, cols, pipe.zvec + r0, pipe.q, pipe.mu, true,
                        pipe.half_lds);
     if (pipe.mark) pipe.mark(pipe.user, pipe.stream, 0, 0.0);
@@ -1847,45 +1726,25 @@ void sweep_pipe_pair(const SweepPipe &pipe, hipStream_t chain, const double *A, 
 // The rows the pairs did not take, [tail_begin, n_pad): every earlier pair has been folded into them (first of the
 // last pair on `stream`, rest of the last pair on `bulk`) and the factor is complete on `chain`: one left-looking
 // launch of the strip kernel on the sub-problem, on the chain stream itself (every CU, full-LDS variant).
-// A pair of panels the pipeline does NOT take (it belongs to the closing left-looking launch): only its block inverses
-// are produced, on the sweep stream, as soon as the chain has the pair's rows -- off the chain, ahead of the closing launch.
-void sweep_pipe_inverses(const SweepPipe &pipe, hipStream_t chain, const double *A, int64_t lda, const double *invDt,
-                         int r0, int klen)
-{
-    if (!pipe.Winv || pipe.inverses_ready) return;
-    std::vector<hipEvent_t> &ev = *pipe.events;
-    const size_t slot = (size_t)(3 * (r0 / 256));                                // the pair's (otherwise unused) chain event
-    while (ev.size() <= slot) {
-        hipEvent_t e;
-        hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence);
-        ev.push_back(e);
-    }
-    hipEventRecord(ev[slot], chain);
-    hipStreamWaitEvent(pipe.stream, ev[slot], 0);
-    launch_block_inverses(pipe.stream, A, lda, r0 / 128, klen / 128, invDt, pipe.Winv, pipe.wflag, nullptr);
-}
-
 void sweep_pipe_tail(const SweepPipe &pipe, hipStream_t chain, const double *A, int64_t lda, const double *invDt,
                      int64_t n_pad, int pairs_done)
 {
     std::vector<hipEvent_t> &ev = *pipe.events;
-    const size_t slot = (size_t)(3 * pairs_done + 1);             // (the "sd done" slot of a pair that has no sd)
+    const size_t slot = (size_t)(3 * pairs_done);
     while (ev.size() <= slot) {
         hipEvent_t e;
         hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence);
         ev.push_back(e);
     }
-    if (pairs_done > 0 || (pipe.Winv && !pipe.inverses_ready)) {
-        hipEventRecord(ev[slot], pipe.stream);                    // sd and first of the last pair, the tail's block inverses
+    if (pairs_done > 0) {
+        hipEventRecord(ev[slot], pipe.stream);                                   // sd and first of the last pair
         hipStreamWaitEvent(chain, ev[slot], 0);
-        if (pairs_done > 0) hipStreamWaitEvent(chain, ev[(size_t)(3 * (pairs_done - 1) + 2)], 0);      // rest of the last pair
+        hipStreamWaitEvent(chain, ev[(size_t)(3 * (pairs_done - 1) + 2)], 0);      // rest of the last pair
     }
     const int t0 = pipe.tail_begin;
     const double rows = (double)((int)n_pad - t0);
     if (pipe.mark) pipe.mark(pipe.user, chain, 1, rows * rows * (double)pipe.m_pad);
     launch_trsm_strips(chain, A + (int64_t)t0 * lda + t0, lda, invDt + (int64_t)(t0 / 16) * 256,
-                       pipe.Winv ? pipe.Winv + (int64_t)(t0 / 128) * (128 * 128) : nullptr,
-                       pipe.Winv ? pipe.wflag + t0 / 128 : nullptr,
                        pipe.V + (int64_t)t0 * pipe.ldv, pipe.ldv, (int64_t)n_pad - t0, pipe.m_pad, pipe.zvec + t0, pipe.q,
                        pipe.mu, true, false);
     if (pipe.mark) pipe.mark(pipe.user, chain, 0, 0.0);
@@ -1962,7 +1821,6 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     int pair = 0;
     auto sweep_rows = [&](int r0, int klen) {
         if (pipe && r0 < pipe->tail_begin) sweep_pipe_pair(*pipe, s, A, lda, invDt, n_pad, pair++, r0, klen);
-        else if (pipe) sweep_pipe_inverses(*pipe, s, A, lda, invDt, r0, klen);
     };
     // Schedule per pair p (panels A_p, B_p):
     //   chain:  diag A_p, panel A_p, rows B_p -= A_p (K = 128), diag B_p, panel B_p,
@@ -2004,7 +1862,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         if (fused) {}
         else if (lean_panel) launch_panel_trsm(s, A, lda, r0, r0 + 128, n2, invDt, info_dev);   // (beside a pipelined sweep: the half-LDS strip kernel)
         else
-        launch_trsm_strips(s, A + (int64_t)r0 * lda + r0, lda, invDt + (int64_t)(r0 / 16) * 256, nullptr, nullptr,
+        launch_trsm_strips(s, A + (int64_t)r0 * lda + r0, lda, invDt + (int64_t)(r0 / 16) * 256,
                            A + (int64_t)r0 * lda + r0 + 128, lda, 128, n2, nullptr, nullptr, nullptr, false, half_lds);
         // rows of the pair's second panel: K = 128 update with the first panel
         if (syrk_rows_form == 2) launch_syrk_rows(s, A, lda, r0, 128, n2, rcol, info_dev);
@@ -2024,7 +1882,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         if (fused) {}
         else if (lean_panel) launch_panel_trsm(s, A, lda, r1, r1 + 128, n3, invDt, info_dev, ev_panel);
         else
-        launch_trsm_strips(s, A + (int64_t)r1 * lda + r1, lda, invDt + (int64_t)(r1 / 16) * 256, nullptr, nullptr,
+        launch_trsm_strips(s, A + (int64_t)r1 * lda + r1, lda, invDt + (int64_t)(r1 / 16) * 256,
                            A + (int64_t)r1 * lda + r1 + 128, lda, 128, n3, nullptr, nullptr, nullptr, false, half_lds);
         sweep_rows(r0, 256);
         if (first_of_group) {

@@ -109,22 +109,17 @@ struct StageCursor {
     int i0, j, lim;                       // block origin, stage index within the block, stages in the block
     int ai0, aj;                          // the same, clamped to the last stage once the cursor is past the end
     const double *a_src;                  // per-lane source of the U tile's first row handled by this wave
-    int64_t a_stride;                     // doubles between consecutive rows of that tile (ldu; 128 for rows of W^T)
     const double *b_src;                  // per-lane source of the wave's first B piece
     int64_t b_stride;                     // doubles between consecutive B pieces
-    int dup;                              // the B pieces fetch the wave's first A rows once more (inverse-form diagonal stages)
 };
 
 template <bool SWEEP, int KB>
-__global__ __launch_bounds__(256, 2) void trsm_strip_kernel(const double *__restrict__ U, int64_t ldu,
-                                                         const double *__restrict__ invDt,
-                                                         const double *__restrict__ Winv, const int *__restrict__ wflag,
-                                                         double *V, int64_t ldv,
+__global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restrict__ U, int64_t ldu,
+                                                         const double *__restrict__ invDt, double *V, int64_t ldv,
                                                          int n, const double *__restrict__ z,
                                                          double *__restrict__ q_out, double *__restrict__ mu_out,
                                                          int accumulate)
 {
-    static_assert(KB == 16, "the inverse form of the diagonal stages below is written for one 16-row tile per stage");
     using G = StageGeom<KB>;
     constexpr int kKB = KB, kABuf = G::kA, kBBuf = G::kB, kDmaPerStage = G::kDma, kStoresPerDiagStage = G::kDiagStores;
     constexpr int kDS = G::kDiagStages, kDT = G::kDiagTiles, kKS = G::kKS, kParts = G::kParts;
@@ -140,23 +135,6 @@ __global__ __launch_bounds__(256, 2) void trsm_strip_kernel(const double *__rest
     const unsigned lds_byte0 = lds_byte_address(lds);      // LDS byte address of lds[0]
     const double *ug = U + (int64_t)(wave * G::kRA) * ldu + lane * 2;
     const double *vg = V + (int64_t)(lane >> 3) * ldv + colw + 2 * (lane & 7);
-    // inverse form of the in-block solve (see trsm_strip8_kernel: the same flags, the same operations per element):
-    // W^T of block b at Winv + b * 128 * 128; diagonal stage m of such a block carries tile row s = kWOrder[m] of W
-    const double *wg = (Winv ? Winv : U) + (int64_t)(wave * G::kRA) * kRB + lane * 2;
-    unsigned long long wmask0 = 0, wmask1 = 0;
-    if (Winv != nullptr) {
-        const int nblk = n / kRB;
-        const int f0 = (lane < nblk) ? wflag[lane] : 0;
-        const int f1 = (64 + lane < nblk) ? wflag[64 + lane] : 0;
-        wmask0 = __ballot(f0 != 0);
-        wmask1 = __ballot(f1 != 0);
-    }
-    auto use_w = [&](int blk) __attribute__((always_inline)) -> int {
-        const unsigned long long msk = (blk & 64) ? wmask1 : wmask0;
-        return (blk < 128) ? (int)((msk >> (blk & 63)) & 1ull) : 0;
-    };
-    // tile row of W in diagonal stage m: the two-wave kernel pairs rows q and 7 - q in its 32-row stage q
-    auto w_row = [](int m) __attribute__((always_inline)) -> int { return (m & 1) ? 7 - (m >> 1) : (m >> 1); };
 
     // Sources of the stage the cursor points at (scalar bookkeeping, done off the MFMA path).  A cursor past
     // the end is clamped to the last stage, whose buffer is free by then, so in-flight counts stay uniform.
@@ -170,14 +148,7 @@ __global__ __launch_bounds__(256, 2) void trsm_strip_kernel(const double *__rest
         c.aj = past ? (n - kRB) / kKB + kDS - 1 : c.j;
     };
     auto locate_b = [&](StageCursor &c) __attribute__((always_inline)) {
-        const int m = c.aj - c.ai0 / kKB;                      // diagonal stage index (negative: a regular stage)
-        const int blk = c.ai0 / kRB;
-        const int64_t wd = (m >= 0) ? use_w(blk) : 0;
-        const double *usrc = ug + (int64_t)(kKB * c.aj) * ldu + c.ai0;
-        const double *wsrc = wg + (int64_t)blk * (kRB * kRB) + (int64_t)(16 * w_row(m & 7)) * kRB;
-        c.a_src = reinterpret_cast<const double *>((uintptr_t)usrc + ((uintptr_t)wsrc - (uintptr_t)usrc) * (uintptr_t)wd);
-        c.a_stride = ldu + ((int64_t)kRB - ldu) * wd;
-        c.dup = (int)wd;
+        c.a_src = ug + (int64_t)(kKB * c.aj) * ldu + c.ai0;
     };
     auto locate_c = [&](StageCursor &c) __attribute__((always_inline)) {
         const int nreg = c.ai0 / kKB;
@@ -206,24 +177,28 @@ __global__ __launch_bounds__(256, 2) void trsm_strip_kernel(const double *__rest
         locate(c);
     };
     // the LDS-DMA instructions of a stage, split so they can sit between MFMAs: kParts groups of 3
-    // one instruction of a group (q = 0, 1: the group's U rows; q = 2: its B piece -- in a diagonal stage of the inverse
-    // form, which needs no B piece, the wave's row `part` once more: same bytes to the same place, same instruction count)
-    auto issue_one = [&](const StageCursor &c, int buf, int part, int q) __attribute__((always_inline)) {
+    auto issue_part = [&](const StageCursor &c, int buf, int part) __attribute__((always_inline)) {
         const unsigned la = __builtin_amdgcn_readfirstlane(lds_byte0 + 8u * (unsigned)(buf * kABuf + (wave * G::kRA) * kLdsLd));
-        if (q < 2) {
+        const unsigned lb = __builtin_amdgcn_readfirstlane(
+            lds_byte0 + 8u * (unsigned)(kNBuf * kABuf + buf * kBBuf + wave * (kKB * 16)));
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
             const int p = 2 * part + q;
-            glds16(c.a_src + (int64_t)p * c.a_stride, la + 8u * (unsigned)(p * kLdsLd));     // one 1 KiB U row
+            glds16(c.a_src + (int64_t)p * ldu, la + 8u * (unsigned)(p * kLdsLd));   // one 1 KiB U row
+        }
+        glds16(c.b_src + part * c.b_stride, lb + 8u * (unsigned)(part * 128));      // one 1 KiB B piece
+    };
+    // the same instructions one at a time (q = 0, 1: the group's U rows; q = 2: its B piece)
+    auto issue_one = [&](const StageCursor &c, int buf, int part, int q) __attribute__((always_inline)) {
+        if (q < 2) {
+            const unsigned la = __builtin_amdgcn_readfirstlane(lds_byte0 + 8u * (unsigned)(buf * kABuf + (wave * G::kRA) * kLdsLd));
+            const int p = 2 * part + q;
+            glds16(c.a_src + (int64_t)p * ldu, la + 8u * (unsigned)(p * kLdsLd));
         } else {
             const unsigned lb = __builtin_amdgcn_readfirstlane(
                 lds_byte0 + 8u * (unsigned)(kNBuf * kABuf + buf * kBBuf + wave * (kKB * 16)));
-            const double *src = c.dup ? c.a_src + (int64_t)part * c.a_stride : c.b_src + part * c.b_stride;
-            const unsigned dst = c.dup ? la + 8u * (unsigned)(part * kLdsLd) : lb + 8u * (unsigned)(part * 128);
-            glds16(src, dst);                                                               // one 1 KiB B piece
+            glds16(c.b_src + part * c.b_stride, lb + 8u * (unsigned)(part * 128));
         }
-    };
-    auto issue_part = [&](const StageCursor &c, int buf, int part) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) issue_one(c, buf, part, q);
     };
     auto issue_stage = [&](const StageCursor &c, int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -231,16 +206,13 @@ __global__ __launch_bounds__(256, 2) void trsm_strip_kernel(const double *__rest
     };
 
     // acc holds the NEGATED residual  L[blk, 0:k] V[0:k] - V[blk]  so the K-loop needs no operand negation
-    // (the next block's right-hand sides are fetched at the block boundary, not a block ahead: with two workgroups per CU
-    //  a lane has 256 registers, and acc plus the diagonal phase's operands leave no room for 64 more in flight; the other
-    //  workgroup of the CU covers the round trip)
-    d4 acc[kT];
+    d4 acc[kT], accn[kT];
 #pragma unroll
     for (int t = 0; t < kT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] = -Vc[(int64_t)(16 * t + kq + 4 * r) * ldv];
 
-    StageCursor ahead{0, 0, kDS, 0, 0, nullptr, 0, nullptr, 0, 0};
+    StageCursor ahead{0, 0, kDS, 0, 0, nullptr, nullptr, 0};
     locate(ahead);
     issue_stage(ahead, 0);
     advance(ahead);
@@ -251,13 +223,11 @@ __global__ __launch_bounds__(256, 2) void trsm_strip_kernel(const double *__rest
     int stamp_i = 0;
 #endif
     int buf = 0;                 // buffer of the current stage; stage g+2 goes to (buf + 2) % 3
-    int extra_prev = 0;          // VMEM operations the previous stage issued after its DMA: 1 = a diagonal stage's V
-                                 // stores (substitution form), 2 = a whole block's (inverse form)
-    // q = sum V^2 and mu = V^T z: lane partials over a PAIR of row blocks (256 rows), the upper tiles 0-3 and the lower
-    // tiles 4-7 of every block apart (the two-wave kernel's waves), each reduced over the four lane groups at the end of
-    // the pair: total = (total + lower) + upper -- the grouping the right-looking pipeline produces naturally (one launch
-    // of this kernel per pair, accumulate = 1), so all schedules give the same bits
-    double qacc = 0.0, macc = 0.0, qaccl = 0.0, maccl = 0.0, qtot = 0.0, mtot = 0.0;
+    int extra_prev = 0;          // VMEM operations the previous stage issued after its DMA (its V stores)
+    // q = sum V^2 and mu = V^T z: lane partials over a PAIR of row blocks (256 rows), reduced over the four
+    // lane groups and added to a running total pair by pair -- the grouping the right-looking pipeline produces
+    // naturally (one launch of this kernel per pair, accumulate = 1), so both schedules give the same bits
+    double qacc = 0.0, macc = 0.0, qtot = 0.0, mtot = 0.0;
     if (SWEEP && accumulate) {            // continue the running totals of the launches before this one
         qtot = q_out[colw + lc];
         mtot = mu_out[colw + lc];
@@ -268,12 +238,10 @@ __global__ __launch_bounds__(256, 2) void trsm_strip_kernel(const double *__rest
     // barrier publishes every wave's share and frees buffer (buf+2)%3, read during the previous stage
 #define STAGE_TOP()                                                                                       \
     do {                                                                                                  \
-        if (extra_prev == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerStage + kStoresPerDiagStage) : "memory"); \
-        else if (extra_prev == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerStage + 4 * kT) : "memory"); \
+        if (extra_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerStage + kStoresPerDiagStage) : "memory"); \
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerStage) : "memory");                          \
         __builtin_amdgcn_s_barrier();                                                                     \
     } while (0)
-    static_assert(kDmaPerStage + 4 * kT <= 63, "s_waitcnt vmcnt is a 6-bit count");
 
     for (int i0 = 0; i0 < n; i0 += kRB) {
         const int nst = i0 / kKB;
@@ -349,82 +317,20 @@ __global__ __launch_bounds__(256, 2) void trsm_strip_kernel(const double *__rest
             for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
         }
 
-        if (use_w(i0 / kRB)) {
-            // ---- diagonal stages, inverse form: x_t = sum_{s <= t} W[t][s] r_s, one tile row s of W per stage in the
-            // order 0, 7, 1, 6, 2, 5, 3, 4 (the two-wave kernel's stage q holds rows q and 7 - q).  The B operands are
-            // the (negated) residual tiles as they stand in acc[]; xacc collects sum W r~ over r~ = -r, so x = -xacc.
-            d4 xacc[kT];
-            const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int m = 0; m < kDS; ++m) {
-                const int srow = w_row(m);
-                STAMP(0);
-                STAGE_TOP();
-                STAMP(1);
-                const int bnext = (buf >= 1) ? buf - 1 : 2;
-                issue_stage(ahead, bnext);
-                advance(ahead);
-                extra_prev = 0;
-                // (two workgroups share the CU: 256 registers per lane at most, and acc, xacc and the next block's
-                //  right-hand sides are 64 each -- so the fragments are not double-buffered here and the right-hand sides
-                //  are requested behind the block's stores, below)
-                const double *ab = lds + buf * kABuf + kq * kLdsLd + lc;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    double wf[kT];
-#pragma unroll
-                    for (int t = srow; t < kT; ++t) wf[t] = ab[4 * kk * kLdsLd + 16 * t];
-#pragma unroll
-                    for (int t = srow; t < kT; ++t)
-                        xacc[t] = MFMA_F64(wf[t], acc[srow][kk], (m == 0 && kk == 0) ? zero4 : xacc[t]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                STAMP(2);
-                STAMP_NEXT();
-                buf = (buf == 2) ? 0 : buf + 1;
-            }
-            // the solved block: to global memory, into q and mu (z rows straight from global memory, as the substitution
-            // form reads them)
-#pragma unroll
-            for (int t = 0; t < kT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double x = -xacc[t][r];
-                    const int row = i0 + 16 * t + kq + 4 * r;
-                    Vc[(int64_t)row * ldv] = x;
-                    if (SWEEP) {
-                        const double zv = z[row];
-                        if (t < kT / 2) {
-                            qacc = fma(x, x, qacc);
-                            macc = fma(x, zv, macc);
-                        } else {
-                            qaccl = fma(x, x, qaccl);
-                            maccl = fma(x, zv, maccl);
-                        }
-                    }
-                }
-            asm volatile("" ::: "memory");
-            extra_prev = 2;
-            if (i0 == 0 && kRB < n) {
-                // block 1's regular stages read these rows through the DMA ring, which asked for the first two of them
-                // before they were stored: drain and start the ring again at block 1 (see trsm_strip8_kernel)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                ahead = StageCursor{kRB, 0, kRB / kKB + kDS, 0, 0, nullptr, 0, nullptr, 0, 0};
-                locate(ahead);
-                issue_stage(ahead, buf);
-                advance(ahead);
-                issue_stage(ahead, (buf == 2) ? 0 : buf + 1);
-                advance(ahead);
-                extra_prev = 0;
-            }
-        } else {
         // ---- diagonal stages (KB rows each): X_s = inv(L_ss) R_s, then R_t -= L_ts X_s for the tiles below
 #pragma unroll
         for (int m = 0; m < kDS; ++m) {
             STAMP(0);
             STAGE_TOP();
             STAMP(1);
+            if (m == 0 && i0 + kRB < n) {
+                // next block's right-hand sides (K* rows) -- issued before this stage's DMA so that the
+                // DMA waits further down never have to cover them early
+#pragma unroll
+                for (int t = 0; t < kT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accn[t][r] = -Vc[(int64_t)(i0 + kRB + 16 * t + kq + 4 * r) * ldv];
+            }
             // z rows of this stage, fetched ahead of the DMA issue so they are older than it in vmcnt order
             double zr[kDT][4];
             if (SWEEP) {
@@ -461,13 +367,8 @@ __global__ __launch_bounds__(256, 2) void trsm_strip_kernel(const double *__rest
                     const int row = i0 + 16 * s + kq + 4 * r;
                     Vc[(int64_t)row * ldv] = x[r];
                     if (SWEEP) {
-                        if (s < kT / 2) {
-                            qacc = fma(x[r], x[r], qacc);
-                            macc = fma(x[r], zr[h][r], macc);
-                        } else {
-                            qaccl = fma(x[r], x[r], qaccl);
-                            maccl = fma(x[r], zr[h][r], maccl);
-                        }
+                        qacc = fma(x[r], x[r], qacc);
+                        macc = fma(x[r], zr[h][r], macc);
                     }
                 }
             };
@@ -528,28 +429,17 @@ __global__ __launch_bounds__(256, 2) void trsm_strip_kernel(const double *__rest
             STAMP_NEXT();
             buf = (buf == 2) ? 0 : buf + 1;
         }
-        }
-        if (i0 + kRB < n) {
 #pragma unroll
-            for (int t = 0; t < kT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[t][r] = -Vc[(int64_t)(i0 + kRB + 16 * t + kq + 4 * r) * ldv];
-        }
+        for (int t = 0; t < kT; ++t) acc[t] = accn[t];
         if (SWEEP && (((i0 / kRB) & 1) || i0 + kRB >= n)) {
             qacc += __shfl_xor(qacc, 16);
             qacc += __shfl_xor(qacc, 32);
             macc += __shfl_xor(macc, 16);
             macc += __shfl_xor(macc, 32);
-            qaccl += __shfl_xor(qaccl, 16);
-            qaccl += __shfl_xor(qaccl, 32);
-            maccl += __shfl_xor(maccl, 16);
-            maccl += __shfl_xor(maccl, 32);
-            qtot = (qtot + qaccl) + qacc;
-            mtot = (mtot + maccl) + macc;
+            qtot += qacc;
+            mtot += macc;
             qacc = 0.0;
             macc = 0.0;
-            qaccl = 0.0;
-            maccl = 0.0;
         }
     }
 #undef STAGE_TOP
@@ -573,38 +463,19 @@ __global__ __launch_bounds__(256, 2) void trsm_strip_kernel(const double *__rest
 // Same strip (64 columns), same 128-row blocks, same LDS stages (KB = 32), DMA ring and per-element operation order
 // as trsm_strip_kernel -- V, q and mu come out bit for bit the same.  The split is by ROWS: waves (cw, 0) and (cw, 1)
 // share the 16 columns of column group cw (and therefore every B fragment); wave (cw, h) owns row tiles 4h .. 4h+3 of
-// each block, i.e. half of every A tile.  Regular stages need nothing else.
-//
-// The in-block solve V[blk] = L[blk,blk]^-1 R has two forms, chosen PER BLOCK by a flag the fit leaves behind (wflag,
-// block_inverse_kernel in kernels_chol.hip; every schedule consults the same flags, so every schedule computes the same
-// bits):
-//   * flag set (round 4; the well-conditioned blocks, i.e. all of them on the d = 3 configurations): ONE multiplication
-//     with the explicit inverse W = L[blk,blk]^-1 of the 128 x 128 block, x_t = sum_{s <= t} W[t][s] r_s over 16 x 16
-//     tiles -- 144 MFMAs per column group like the substitution, but no MFMA depends on another: the diagonal phase is
-//     four more stages of the regular kind (A operand = rows of W^T through the same DMA ring, B operand = the residual
-//     tiles, which ARE B fragments as they stand in the accumulators), balanced at 36 MFMAs per SIMD: stage q carries the
-//     tile rows s = q and s = 7 - q of W.  The upper half's residual tiles reach the lower half's waves through the
-//     stages' B regions (which receive no DMA in these stages: the cursor points the two B pieces at rows the wave
-//     fetches anyway), written where the ring's barriers already order them -- no extra barrier, no dependent chain.
-//     The solved tiles leave for global memory (and enter q, mu) right behind the block's last stage.
-//   * flag clear (a block whose inverse is large, kappa = max|W| max|L| above the threshold: the ill-conditioned 1-D / 2-D
-//     sets of the reference at its 1e-10 noise, where multiplying by an explicit inverse loses up to 50x against the
-//     substitution, scripts/probes/block_inverse_accuracy.py): the substitution over 16 x 16 diagonal inverses of rounds
-//     1-3, tile by tile.  The solved tiles of the upper half must reach the lower half's wave: the solver wave (h = 0 in
-//     diagonal stages 0 and 1) writes x_s, x_{s+1} over the two 16x16 inverses it has just consumed in the stage's B
-//     region, a mid-stage barrier publishes them, and wave (cw, 1) folds them into its four tiles (32 MFMAs) while the
-//     solver finishes its own updates.
-// q = sum V^2 and mu = V^T z: every wave keeps lane partials over ITS tiles of a PAIR of row blocks (upper half: tiles
-// 0-3, lower half: tiles 4-7, each in row order); at the end of the pair both are reduced over the four lane groups and
-// the running total becomes (total + lower) + upper -- the lower waves hold the totals, the upper half's sum crosses
-// through two padding doubles of an LDS stage buffer, ordered by the stage barriers.
+// each block, i.e. half of every A tile.  Regular stages need nothing else.  In the diagonal stages the solved tiles
+// of the upper half must reach the lower half's wave: the solver wave (h = 0 in diagonal stages 0 and 1) writes x_s,
+// x_{s+1} over the two 16x16 inverses it has just consumed in the stage's B region (same size, layout = the B
+// operand's), a mid-stage barrier publishes them, and wave (cw, 1) folds them into its four tiles (32 MFMAs) while the
+// solver finishes its own updates.  q = sum V^2 and mu = V^T z keep the sequential per-lane order of the one-wave
+// kernel: the running lane partials are handed from (cw, 0) to (cw, 1) in the middle of each block and back at its
+// end through the padding columns of an LDS stage buffer (the stage barriers order the hand-over).
 constexpr int kTH = kT / 2;               // row tiles per wave
 
 template <bool SWEEP>
 __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restrict__ U, int64_t ldu,
-                                                          const double *__restrict__ invDt,
-                                                          const double *__restrict__ Winv, const int *__restrict__ wflag,
-                                                          double *V, int64_t ldv, int n, const double *__restrict__ z,
+                                                          const double *__restrict__ invDt, double *V, int64_t ldv,
+                                                          int n, const double *__restrict__ z,
                                                           double *__restrict__ q_out, double *__restrict__ mu_out,
                                                           int accumulate)
 {
@@ -613,8 +484,7 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
     constexpr int kABuf = G::kA, kBBuf = G::kB, kKS = G::kKS, kDS = G::kDiagStages, kDT = G::kDiagTiles;
     constexpr int kRows8 = KB / 8;                    // U rows a wave fetches per stage
     constexpr int kDma8 = kRows8 + 2;                 // LDS-DMA instructions a wave issues per stage (+ two B pieces)
-    constexpr int kSolverStores = 4 * kDT;            // V stores the solver wave issues in a diagonal stage (substitution form)
-    constexpr int kEmitStores = 4 * kTH;              // V stores a wave issues for a block solved by the inverse form
+    constexpr int kSolverStores = 4 * kDT;            // V stores the solver wave issues in a diagonal stage
     static_assert(kDT == 2 && kDS == 4 && kKS == 8 && kDma8 <= kKS - 2, "geometry the schedule below is written for");
     __shared__ __align__(16) double lds[kNBuf * (kABuf + kBBuf)];      // 159,744 B
     __shared__ __align__(16) double zl[SWEEP ? 2 * kRB : 2];           // z rows of the current and the next block
@@ -645,41 +515,16 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
     // B pieces (8 rows x 16 columns, 1 KiB): this wave fetches pieces 2h and 2h+1 of its column group
     const double *vg = V + (int64_t)((lane >> 3) + 16 * h) * ldv + colw + 2 * (lane & 7);
     const double *inv_lane = invDt + lane * 2 + 256 * h;               // diagonal stages: inverse h of the stage's two
-    // inverse form: W^T of block b at Winv + b * 128 * 128, row-major; in stage q a wave of half 0 fetches rows
-    // 16 q + 4 cw + i, a wave of half 1 rows 16 (7 - q) + 4 cw + i (see locate_b)
-    const double *wg = (Winv ? Winv : U) + (int64_t)(kRows8 * cw) * kRB + lane * 2;
-    // which blocks take the inverse form: the fit's flags of blocks 0..127 as two wave-uniform bit masks (blocks beyond
-    // that -- more than 16384 rows in one launch -- take the substitution)
-    unsigned long long wmask0 = 0, wmask1 = 0;
-    if (Winv != nullptr) {
-        const int nblk = n / kRB;
-        const int f0 = (lane < nblk) ? wflag[lane] : 0;
-        const int f1 = (64 + lane < nblk) ? wflag[64 + lane] : 0;
-        wmask0 = __ballot(f0 != 0);
-        wmask1 = __ballot(f1 != 0);
-    }
-    auto use_w = [&](int blk) __attribute__((always_inline)) -> int {
-        const unsigned long long msk = (blk & 64) ? wmask1 : wmask0;
-        return (blk < 128) ? (int)((msk >> (blk & 63)) & 1ull) : 0;
-    };
 
-    StageCursor ahead{0, 0, kDS, 0, 0, nullptr, 0, nullptr, 0, 0};
+    StageCursor ahead{0, 0, kDS, 0, 0, nullptr, nullptr, 0};
     auto locate_a = [&](StageCursor &c) __attribute__((always_inline)) {
         const bool past = c.i0 >= n;
         c.ai0 = past ? n - kRB : c.i0;
         c.aj = past ? (n - kRB) / KB + kDS - 1 : c.j;
     };
     auto locate_b = [&](StageCursor &c) __attribute__((always_inline)) {
-        // a diagonal stage of a block that takes the inverse form fetches rows of W^T (row stride 128) instead of U's
-        const int q = c.aj - c.ai0 / KB;                       // diagonal stage index (negative: a regular stage)
-        const int blk = c.ai0 / kRB;
-        const int64_t wd = (q >= 0) ? use_w(blk) : 0;
-        const double *usrc = ug + (int64_t)(KB * c.aj) * ldu + c.ai0;
-        const double *wsrc = wg + (int64_t)blk * (kRB * kRB) + (int64_t)(h ? 16 * (7 - q) : 16 * q) * kRB;
-        c.a_src = reinterpret_cast<const double *>((uintptr_t)usrc + ((uintptr_t)wsrc - (uintptr_t)usrc) * (uintptr_t)wd);
-        c.a_stride = ldu + ((int64_t)kRB - ldu) * wd;
-        c.dup = (int)wd;
-        if (dmask & 16) { c.a_src = ug; c.a_stride = ldu; }    // timing only: every U tile from the same (cached) rows
+        c.a_src = ug + (int64_t)(KB * c.aj) * ldu + c.ai0;
+        if (dmask & 16) c.a_src = ug;                          // timing only: every U tile from the same (cached) rows
     };
     auto locate_c = [&](StageCursor &c) __attribute__((always_inline)) {
         const int nreg = c.ai0 / KB;
@@ -703,22 +548,17 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
         locate_b(c);
         locate_c(c);
     };
-    // DMA instruction i of the wave's kDma8 for the stage the cursor points at: i < kRows8: U (or W^T) row
-    // wave*kRows8 + i; then the two B pieces -- in a diagonal stage of the inverse form, whose B region carries the
-    // residual tiles, they fetch the wave's first two rows once more instead (same bytes to the same place: the count
-    // of DMA instructions per stage, which the stage-top waits rest on, stays the same)
+    // DMA instruction i of the wave's kDma8 for the stage the cursor points at: i < kRows8: U row wave*kRows8 + i;
+    // then the two B pieces
     auto issue_one = [&](const StageCursor &c, int buf, int i) __attribute__((always_inline)) {
-        const unsigned la = __builtin_amdgcn_readfirstlane(
-            lds_byte0 + 8u * (unsigned)(buf * kABuf + (wave * kRows8) * kLdsLd));
         if (i < kRows8) {
-            glds16(c.a_src + (int64_t)i * c.a_stride, la + 8u * (unsigned)(i * kLdsLd));
+            const unsigned la = __builtin_amdgcn_readfirstlane(
+                lds_byte0 + 8u * (unsigned)(buf * kABuf + (wave * kRows8) * kLdsLd));
+            glds16(c.a_src + (int64_t)i * ldu, la + 8u * (unsigned)(i * kLdsLd));
         } else {
             const unsigned lb = __builtin_amdgcn_readfirstlane(
                 lds_byte0 + 8u * (unsigned)(kNBuf * kABuf + buf * kBBuf + cw * (KB * 16) + (2 * h) * 128));
-            const int jp = i - kRows8;
-            const double *src = c.dup ? c.a_src + (int64_t)jp * c.a_stride : c.b_src + jp * c.b_stride;
-            const unsigned dst = c.dup ? la + 8u * (unsigned)(jp * kLdsLd) : lb + 8u * (unsigned)(jp * 128);
-            glds16(src, dst);
+            glds16(c.b_src + (i - kRows8) * c.b_stride, lb + 8u * (unsigned)((i - kRows8) * 128));
         }
     };
     auto issue_stage = [&](const StageCursor &c, int buf) __attribute__((always_inline)) {
@@ -800,23 +640,17 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
 #define STAMP8(slot)
 #define FINE(pt)
 #endif
-    // lane partials of this wave's tiles over the current pair of row blocks; the running totals live in the h = 1 waves
-    double qacc = 0.0, macc = 0.0, qtot = 0.0, mtot = 0.0;
+    double qacc = 0.0, macc = 0.0, qtot = 0.0, mtot = 0.0;       // totals live in the h = 1 waves
     if (SWEEP && accumulate && h == 1) {
         qtot = q_out[colw + lc];
         mtot = mu_out[colw + lc];
     }
-    // inverse form: the (negated) solved tiles of the block; the upper half's pair sum has been left in the hand-over
-    // slots and is not yet in the totals
-    d4 xacc[kTH];
-    int pend_hand = 0;
 
     // Stage-top wait.  This wave's DMA of stage k (issued during stage k-2) has landed once only what is younger than its
     // LAST instruction may still be in flight (vmcnt retires in order): what stage k-2 issued after its DMA (a2), and all
     // of stage k-1 -- what it issued before or among its DMA instructions (b1), the DMA (kDma8), what it issued after
-    // (a1).  "After" are the solver's V stores of a diagonal stage of the substitution form and the V stores of a block
-    // solved by the inverse form (issued behind its last stage); "before" are the hand-issued loads for the next block,
-    // spread over the first regular stage of a block.
+    // (a1).  "After" are the solver's V stores of a diagonal stage; "before" are the
+    // hand-issued loads for the next block, spread over the first regular stage of a block.
     int a1 = 0, b1 = 0, a2 = 0;
     auto wait_top = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -828,8 +662,6 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
         else WAIT_IF(kAhead);
         else WAIT_IF(kAhead + kSolverStores);
         else WAIT_IF(kAhead + 2 * kSolverStores);
-        else WAIT_IF(kEmitStores);
-        else WAIT_IF(kAhead + kEmitStores);
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma8) : "memory");       // (any other count: the strict wait)
 #undef WAIT_IF
         __builtin_amdgcn_s_barrier();
@@ -838,50 +670,8 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
         a1 = 0;
         b1 = 0;
     };
-    static_assert(kDma8 + kAhead + 2 * kSolverStores <= 63 && kDma8 + kAhead + kEmitStores <= 63, "s_waitcnt vmcnt is a 6-bit count");
+    static_assert(kDma8 + kAhead + 2 * kSolverStores <= 63, "s_waitcnt vmcnt is a 6-bit count");
 #define STAGE8_TOP() wait_top()
-
-    auto pair_ends_at = [&](int b0) __attribute__((always_inline)) -> bool { return ((b0 / kRB) & 1) || b0 + kRB >= n; };
-    // this wave's partial over the pair is complete: reduce over the four lane groups; the upper half leaves its sum for the
-    // lower half (read behind a later stage barrier), the lower half adds its own to the totals
-    auto close_pair = [&]() __attribute__((always_inline)) {
-        qacc += __shfl_xor(qacc, 16);
-        qacc += __shfl_xor(qacc, 32);
-        macc += __shfl_xor(macc, 16);
-        macc += __shfl_xor(macc, 32);
-        if (h == 0) {
-            hand[0] = qacc;
-            hand[1] = macc;
-        } else {
-            qtot += qacc;
-            mtot += macc;
-        }
-        qacc = 0.0;
-        macc = 0.0;
-    };
-    // the tiles the inverse form of the block at b0 left in xacc: to global memory, into q and mu (straight behind the
-    // block's last stage: holding them until the next block's first stage costs 36 registers and spills)
-    auto emit_block = [&](int b0) __attribute__((always_inline)) {
-        const double *zrow = zl + ((b0 / kRB) & 1) * kRB + 16 * (kTH * h) + kq;
-#pragma unroll
-        for (int t = 0; t < kTH; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double x = -xacc[t][r];
-                const int row = b0 + 16 * (kTH * h + t) + kq + 4 * r;
-                if (!(dmask & 4)) Vc[(int64_t)row * ldv] = x;
-                if (SWEEP) {
-                    qacc = fma(x, x, qacc);
-                    macc = fma(x, zrow[16 * t + 4 * r], macc);
-                }
-            }
-        asm volatile("" ::: "memory");
-        if (!(dmask & 4)) a1 += kEmitStores;              // issued after the last stage's DMA, before the next stage's top
-        if (SWEEP && pair_ends_at(b0)) {
-            close_pair();
-            pend_hand = 1;
-        }
-    };
 
     for (int i0 = 0; i0 < n; i0 += kRB) {
         const int nst = i0 / KB;
@@ -894,13 +684,6 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
             STAMP8(0);
             STAGE8_TOP();
             STAMP8(1);
-            if (!FIRST && SWEEP && pend_hand) {
-                if (h == 1) {                                     // the upper half's pair sum, written a barrier ago
-                    qtot += hand[0];
-                    mtot += hand[1];
-                }
-                pend_hand = 0;
-            }
             const int bnext = (buf >= 1) ? buf - 1 : 2;       // (buf + 2) % 3
             const double *abase = lds + buf * kABuf + kq * kLdsLd + lc + 64 * h;
             const double *bbase = ldsB + buf * kBBuf + cw * (KB * 16) + kq * 16 + lc;
@@ -954,125 +737,7 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
             for (int t = 0; t < kTH; ++t) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
         }
 
-        if (use_w(i0 / kRB)) {
-            // ---- diagonal stages, inverse form: x_t = sum_{s <= t} W[t][s] r_s.  Stage q holds rows 16 q .. 16 q + 15 (k-steps
-            // 0-3: tile row s = q, for the tiles t >= q) and 16 (7 - q) .. (k-steps 4-7: s = 7 - q, tiles t >= 7 - q) of
-            // W^T: 36 MFMAs per SIMD in every stage.  B operands: the (negated) residual tiles themselves -- acc[] of the
-            // owning wave, or, for the lower half's products with the upper half's tiles 0..3, rows 0-15 of the stage's B
-            // region, where the upper half's wave has put tile q: tiles 0 and 1 before stage 0's barrier (those two
-            // regions were last read two and three stages ago), tile 2 during stage 0 (the buffer of the last regular
-            // stage, free once every wave has passed that barrier), tile 3 during stage 1 (stage 0's own buffer again).
-            // xacc collects sum W r~ over the NEGATED residuals r~ = -r, so x = -xacc.
-            auto publish = [&](int tile, int pbuf) __attribute__((always_inline)) {
-                double *dst = ldsB + pbuf * kBBuf + cw * (KB * 16) + kq * 16 + lc;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dst[64 * r] = acc[tile][r];
-            };
-            if (h == 0) {
-                publish(0, buf);
-                publish(1, (buf == 2) ? 0 : buf + 1);
-            }
-#pragma unroll
-            for (int q = 0; q < kDS; ++q) {
-                STAMP8(0);
-                STAGE8_TOP();
-                STAMP8(1);
-                const int bnext = (buf >= 1) ? buf - 1 : 2;
-                if (h == 0 && q == 0) publish(2, bnext);
-                if (h == 0 && q == 1) publish(3, bnext);
-                // the stage's other work, one piece per MFMA slot where there are slots: the DMA of stage g+2, the cursor
-                int piece = 0;
-                auto do_piece = [&](int k) __attribute__((always_inline)) {
-                    if (k < kDma8) issue_one(ahead, bnext, k);
-                    else if (k == kDma8) step(ahead);
-                    else if (k == kDma8 + 1) locate_a(ahead);
-                    else if (k == kDma8 + 2) locate_b(ahead);
-                    else if (k == kDma8 + 3) locate_c(ahead);
-                };
-                constexpr int kPieces = kDma8 + 4;
-                const double *ab = lds + buf * kABuf + kq * kLdsLd + lc + 64 * h;
-                const double *bb = ldsB + buf * kBBuf + cw * (KB * 16) + kq * 16 + lc;
-                const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
-                double wf[2][kTH], bq[2];
-                if (dmask & 1) {
-                    // timing only: no arithmetic
-                } else if (h == 0) {
-                    // upper half: tiles q..3 against tile row s = q (its own residual tile q)
-#pragma unroll
-                    for (int tl = q; tl < kTH; ++tl) wf[0][tl] = ab[16 * tl];
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-#pragma unroll
-                        for (int tl = q; tl < kTH; ++tl) {
-                            xacc[tl] = MFMA_F64(wf[jj & 1][tl], acc[q][jj], (q == 0 && jj == 0) ? zero4 : xacc[tl]);
-                            if (tl == q && jj < 3) {
-#pragma unroll
-                                for (int t2 = q; t2 < kTH; ++t2) wf[(jj + 1) & 1][t2] = ab[4 * (jj + 1) * kLdsLd + 16 * t2];
-                            } else if (piece < kPieces) {
-                                do_piece(piece);
-                                ++piece;
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                } else {
-                    // lower half: all four tiles against tile row s = q (the upper half's tile q, from the B region), then
-                    // tiles 3-q..3 against tile row s = 7 - q (its own residual tile 3 - q)
-#pragma unroll
-                    for (int tl = 0; tl < kTH; ++tl) wf[0][tl] = ab[16 * tl];
-                    bq[0] = bb[0];
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        const int lo = (jj < 4) ? 0 : kTH - 1 - q;
-                        const int lo_next = (jj + 1 < 4) ? 0 : kTH - 1 - q;
-#pragma unroll
-                        for (int tl = lo; tl < kTH; ++tl) {
-                            const double bop = (jj < 4) ? bq[jj & 1] : acc[kTH - 1 - q][jj - 4];
-                            xacc[tl] = MFMA_F64(wf[jj & 1][tl], bop, (q == 0 && jj == 0) ? zero4 : xacc[tl]);
-                            if (tl == lo && jj < 7) {
-#pragma unroll
-                                for (int t2 = lo_next; t2 < kTH; ++t2) wf[(jj + 1) & 1][t2] = ab[4 * (jj + 1) * kLdsLd + 16 * t2];
-                                if (jj + 1 < 4) bq[(jj + 1) & 1] = bb[4 * (jj + 1) * 16];
-                            } else if (piece < kPieces) {
-                                do_piece(piece);
-                                ++piece;
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < kPieces; ++k)
-                    if (k >= piece) do_piece(k);
-                STAMP8(3);
-                STAMP8(2);
-                STAMP_NEXT();
-                buf = (buf == 2) ? 0 : buf + 1;
-            }
-            emit_block(i0);
-            if (i0 == 0 && kRB < n) {
-                // Block 0 solved by the inverse form: block 1's regular stages read ITS rows of V through the DMA ring, and
-                // the ring requested the first two of them during block 0's last diagonal stages -- before the rows were
-                // stored.  (From block 1 on a block's rows are first read four or more stages after its stores.)  So here,
-                // once per launch: drain, and start the ring again at block 1's first stage.
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                ahead = StageCursor{kRB, 0, kRB / KB + kDS, 0, 0, nullptr, 0, nullptr, 0, 0};
-                locate_a(ahead);
-                locate_b(ahead);
-                locate_c(ahead);
-                issue_stage(ahead, buf);
-                advance(ahead);
-                issue_stage(ahead, (buf == 2) ? 0 : buf + 1);
-                advance(ahead);
-                a1 = 0;
-                b1 = 0;
-                a2 = 0;
-            }
-        } else {
-        // ---- diagonal stages, substitution form (two 16-row tiles each): tiles 2m, 2m+1 belong to the waves of half m >> 1
+        // ---- diagonal stages (two 16-row tiles each): tiles 2m, 2m+1 belong to the waves of half m >> 1
 #pragma unroll
         for (int m = 0; m < kDS; ++m) {
             STAMP8(0);
@@ -1082,6 +747,10 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
             if (h == hs) FINE(0);
             const int ls = kDT * (m & 1);                     // its first tile of the stage, as an index into acc[]
             const bool solver = (h == hs);
+            if (SWEEP && solver && (m == 2 || (m == 0 && ((i0 / kRB) & 1)))) {     // take over the running lane partials
+                qacc = hand[0];
+                macc = hand[1];
+            }
             const int bnext = (buf >= 1) ? buf - 1 : 2;
             // the stage's DMA issue and cursor arithmetic: placed where the wave would otherwise wait (behind the first
             // MFMAs of the solve, ahead of the lower half's rendezvous), always ahead of the stage's V stores
@@ -1206,13 +875,24 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
                 }
                 FINE(8);
                 if (!(dmask & 4)) a1 += kSolverStores;
-                // done with this half's tiles of the block; at the end of a pair the partial is closed -- the lower half
-                // solves two stages (two barriers) after the upper half has left its sum in the hand-over slots
-                if (SWEEP && (m & 1) && pair_ends_at(i0)) {
-                    close_pair();
-                    if (hs == 1) {
-                        qtot += hand[0];
-                        mtot += hand[1];
+                if (SWEEP && (m & 1)) {                                   // done with this half's tiles: hand over
+                    if (hs == 0) {
+                        hand[0] = qacc;
+                        hand[1] = macc;
+                        qacc = 0.0;                                       // (an even block starts from zero)
+                        macc = 0.0;
+                    } else if (((i0 / kRB) & 1) || i0 + kRB >= n) {       // end of a block pair: reduce, add
+                        qacc += __shfl_xor(qacc, 16);
+                        qacc += __shfl_xor(qacc, 32);
+                        macc += __shfl_xor(macc, 16);
+                        macc += __shfl_xor(macc, 32);
+                        qtot += qacc;
+                        mtot += macc;
+                        qacc = 0.0;
+                        macc = 0.0;
+                    } else {
+                        hand[0] = qacc;
+                        hand[1] = macc;
                     }
                 }
             } else if (hs == 0) {
@@ -1245,7 +925,6 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
             STAMP_NEXT();
             buf = (buf == 2) ? 0 : buf + 1;
         }
-        }
         // the hand-issued loads were retired by diagonal stage 3's top (they are older than that stage's DMA)
 #pragma unroll
         for (int t = 0; t < kTH; ++t)
@@ -1263,18 +942,11 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
 #undef STAMP8
 #undef FINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the clamped tail DMA before the LDS goes away
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    if (SWEEP && h == 1) {
-        if (pend_hand) {
-            qtot += hand[0];
-            mtot += hand[1];
-        }
-        if (kq == 0) {
-            q_out[colw + lc] = qtot;
-            mu_out[colw + lc] = mtot;
-        }
+    if (SWEEP && h == 1 && kq == 0) {
+        q_out[colw + lc] = qtot;
+        mu_out[colw + lc] = mtot;
     }
 #ifdef CBO_DIAG_KNOBS
     if (tid == 0 && blockIdx.x < 4096) {
@@ -1483,41 +1155,45 @@ __global__ __launch_bounds__(256) void trsm_update_kernel(const double *__restri
 #undef UPD_STAMP
 }
 
-void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const double *invDt, const double *Winv,
-                        const int *wflag, double *V, int64_t ldv, int64_t n, int64_t m_pad, const double *z, double *q,
-                        double *mu, bool accumulate, bool half_lds)
+void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const double *invDt, double *V, int64_t ldv,
+                        int64_t n, int64_t m_pad, const double *z, double *q, double *mu, bool accumulate,
+                        bool half_lds)
 {
     if (n <= 0 || m_pad <= 0) return;
-    // n is a multiple of 128 at every call site (n_pad of the sweep, the 128-row Cholesky panel).  Winv / wflag: the
-    // explicit inverses of the 128 x 128 diagonal blocks and which blocks use them (nullptr: the substitution form for
-    // every block).  half_lds: the one-wave-per-SIMD kernel with 16-row stages, two workgroups per CU, for launches that
-    // share the device with other streams' kernels; default: two waves per SIMD, a CU's whole LDS (trsm_strip8_kernel).
-    // Same bits either way.
+    // n is a multiple of 128 at every call site (n_pad of the sweep, the 128-row Cholesky panel)
     const dim3 grid((unsigned)(m_pad / kStrip));
-    if (wflag == nullptr) Winv = nullptr;
-    if (!half_lds) {
-        int acc = accumulate ? 1 : 0;
+    const int acc = accumulate ? 1 : 0;
+    // CBO_HIP_STRIP_FORM=4: the one-wave-per-SIMD kernel also where a workgroup has the CU to itself (A/B timing;
+    // same bits).  Default: two waves per SIMD (trsm_strip8_kernel).
+    static const int strip_form = [] {
+        const char *e = getenv("CBO_HIP_STRIP_FORM");
+        return e ? atoi(e) : 8;
+    }();
+    if (!half_lds && strip_form != 4) {
 #ifdef CBO_DIAG_KNOBS
         static const int strip_mask = [] {
             const char *e = getenv("CBO_HIP_STRIP_MASK");
             return e ? atoi(e) : 0;
         }();
-        acc |= strip_mask << 8;
+        const int acc = (accumulate ? 1 : 0) | (strip_mask << 8);
 #endif
         if (q != nullptr)
-            hipLaunchKernelGGL((trsm_strip8_kernel<true>), grid, dim3(512), 0, s, U, ldu, invDt, Winv, wflag, V, ldv, (int)n,
-                               z, q, mu, acc);
+            hipLaunchKernelGGL((trsm_strip8_kernel<true>), grid, dim3(512), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, acc);
         else
-            hipLaunchKernelGGL((trsm_strip8_kernel<false>), grid, dim3(512), 0, s, U, ldu, invDt, Winv, wflag, V, ldv, (int)n,
-                               z, q, mu, 0);
+            hipLaunchKernelGGL((trsm_strip8_kernel<false>), grid, dim3(512), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, 0);
         return;
     }
-    if (q != nullptr)
-        hipLaunchKernelGGL((trsm_strip_kernel<true, 16>), grid, dim3(256), 0, s, U, ldu, invDt, Winv, wflag, V, ldv, (int)n, z,
-                           q, mu, accumulate ? 1 : 0);
-    else
-        hipLaunchKernelGGL((trsm_strip_kernel<false, 16>), grid, dim3(256), 0, s, U, ldu, invDt, Winv, wflag, V, ldv, (int)n, z,
-                           q, mu, 0);
+    if (q != nullptr) {
+        if (half_lds)
+            hipLaunchKernelGGL((trsm_strip_kernel<true, 16>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, acc);
+        else
+            hipLaunchKernelGGL((trsm_strip_kernel<true, 32>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, acc);
+    } else {
+        if (half_lds)
+            hipLaunchKernelGGL((trsm_strip_kernel<false, 16>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, 0);
+        else
+            hipLaunchKernelGGL((trsm_strip_kernel<false, 32>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, 0);
+    }
 }
 
 void launch_trsm_update(hipStream_t s, const double *U, int64_t ldu, double *V, int64_t ldv, int k0, int klen,

@@ -1785,7 +1785,13 @@ def test_path_failure_on_one_rank_reaches_every_rank(hip, monkeypatch):
     with pytest.raises(RuntimeError, match="another rank failed"):
         path.compute_best_acquisition_values(0.0)
     assert comm.flags == [0.0] and comm.calls == []
-    comm = FlagComm(2, 0)                       # nobody failed: the flag exchange, then one arg-max exchange per set
+    class HealthyComm(FlagComm):                # (the other rank's sets come back with a valid winner)
+        def argmax(self, val, idx):
+            from cbo_with_oop_amd.sharding import NO_CANDIDATE
+            self.calls.append((val, idx))
+            return (val, idx) if idx != NO_CANDIDATE else (0.0, 0)
+
+    comm = HealthyComm(2, 0)                    # nobody failed: the flag exchange, then one arg-max exchange per set
     path = make(comm)
     path.compute_best_acquisition_values(0.0)
     assert comm.flags == [0.0] and len(comm.calls) == len(es)
