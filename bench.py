@@ -159,8 +159,9 @@ def pmc_traffic(section):
 def bench_small_sets(args):
     """--config c1 = BASELINE.json configs[0]: toy_graph, 50 observations and a 200-candidate sweep per exploration set
     (2 sets).  Step = what CBO.intervene() does per trial at that size (/root/reference/src/CBO.py:152-164): the model of
-    the set intervened on is rebuilt, then ONE cbo_acq_sweep_sets call factors and sweeps every set in one launch, then
-    the set is picked.  Every rank runs the same pass (replicas: two 200-candidate sets are not worth sharding)."""
+    the set intervened on is rebuilt, every set is factored and swept in one launch, the set is picked -- ONE library call
+    (cbo_trial_step through CBOAcquisitionPath.trial_step).  Every rank runs the same pass (replicas: two 200-candidate
+    sets are not worth sharding)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -181,9 +182,9 @@ def bench_small_sets(args):
     path.last_intervention = 1
 
     def step():
-        path.update_gaussian_process_of_last_intervention()
-        _, vals = path.compute_best_acquisition_values(best)
-        return path.select_next_intervention(vals), vals
+        path.last_intervention = 1                  # (the set whose model is rebuilt: the same every step)
+        _, vals, choice = path.trial_step(best)     # one cbo_trial_step call: rebuild + sweep of every set + pick
+        return choice, vals
 
     def fence():
         if comm is not None:
@@ -210,8 +211,8 @@ def bench_small_sets(args):
                "warmup": max(5, args.warmup), "ms_per_step": per * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "toy_graph, 50 obs, 200-candidate sweep of each of the 2 exploration sets "
-                                      "(BASELINE.json configs[0]); step = rebuild the intervened set's model + one "
-                                      "cbo_acq_sweep_sets call (every set factored and swept in ONE launch) + pick",
+                                      "(BASELINE.json configs[0]); step = ONE cbo_trial_step call: rebuild the intervened "
+                                      "set's model + every set factored and swept in one launch + pick",
                           "config": "c1", "n_obs": n, "candidates_total": n_sets * m, "sets": n_sets,
                           "rccl_ranks": comm.size()[0] if comm is not None else 0,
                           "parallelism": f"replicas x{world} (every rank runs the whole pass)"},
@@ -554,6 +555,42 @@ def main():
                                        "avg_launch_ms": t16["ms_kxx"], "algorithmic_bytes_per_launch": b16,
                                        "cholesky_ms": t16["ms_chol"],
                                        "cholesky_tflops": float(n16) ** 3 / 3.0 / (t16["ms_chol"] * 1e-3) / 1e12}
+        if world == 1 and args.post_steps > 0 and args.config == "c2":
+            # the north-star's other HBM-bound piece: the EI / cost / arg-max pass alone (3 * 8 B per
+            # candidate -- q and mu in, the acquisition value out -- against 8 TB/s), on stored q, mu of 2^20 and 2^24
+            # candidates (a re-sweep of an unchanged model skips the substitution: the epilogue is all that runs)
+            out["roofline_ei"] = []
+            Xe = np.random.default_rng(3).uniform(-5.0, 5.0, (64, 3))
+            ye = np.sin(Xe).sum(1, keepdims=True)
+            me = HipGaussianProcess(Xe, ye, context=ctx)
+            for log2m in (20, 24):
+                m_ei = 1 << log2m
+                Ce = np.random.default_rng(4).uniform(-5.0, 5.0, (m_ei, 3))
+                ge = CandidateGrid(Ce, me, context=ctx)
+                acq_host = np.empty(m_ei)
+                bve, bie = ctypes.c_double(), ctypes.c_int64()
+
+                def ei_pass():
+                    _lib.check(lib.cbo_acq_sweep(me._handle, ge._handle, float(ye.min()), 0, 0.0, 3.0, _lib.dptr(acq_host),
+                                                 None, None, ctypes.byref(bve), ctypes.byref(bie)))
+                ei_pass()                          # the substitution, once; q and mu stay with the candidates
+                ei_pass()
+                ctx.set_profiling(True)
+                ctx.reset_timers()
+                reps_ei = 10
+                for _ in range(reps_ei):
+                    ei_pass()
+                te = ctx.timers()
+                ctx.set_profiling(False)
+                ms_ei = te["ms_acq"] / reps_ei
+                out["roofline_ei"].append({
+                    "kernel": "acq_kernel + argmax_final_kernel (variance, mean, EI / cost, arg-max from stored q, mu)",
+                    "candidates": m_ei, "bound": "hbm", "achieved": 24.0 * m_ei / (ms_ei * 1e-3) / 1e9, "peak": 8000.0,
+                    "unit": "GB/s", "frac": 24.0 * m_ei / (ms_ei * 1e-3) / 1e9 / 8000.0, "avg_pass_ms": ms_ei,
+                    "algorithmic_bytes_per_pass": 24 * m_ei, "substitutions_in_the_timed_passes": int(te["n_trsm_launches"])})
+                ge.close()
+                del Ce, acq_host
+            me.close()
         if world == 1 and args.post_steps > 0 and args.config == "c2":
             # what a CBO trial costs once data only grow by one observation (not part of `value`: the timed steps
             # refit from scratch): append one point to a 4000-point model, then sweep the same 16384-candidate grid

@@ -198,6 +198,46 @@ class CBOAcquisitionPath:
             xs.append(x_new)
         return xs, out
 
+    def trial_step(self, current_best):
+        """One trial of the reference's loop between two observations (src/CBO.py:143-173, ``CBO.intervene``) as ONE
+        device-library call: ``update_gaussian_process_of_last_intervention`` (the model of the set intervened on last takes
+        ``data_x / data_y`` of that set), ``compute_best_acquisition_values`` and ``select_next_intervention``.  Returns
+        ``(xs, ys, (exploration set, index))`` -- what those three return -- and leaves ``last_intervention`` at the pick.
+        At the reference's model sizes the three calls' host glue costs as much as the one launch that serves them
+        (``cbo_trial_step``); anything the one call does not cover (several ranks, a model rebuilt with other prior closures
+        or other hyper-parameters, the first trial) takes the three calls."""
+        import ctypes
+        from . import _lib
+        from .utils_functions.utils import winners_to_points
+        s = self.last_intervention
+        st = self._call_cache.get("sweep_sets")
+        model = self.models[s] if (s is not None and self.models) else None
+        fast = (st is not None and model is not None and self.placement()[0] == "single"
+                and model.mean_function is self.mean_functions[s] and model.variance_adjustment is self.var_functions[s]
+                and model.hyper_is_initial() and st["cost_table"] is self.costs and len(st["models"]) == self.es_size
+                and all(a is b for a, b in zip(st["models"], self.models))
+                and all(self._grids.get(i) is not None and self._grids[i][1] is st["grids"][i] for i in range(self.es_size)))
+        if not fast:
+            if s is not None:
+                self.update_gaussian_process_of_last_intervention()
+            xs, ys = self.compute_best_acquisition_values(current_best)
+            return xs, ys, self.select_next_intervention(ys)
+        model._set_arrays(self.data_x[s], self.data_y[s])
+        pm, pv = model._prior(model.X)
+        st["y_best"][:] = float(np.asarray(current_best, dtype=np.float64).reshape(-1)[0])
+        chosen = ctypes.c_int(-1)
+        _lib.check(_lib.load().cbo_trial_step(self.es_size, st["gps"], st["cds"], s, model.X.shape[0], _lib.dptr(model.X),
+                                              _lib.dptr(model._y_flat), _lib.dptr(pm), _lib.dptr(pv), _lib.dptr(st["y_best"]),
+                                              _lib.TASK_CODE[self.task], 0.0, _lib.dptr(st["batch_cost"]), _lib.dptr(st["vals"]),
+                                              st["idxs"].ctypes.data_as(_lib.c_int64_p), ctypes.byref(chosen)))
+        model.stale = model.small            # (a larger model was refitted by the general path inside the call)
+        for m in self.models:
+            if not m.small:
+                m.stale = False
+        xs, ys = winners_to_points(st, self.models, st["grids"], current_best, self.task)
+        self.last_intervention = chosen.value
+        return xs, ys, (self.exploration_set[chosen.value], chosen.value)
+
     def current_best_solution(self, current_best_y):
         """CBO.py:262-267 (the monitor's ``current_best_y`` dict is passed in)."""
         return find_current_global(current_best_y, self.intervention_names, self.task)

@@ -273,12 +273,17 @@ class HipGaussianProcess:
         if fit:
             self._fit()
 
+    def hyper_is_initial(self):
+        """The hyper-parameters are the ones the constructor was given (what a model rebuilt by the reference starts from)."""
+        v0, ls0, nv0 = self._initial_hyper
+        return (self.variance, self.noise_var) == (v0, nv0) and np.array_equal(self.lengthscale, ls0)
+
     def rebuild(self, X, Y, fit=True):
         """What the reference obtains by constructing a NEW model on new data (src/CBO.py:224-235 builds one each
         trial): the hyper-parameters the constructor was given, the new data.  Same device handle and buffers, so
         nothing is allocated when the padded size does not change."""
-        v0, ls0, nv0 = self._initial_hyper
-        if (self.variance, self.noise_var) != (v0, nv0) or not np.array_equal(self.lengthscale, ls0):
+        if not self.hyper_is_initial():
+            v0, ls0, nv0 = self._initial_hyper
             self.set_hyperparameters(v0, ls0, nv0, fit=False)
         self.set_data(X, Y, fit=fit)                 # appends when the data merely grew by one row
 

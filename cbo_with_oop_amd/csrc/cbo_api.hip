@@ -1684,6 +1684,7 @@ static void fill_small_model(cbo_small_set &st, const cbo_gp *g)
     st.n = (int)g->n; st.d = g->d; st.zero_diag = g->h.zero_diag; st.ard = g->h.ard; st.pad_ = 0;
     st.variance = g->h.variance; st.lengthscale = g->h.lengthscale; st.noise_var = g->noise_var;
     st.diag_add = g->noise_var + kGpyDiagJitter;
+    st.stage = nullptr; st.stage_ls = nullptr; st.raw = g->raw; st.pv = g->X.pv;
 }
 
 static int ensure_small_buffers(cbo_ctx *c, int n_sets, int blocks)
@@ -1720,8 +1721,19 @@ static int ensure_small_buffers(cbo_ctx *c, int n_sets, int blocks)
     return CBO_OK;
 }
 
+// staged_set >= 0 (cbo_trial_step): that set's new data sit in the context's staging buffer, its model's host-side state
+// is already the new one, and the one-launch path -- which the caller has checked the set takes -- prepares and stores them
+static int sweep_sets_impl(int n_sets, cbo_gp *const *gps, cbo_cands *const *cands, const double *y_best, int task,
+                           double ei_jitter, const double *costs, double *best_vals, int64_t *best_idxs, int staged_set);
+
 extern "C" int cbo_acq_sweep_sets(int n_sets, cbo_gp *const *gps, cbo_cands *const *cands, const double *y_best, int task,
                                   double ei_jitter, const double *costs, double *best_vals, int64_t *best_idxs)
+{
+    return sweep_sets_impl(n_sets, gps, cands, y_best, task, ei_jitter, costs, best_vals, best_idxs, -1);
+}
+
+static int sweep_sets_impl(int n_sets, cbo_gp *const *gps, cbo_cands *const *cands, const double *y_best, int task,
+                           double ei_jitter, const double *costs, double *best_vals, int64_t *best_idxs, int staged_set)
 {
     if (n_sets <= 0 || !gps || !cands || !y_best || !costs || !best_vals || !best_idxs)
         return fail(CBO_ERR_INVALID, "bad argument");
@@ -1754,6 +1766,10 @@ extern "C" int cbo_acq_sweep_sets(int n_sets, cbo_gp *const *gps, cbo_cands *con
             const bool causal = g->X.sv != nullptr;
             cbo_small_set &st = c->sets_host[j];
             fill_small_model(st, g);
+            if (small[j] == staged_set) {
+                st.stage = c->stage;
+                st.stage_ls = g->h.ard ? g->ls_dev : nullptr;
+            }
             st.cxs = k->P.xs; st.csq = k->P.sq; st.csv = causal ? k->P.sv : nullptr;
             st.cpm = causal ? k->pm : nullptr; st.cpv = causal ? k->pv : nullptr;
             st.cld = k->P.ld; st.m = k->m; st.index_offset = k->index_offset;
@@ -1815,6 +1831,61 @@ extern "C" int cbo_acq_sweep_sets(int n_sets, cbo_gp *const *gps, cbo_cands *con
         if (rc != CBO_OK) return rc;
     }
     return CBO_OK;
+}
+
+// One reference-scale trial in ONE call (src/CBO.py:143-173, CBO.intervene): the model of the set that was intervened on
+// last receives its new data (src/CBO.py:224-235 rebuilds it; src/Monitor.py:160), every exploration set is swept
+// (src/CBO.py:237-260) and the set to intervene on next is picked (src/CBO.py:269-277) -- cbo_gp_upload_data +
+// cbo_acq_sweep_sets + cbo_argmax_sets without the three trips through the caller's language, which at the reference's
+// model sizes (one 29 us launch for all sets) cost as much as the device work.
+extern "C" int cbo_trial_step(int n_sets, cbo_gp *const *gps, cbo_cands *const *cands, int refit_set, int64_t n,
+                              const double *X, const double *y, const double *pm, const double *pv, const double *y_best,
+                              int task, double ei_jitter, const double *costs, double *best_vals, int64_t *best_idxs,
+                              int *chosen_out)
+{
+    if (n_sets <= 0 || !gps || !chosen_out) return fail(CBO_ERR_INVALID, "bad argument");
+    if (refit_set >= n_sets) return fail(CBO_ERR_INVALID, "refit_set out of range");
+    int staged = -1;
+    if (refit_set >= 0) {
+        cbo_gp *g = gps[refit_set];
+        if (!g) return fail(CBO_ERR_INVALID, "gp is NULL");
+        if (!cands || !y_best || !costs || !best_vals || !best_idxs) return fail(CBO_ERR_INVALID, "bad argument");
+        cbo_ctx *c = g->ctx;
+        // The upload folded into the sweep's one launch: when the set takes the one-launch path (as every model the
+        // reference builds does) its new data go to the staging buffer and the launch's workgroups prepare the points
+        // from there themselves -- no preparation launch, no stream synchronisation (15 of a trial's 57 us).  The same
+        // conditions as sweep_sets_impl's, plus: the padded size and the prior-ness do not change, the data fit the buffer.
+        bool fuse = c->small_sets && g->dtype == CBO_DTYPE_F64 && g->n_pad == kPadN && n > 0 && n <= kPadN && X && y &&
+                    ((pm == nullptr) == (pv == nullptr)) && ((pv != nullptr) == (g->X.sv != nullptr)) &&
+                    sizeof(double) * (size_t)(n * g->d + n + (pv ? 2 * n : 0)) <= kStageBytes;
+        for (int i = 0; i < n_sets && fuse; ++i) {
+            if (!gps[i] || !cands[i] || gps[i]->ctx != c) fuse = false;
+            else if (gps[i]->dtype == CBO_DTYPE_F64 && gps[i]->n_pad == kPadN && (cands[i]->m + 63) / 64 > 65535) fuse = false;
+        }
+        if (fuse) {
+            HIP_TRY(hipSetDevice(c->device));
+            if (c->stage_pending) { HIP_TRY(hipEventSynchronize(c->stage_done)); c->stage_pending = false; }
+            double *sb = c->stage;
+            std::memcpy(sb, X, sizeof(double) * n * g->d);
+            std::memcpy(sb + n * g->d, y, sizeof(double) * n);
+            g->h_pv.clear();
+            if (pv) {
+                std::memcpy(sb + n * g->d + n, pm, sizeof(double) * n);
+                std::memcpy(sb + n * g->d + 2 * n, pv, sizeof(double) * n);
+                g->h_pv.assign(pv, pv + n);
+            }
+            g->n = n;
+            g->X.n = n;
+            g->fitted = false;
+            staged = refit_set;
+        } else {
+            const int rc = cbo_gp_upload_data(g, n, X, y, pm, pv);      // unfitted: the sweep below refits it
+            if (rc != CBO_OK) return rc;
+        }
+    }
+    int rc = sweep_sets_impl(n_sets, gps, cands, y_best, task, ei_jitter, costs, best_vals, best_idxs, staged);
+    if (rc != CBO_OK) return rc;
+    return cbo_argmax_sets(best_vals, n_sets, chosen_out);
 }
 
 extern "C" int cbo_acq_sweep_host(cbo_gp *g, int64_t m, const double *Xs, const double *pm, const double *pv,

@@ -197,6 +197,12 @@ struct cbo_small_set {
     int n, d, zero_diag, task;
     double variance, lengthscale, noise_var, diag_add, y_best, ei_jitter, cost;
     int ard, pad_;                                     // inputs pre-scaled per dimension (lengthscale gradient per dimension)
+    // cbo_trial_step: the model's NEW data have not been uploaded -- they sit in pinned (device-mapped) memory as
+    // [X (n,d) | y (n) | prior mean (n) | prior variance (n)] and every workgroup of the set prepares the points from there
+    // itself (the arithmetic of prep_points_staged_kernel); the set's first workgroup also fills the resident copies
+    // (raw, y, pm, pv and xs, sq, sv above).  nullptr: the resident copies are current.
+    const double *stage, *stage_ls;                    // stage_ls: per-dimension lengthscales (ARD) or nullptr
+    double *raw, *pv;
 };
 struct cbo_small_result {
     double best_val;

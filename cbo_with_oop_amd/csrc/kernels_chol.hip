@@ -1069,11 +1069,68 @@ __device__ __forceinline__ void small_model_factor(SmallShared &sh, const cbo_sm
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lc = lane & 15, kq = lane >> 4;
     // ---- the model's points and K(X,X) + diag, rhs, zero fill of what the factorisation reads beyond the tiles
+    // staged: the model's new data are still in the caller's staging buffer (cbo_trial_step): prepared here, from there, with
+    // prep_points_staged_kernel's arithmetic; the set's first workgroup also writes the resident copies
+    const bool staged = st.stage != nullptr && (phases & 1);
+    const bool writer = staged && blockIdx.x == 0;
+    const double *ysrc = staged ? st.stage + (int64_t)st.n * st.d : st.y;
+    const double *pmsrc = staged ? (st.sv ? st.stage + (int64_t)st.n * st.d + st.n : nullptr) : st.pm;
     if (tid < 128) {
         const bool in = tid < st.n;
-        for (int k = 0; k < st.d; ++k) sh.xs[k][tid] = in ? st.xs[(int64_t)k * st.ld + tid] : 0.0;
-        sh.sq[tid] = in ? st.sq[tid] : 0.0;
-        sh.sv[tid] = (in && st.sv) ? st.sv[tid] : 0.0;
+        if (staged) {
+            double x[CBO_MAX_DIM];
+#pragma unroll
+            for (int k = 0; k < CBO_MAX_DIM; ++k) x[k] = 0.0;
+            double pvi = 0.0;
+            if (in) {
+#pragma unroll
+                for (int k = 0; k < CBO_MAX_DIM; ++k)
+                    if (k < st.d) {
+                        double v = st.stage[(int64_t)tid * st.d + k];
+                        if (writer) st.raw[(int64_t)tid * st.d + k] = v;
+                        if (st.stage_ls) v = v / st.stage_ls[k];
+                        x[k] = v;
+                    }
+                if (st.sv) pvi = st.stage[(int64_t)st.n * st.d + 2 * st.n + tid];
+            }
+            double sum;
+            if (st.d == 8) {
+                double r[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) r[k] = __dmul_rn(x[k], x[k]);
+                sum = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])),
+                                __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
+            } else {
+                sum = 0.0;
+#pragma unroll
+                for (int k = 0; k < CBO_MAX_DIM; ++k)
+                    if (k < st.d) sum = __dadd_rn(sum, __dmul_rn(x[k], x[k]));
+            }
+            const double svi = (in && st.sv) ? sqrt(pvi) : 0.0;
+#pragma unroll
+            for (int k = 0; k < CBO_MAX_DIM; ++k)
+                if (k < st.d) sh.xs[k][tid] = x[k];
+            sh.sq[tid] = sum;
+            sh.sv[tid] = svi;
+            if (writer) {
+#pragma unroll
+                for (int k = 0; k < CBO_MAX_DIM; ++k)
+                    if (k < st.d) const_cast<double *>(st.xs)[(int64_t)k * st.ld + tid] = x[k];
+                const_cast<double *>(st.sq)[tid] = sum;
+                if (st.sv) const_cast<double *>(st.sv)[tid] = svi;
+                if (in) {
+                    const_cast<double *>(st.y)[tid] = ysrc[tid];
+                    if (st.sv) {
+                        const_cast<double *>(st.pm)[tid] = pmsrc[tid];
+                        st.pv[tid] = pvi;
+                    }
+                }
+            }
+        } else {
+            for (int k = 0; k < st.d; ++k) sh.xs[k][tid] = in ? st.xs[(int64_t)k * st.ld + tid] : 0.0;
+            sh.sq[tid] = in ? st.sq[tid] : 0.0;
+            sh.sv[tid] = (in && st.sv) ? st.sv[tid] : 0.0;
+        }
     }
     __syncthreads();
     SSTAMP(1);
@@ -1093,7 +1150,7 @@ __device__ __forceinline__ void small_model_factor(SmallShared &sh, const cbo_sm
         for (int r = tid >> 4; r < rows; r += 16)
             for (int c = rows + (tid & 15); c < kDiagLd; c += 16) {
                 double v = 0.0;
-                if (c == 128 && r < st.n) v = st.pm ? __dadd_rn(st.y[r], -st.pm[r]) : st.y[r];   // r = y - m(X)
+                if (c == 128 && r < st.n) v = pmsrc ? __dadd_rn(ysrc[r], -pmsrc[r]) : ysrc[r];   // r = y - m(X)
                 sh.blk.S[r][c] = v;
             }
     }

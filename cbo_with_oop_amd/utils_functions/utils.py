@@ -141,10 +141,17 @@ def find_next_y_points(models, current_global_best, evaluated_sets, costs_functi
             models[i].stale = False
     if raw:
         return None, [(float(vals[i]), int(idxs[i])) for i in range(s)]
+    return winners_to_points(st, models, grids, current_global_best, task)
+
+
+def winners_to_points(st, models, grids, current_global_best, task):
+    """(xs, ys) of utils.py:36 from the winners a multi-set sweep left in ``st`` (the cache entry of
+    ``find_next_y_points``): the grid point of every set and its acquisition value re-evaluated at that point alone --
+    only variable costs change the value."""
+    costs, batch_cost, vals, idxs = st["costs"], st["batch_cost"], st["vals"], st["idxs"]
     xs, ys = [], []
-    for i in range(s):
+    for i in range(len(models)):
         x_new = grids[i].points[idxs[i] - grids[i].index_offset][None, :].copy()
-        # utils.py:36 re-evaluates the acquisition at x_new alone; only variable costs change the value
         point_cost = float(costs[i].evaluate(x_new))
         if point_cost == batch_cost[i]:
             y = np.array([[vals[i]]])

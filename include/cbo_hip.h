@@ -26,7 +26,7 @@ extern "C" {
  * cbo_abi_version() returns this value from a product build.  Timing-only builds (CBO_DIAG_KNOBS, or a non-zero
  * F32_DBG mask, whose results may be wrong by construction) return CBO_HIP_ABI_DIAG_BASE + this value, so that a
  * consumer checking the version refuses them as the product. */
-#define CBO_HIP_ABI_VERSION 2
+#define CBO_HIP_ABI_VERSION 3
 #define CBO_HIP_ABI_DIAG_BASE 1000
 #define CBO_MAX_DIM 8
 
@@ -240,6 +240,18 @@ int cbo_gp_fit_sweep(cbo_gp *gp, cbo_cands *cands, double y_best, int task, doub
  * Same numbers as the per-set calls (same device functions, same summation orders).  All pairs on one context. */
 int cbo_acq_sweep_sets(int n_sets, cbo_gp *const *gps, cbo_cands *const *cands, const double *y_best, int task,
                        double ei_jitter, const double *costs, double *best_vals, int64_t *best_idxs);
+
+/* One whole trial of the reference's loop in one call -- what CBO.intervene() (src/CBO.py:143-173) does between two
+ * observations, for callers whose models are small enough that three calls' worth of host glue would cost as much as
+ * the device work: (1) the model of the set intervened on last takes its new data, as src/CBO.py:224-235
+ * (update_gaussian_process_of_last_intervention) / src/Monitor.py:160 (set_data) give it: gps[refit_set] <- (n, X, y,
+ * prior mean / variance at X or NULL), left unfitted; refit_set < 0 skips this; (2) cbo_acq_sweep_sets over all pairs
+ * (src/CBO.py:237-260); (3) cbo_argmax_sets over the S winners (src/CBO.py:269-277) into *chosen_out.  Errors as those
+ * calls; on an error the outputs are unspecified and the model may already hold the new data. */
+int cbo_trial_step(int n_sets, cbo_gp *const *gps, cbo_cands *const *cands, int refit_set, int64_t n,
+                   const double *X, const double *y, const double *prior_mean_X, const double *prior_var_X,
+                   const double *y_best, int task, double ei_jitter, const double *costs, double *best_vals,
+                   int64_t *best_idxs, int *chosen_out);
 
 /* Host-buffer convenience form of the same call (uploads Xs first). */
 int cbo_acq_sweep_host(cbo_gp *gp, int64_t m, const double *Xs, const double *prior_mean_s,

@@ -1620,6 +1620,51 @@ def test_sweep_sets_switch_and_path_integration(hip, monkeypatch):
     assert run() == one_launch
 
 
+def test_trial_step_is_the_three_calls_in_one(hip):
+    """CBOAcquisitionPath.trial_step = ONE cbo_trial_step call for what CBO.intervene() does between two observations
+    (src/CBO.py:143-173): the rebuilt model of the set intervened on last, the sweep of every set, the pick.  Over a short
+    trajectory on the toy graph (data of the chosen set growing by one observation per trial) it must return exactly what
+    the three calls return on a twin path -- same device functions, same bits -- and pick what the oracle picks."""
+    from cbo_with_oop_amd import CBOAcquisitionPath, GaussianProcessType
+    from cbo_with_oop_amd.graphs import ToyGraph, meshgrid_candidates
+    rng = np.random.default_rng(4)
+    es = ToyGraph.get_exploration_set("MIS")
+    targets = [ToyGraph.target_do_x, ToyGraph.target_do_z]
+
+    def fresh():
+        xs = [rng0.uniform(-5, 5, (12, 1)), rng0.uniform(-5, 20, (12, 1))]
+        ys = [targets[0](xs[0]), targets[1](xs[1])]
+        path = CBOAcquisitionPath(GaussianProcessType.NON_CAUSAL_GP, es, ToyGraph.get_cost_structure(1), "min", xs, ys,
+                                  [ToyGraph.bounds(s) for s in es], grid_shapes=[[200], [200]], comm=None)
+        path.update_all_gaussian_processes()
+        return path, xs, ys
+
+    rng0 = np.random.default_rng(4)
+    one, xs1, ys1 = fresh()
+    rng0 = np.random.default_rng(4)
+    three, xs3, ys3 = fresh()
+    grids = [meshgrid_candidates(ToyGraph.bounds(s), [200]) for s in es]
+    for trial in range(8):
+        best = min(float(ys1[0].min()), float(ys1[1].min()))
+        a_x, a_y, (a_set, a_idx) = one.trial_step(best)
+        if three.last_intervention is not None:
+            three.update_gaussian_process_of_last_intervention()
+        b_x, b_y = three.compute_best_acquisition_values(best)
+        b_set, b_idx = three.select_next_intervention(b_y)
+        assert a_idx == b_idx and a_set == b_set
+        assert all(np.array_equal(p, q) for p, q in zip(a_x, b_x)) and all(np.array_equal(p, q) for p, q in zip(a_y, b_y))
+        # the oracle's pick on the same data and grids
+        vals = [O.acquisition_sweep(O.fit(xs1[s], ys1[s]), grids[s], best, cost=1.0)[1] for s in range(2)]
+        assert O.select_next_intervention([np.array([[v]]) for v in vals]) == a_idx
+        # intervene: the chosen set gains the point (both paths share the arrays' contents, not the objects)
+        for xs, ys in ((xs1, ys1), (xs3, ys3)):
+            xs[a_idx] = np.vstack([xs[a_idx], a_x[a_idx]])
+            ys[a_idx] = np.vstack([ys[a_idx], targets[a_idx](a_x[a_idx])])
+        assert one.last_intervention == a_idx
+    # from the second trial on the one-call form was taken (the first builds the handle arrays through the three calls)
+    assert one._call_cache.get("sweep_sets") is not None and one.models[a_idx].small
+
+
 def test_path_rebuilds_between_sweeps_never_reuse_destroyed_handles(hip):
     """A set rebuilt twice without a sweep in between (two observe trials in a row with one set, or closures that
     change twice): the multi-set call must be handed the handles of the objects that are alive now.  The cache of the
