@@ -212,11 +212,17 @@ class CBOAcquisitionPath:
         s = self.last_intervention
         st = self._call_cache.get("sweep_sets")
         model = self.models[s] if (s is not None and self.models) else None
-        fast = (st is not None and model is not None and self.placement()[0] == "single"
+        fast = (st is not None and model is not None and (self.comm is None or self.comm.world == 1)
                 and model.mean_function is self.mean_functions[s] and model.variance_adjustment is self.var_functions[s]
-                and model.hyper_is_initial() and st["cost_table"] is self.costs and len(st["models"]) == self.es_size
-                and all(a is b for a, b in zip(st["models"], self.models))
-                and all(self._grids.get(i) is not None and self._grids[i][1] is st["grids"][i] for i in range(self.es_size)))
+                and model._hyper_initial and st["cost_table"] is self.costs
+                and st["models"] == self.models)             # (lists of the same objects: compared by identity first)
+        if fast:
+            grids, cached = st["grids"], self._grids
+            for i in range(self.es_size):
+                entry = cached.get(i)
+                if entry is None or entry[1] is not grids[i]:
+                    fast = False
+                    break
         if not fast:
             if s is not None:
                 self.update_gaussian_process_of_last_intervention()
@@ -224,12 +230,19 @@ class CBOAcquisitionPath:
             return xs, ys, self.select_next_intervention(ys)
         model._set_arrays(self.data_x[s], self.data_y[s])
         pm, pv = model._prior(model.X)
-        st["y_best"][:] = float(np.asarray(current_best, dtype=np.float64).reshape(-1)[0])
-        chosen = ctypes.c_int(-1)
-        _lib.check(_lib.load().cbo_trial_step(self.es_size, st["gps"], st["cds"], s, model.X.shape[0], _lib.dptr(model.X),
-                                              _lib.dptr(model._y_flat), _lib.dptr(pm), _lib.dptr(pv), _lib.dptr(st["y_best"]),
-                                              _lib.TASK_CODE[self.task], 0.0, _lib.dptr(st["batch_cost"]), _lib.dptr(st["vals"]),
-                                              st["idxs"].ctypes.data_as(_lib.c_int64_p), ctypes.byref(chosen)))
+        st["y_best"].fill(current_best if type(current_best) is float else
+                          float(np.asarray(current_best, dtype=np.float64).reshape(-1)[0]))
+        fixed = st.get("trial_args")             # the pointers that do not change from trial to trial, made once
+        if fixed is None:
+            chosen = ctypes.c_int(-1)
+            fixed = st["trial_args"] = (_lib.load().cbo_trial_step, _lib.dptr(st["y_best"]), _lib.dptr(st["batch_cost"]),
+                                        _lib.dptr(st["vals"]), st["idxs"].ctypes.data_as(_lib.c_int64_p), chosen,
+                                        ctypes.byref(chosen))
+        call, y_best, batch_cost, vals, idxs, chosen, chosen_ref = fixed
+        rc = call(self.es_size, st["gps"], st["cds"], s, model.X.shape[0], _lib.dptr(model.X), _lib.dptr(model._y_flat),
+                  _lib.dptr(pm), _lib.dptr(pv), y_best, _lib.TASK_CODE[self.task], 0.0, batch_cost, vals, idxs, chosen_ref)
+        if rc:
+            _lib.check(rc)
         model.stale = model.small            # (a larger model was refitted by the general path inside the call)
         for m in self.models:
             if not m.small:

@@ -81,6 +81,7 @@ class HipGaussianProcess:
             _lib.dptr(pm), _lib.dptr(pv), self.variance, _lib.dptr(self.lengthscale), int(self.ard), self.noise_var,
             int(self.zero_diag), ctypes.byref(self._handle)))
         self._initial_hyper = (self.variance, self.lengthscale.copy(), self.noise_var)
+        self._hyper_initial = True
         if fit:
             self._fit()
         else:
@@ -269,14 +270,16 @@ class HipGaussianProcess:
         ls = np.ascontiguousarray(ls)
         _lib.check(self._lib.cbo_gp_set_hyper(self._handle, float(variance), _lib.dptr(ls), float(noise_var)))
         self.variance, self.lengthscale, self.noise_var = float(variance), ls, float(noise_var)
+        v0, ls0, nv0 = self._initial_hyper
+        self._hyper_initial = (self.variance, self.noise_var) == (v0, nv0) and np.array_equal(ls, ls0)
         self.stale = True            # the device model is unfitted from here on; _fit clears the flag when it succeeds
         if fit:
             self._fit()
 
     def hyper_is_initial(self):
-        """The hyper-parameters are the ones the constructor was given (what a model rebuilt by the reference starts from)."""
-        v0, ls0, nv0 = self._initial_hyper
-        return (self.variance, self.noise_var) == (v0, nv0) and np.array_equal(self.lengthscale, ls0)
+        """The hyper-parameters are the ones the constructor was given (what a model rebuilt by the reference starts
+        from); they only change through ``set_hyperparameters``, which keeps the answer."""
+        return self._hyper_initial
 
     def rebuild(self, X, Y, fit=True):
         """What the reference obtains by constructing a NEW model on new data (src/CBO.py:224-235 builds one each

@@ -188,8 +188,19 @@ def dptr(a):
     """float64 C-contiguous ndarray (or None) -> double*; the array must be kept alive by the caller."""
     if a is None:
         return None
-    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    n = a.size
+    if 0 < n <= 65536 and a.flags.writeable:
+        # a ctypes array over the same memory: accepted where double* is declared, and four times cheaper to make than
+        # ndarray.ctypes.data_as (0.8 against 3.5 us -- a reference-scale trial is 50 us)
+        t = _array_types.get(n)
+        if t is None:
+            t = _array_types[n] = ctypes.c_double * n
+        return t.from_buffer(a)
     return a.ctypes.data_as(c_double_p)
+
+
+_array_types = {}
 
 
 def as_f64(a, shape=None):

@@ -1780,7 +1780,10 @@ static int sweep_sets_impl(int n_sets, cbo_gp *const *gps, cbo_cands *const *can
         if (++c->small_seq == 0) c->small_seq = 1;
         const int seq = c->small_seq;
         // CBO_HIP_TRACE_SLOW=1: a call that takes more than a millisecond says on stderr where the time went
+        // (a value above 1 is the threshold in microseconds instead)
         static const bool trace_slow = std::getenv("CBO_HIP_TRACE_SLOW") != nullptr;
+        static const double trace_over_us = trace_slow && std::atof(std::getenv("CBO_HIP_TRACE_SLOW")) > 1.0
+                                                ? std::atof(std::getenv("CBO_HIP_TRACE_SLOW")) : 1000.0;
         using clk = std::chrono::steady_clock;
         const clk::time_point t_begin = trace_slow ? clk::now() : clk::time_point();
         clk::time_point t_launched, t_polled;
@@ -1802,9 +1805,9 @@ static int sweep_sets_impl(int n_sets, cbo_gp *const *gps, cbo_cands *const *can
             if (trace_slow) {
                 const clk::time_point t_end = clk::now();
                 auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-                if (us(t_begin, t_end) > 1000.0)
-                    std::fprintf(stderr, "[cbo] slow cbo_acq_sweep_sets call #%d: launch %.0f us, poll %.0f us (%s), "
-                                 "synchronise %.0f us (%s)\n", seq, us(t_begin, t_launched), us(t_launched, t_polled),
+                if (us(t_begin, t_end) > trace_over_us)
+                    std::fprintf(stderr, "[cbo] slow cbo_acq_sweep_sets call #%d: launch %.1f us, poll %.1f us (%s), "
+                                 "synchronise %.1f us (%s)\n", seq, us(t_begin, t_launched), us(t_launched, t_polled),
                                  all ? "records arrived" : "gave up", us(t_polled, t_end),
                                  !all ? "after the poll gave up" : reap ? "periodic reap" : "none");
             }

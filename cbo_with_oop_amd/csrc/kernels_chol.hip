@@ -24,6 +24,7 @@
 // gradients of one MLE iterate).
 #include <hip/hip_ext.h>
 #include <climits>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -298,8 +299,11 @@ struct Diag2Shared {
 //     lets NaN / Inf through the rest of the tile, which jitchol's retry discards anyway;
 //   * a rank-4 MFMA carries the block into the rows below it.
 // Every value goes through the same operations in the same order as the plain right-looking form.
+// `blocks` (uniform) < 4: only the tile's first `blocks` blocks of four pivots are factored -- the rows of the others are
+// identity padding (a model of fewer rows than its tiles hold), whose factor and inverse are the identity they already
+// are; nothing a posterior reads depends on them.
 __device__ __forceinline__ d4 factor_tile_regs(d4 din, int lane, int pivot_row0, int *info, double (*Yt)[16],
-                                               double *__restrict__ invDt_tile)
+                                               double *__restrict__ invDt_tile, int blocks = 4)
 {
     const int lc = lane & 15, kq = lane >> 4;
     d4 d, e;
@@ -313,6 +317,7 @@ __device__ __forceinline__ d4 factor_tile_regs(d4 din, int lane, int pivot_row0,
     int bad = 0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
+        if (b >= blocks) break;
         d4 t = MFMA_F64(sel, d[b], zero);
         d4 s = MFMA_F64(sel, e[b], zero);
         double a[4][4], u[4][4], inv[4], dj[4];
@@ -584,7 +589,8 @@ __device__ __forceinline__ void diag_worker(Diag2Shared &sh, double *A, int64_t 
 template <bool PUBLISH = false>
 __device__ __forceinline__ void diag128_factor_in_lds(Diag2Shared &sh, double *A, int64_t lda, int r0, int rcol,
                                                       double *__restrict__ invDt, int *info,
-                                                      double *__restrict__ zvec, int tiles, int *flag = nullptr)
+                                                      double *__restrict__ zvec, int tiles, int *flag = nullptr,
+                                                      int last_blocks = 4)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -597,7 +603,7 @@ __device__ __forceinline__ void diag128_factor_in_lds(Diag2Shared &sh, double *A
         for (int r = 0; r < 4; ++r) t0[r] = sh.S[kq + 4 * r][lc];
         // the factor of the tile stays in LDS, in the tile's own place (nobody else touches it): a worker wave takes
         // it and the inverse to global memory in the tile's interval
-        const d4 u = factor_tile_regs(t0, lane, r0, info, sh.Yt[0], nullptr);
+        const d4 u = factor_tile_regs(t0, lane, r0, info, sh.Yt[0], nullptr, tiles == 1 ? last_blocks : 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) sh.S[kq + 4 * r][lc] = u[r];
     }
@@ -629,7 +635,8 @@ __device__ __forceinline__ void diag128_factor_in_lds(Diag2Shared &sh, double *A
                 accb = MFMA_F64(x[3], -x[3], accb);
                 acc += accb;
                 DSTAMP(0, jb, 1);
-                const d4 u = factor_tile_regs(acc, lane, r0 + o + 16, info, sh.Yt[(jb + 1) & 1], nullptr);
+                const d4 u = factor_tile_regs(acc, lane, r0 + o + 16, info, sh.Yt[(jb + 1) & 1], nullptr,
+                                              jb + 2 == tiles ? last_blocks : 4);
                 DSTAMP(0, jb, 2);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sh.S[o + 16 + kq + 4 * r][o + 16 + lc] = u[r];
@@ -974,35 +981,51 @@ __device__ __forceinline__ void small_assemble(SmallShared &sh, const cbo_small_
     const int i = tid >> 4, j = tid & 15;
     const double inv_l2 = 1.0 / (st.lengthscale * st.lengthscale);
     const bool causal = st.sv != nullptr;
-    for (int ti = 0; ti < tiles; ++ti)
-        for (int tj = ti; tj < tiles; ++tj) {
-            const int gi = 16 * ti + i, gj = 16 * tj + j;
-            double v;
-            if (gi < st.n && gj < st.n) {
-                double xi[D], xj[D];
+    // Four tile pairs at a time, no branch around a value: one wave per SIMD has nothing to hide an exp's dependent
+    // chain behind but the next value's chain (the points beyond n are zeros in LDS: computed, then replaced).
+    int ti = 0, tj = 0;                                                // (uniform)
+    while (ti < tiles) {
+        int gis[4], gjs[4];
+        bool due[4];
 #pragma unroll
-                for (int k = 0; k < D; ++k) { xi[k] = sh.xs[k][gi]; xj[k] = sh.xs[k][gj]; }
-                v = kernel_value<D>(xi, xj, sh.sq[gi], sh.sq[gj], st.variance, inv_l2, st.zero_diag && gi == gj);
-                if (causal) v = __dadd_rn(v, __dmul_rn(sh.sv[gi], sh.sv[gj]));
-                if (gi == gj) v = __dadd_rn(v, st.diag_add);           // Ky = K + (noise + 1e-8) I
-            } else {
-                v = (gi == gj) ? 1.0 : 0.0;                            // identity padding
-            }
-            sh.blk.S[gi][gj] = v;
+        for (int u = 0; u < 4; ++u) {
+            due[u] = ti < tiles;
+            gis[u] = 16 * (due[u] ? ti : 0) + i;
+            gjs[u] = 16 * (due[u] ? tj : 0) + j;
+            if (++tj >= tiles) { ++ti; tj = ti; }
         }
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int gi = gis[u], gj = gjs[u];
+            double xi[D], xj[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) { xi[k] = sh.xs[k][gi]; xj[k] = sh.xs[k][gj]; }
+            double w = kernel_value<D>(xi, xj, sh.sq[gi], sh.sq[gj], st.variance, inv_l2, st.zero_diag && gi == gj);
+            if (causal) w = __dadd_rn(w, __dmul_rn(sh.sv[gi], sh.sv[gj]));
+            const double wd = __dadd_rn(w, st.diag_add);               // Ky = K + (noise + 1e-8) I
+            w = (gi == gj) ? wd : w;
+            const double pad = (gi == gj) ? 1.0 : 0.0;                 // identity padding
+            v[u] = (gi < st.n && gj < st.n) ? w : pad;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (due[u]) sh.blk.S[gis[u]][gjs[u]] = v[u];
+    }
 }
 
 template <int D>
 __device__ __forceinline__ double small_kstar(const SmallShared &sh, const cbo_small_set &st, int row, const double *xc,
                                               double csq, double csv, double inv_l2)
 {
-    if (row >= st.n) return 0.0;
+    // (no branch around the value -- the four of a tile interleave; rows beyond n are zeros in LDS)
     double xi[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) xi[k] = sh.xs[k][row];
     double v = kernel_value<D>(xi, xc, sh.sq[row], csq, st.variance, inv_l2, false);
-    if (st.sv != nullptr) v = __dadd_rn(v, __dmul_rn(sh.sv[row], csv));
-    return v;
+    const double vc = __dadd_rn(v, __dmul_rn(sh.sv[row], csv));
+    v = (st.sv != nullptr) ? vc : v;
+    return (row < st.n) ? v : 0.0;
 }
 
 template <int D>
@@ -1011,10 +1034,15 @@ __device__ __forceinline__ void small_kstar_tiles(const SmallShared &sh, const c
                                                   d4 (&acc)[8])
 {
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
+    for (int t = 0; t < 8; ++t) {
+        if (t < tiles) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            acc[t][r] = (t < tiles) ? small_kstar<D>(sh, st, 16 * t + kq + 4 * r, xc, csq, csv, inv_l2) : 0.0;
+            for (int r = 0; r < 4; ++r) acc[t][r] = small_kstar<D>(sh, st, 16 * t + kq + 4 * r, xc, csq, csv, inv_l2);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] = 0.0;
+        }
+    }
 }
 
 // The last workgroup of a set to finish (an atomic ticket) reduces the set's per-workgroup winners, hands the result
@@ -1035,6 +1063,7 @@ __device__ __forceinline__ void small_set_finish(double bv, int64_t bi, int set,
     __syncthreads();
     if (*last_flag == 0 || tid >= 64) return;
     __threadfence();
+    const int status = (tid == 0) ? atomicAdd(&info[set], 0) : 0;       // (in flight with the loads below)
     bv = -INFINITY;
     bi = INT64_MAX;
     for (int b = tid; b < blocks_per_set; b += 64) {
@@ -1046,7 +1075,7 @@ __device__ __forceinline__ void small_set_finish(double bv, int64_t bi, int set,
     if (tid == 0) {
         out[set].best_val = bv;
         out[set].best_idx = bi;
-        out[set].info = atomicAdd(&info[set], 0);
+        out[set].info = status;
         __threadfence_system();
         *reinterpret_cast<volatile int *>(&out[set].seq) = seq;
         info[set] = 0;
@@ -1062,7 +1091,7 @@ __device__ __forceinline__ void small_set_finish(double bv, int64_t bi, int set,
 // the scratch (somebody factored the model before this launch), 3 = both.
 __device__ __forceinline__ void small_model_factor(SmallShared &sh, const cbo_small_set &st, int tiles, double *Us,
                                                    double *invs, int *info_word, double (&iv)[8][4], double (&zr)[8][4],
-                                                   int phases = 3)
+                                                   int phases = 3, bool skip_padding = false)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1075,6 +1104,7 @@ __device__ __forceinline__ void small_model_factor(SmallShared &sh, const cbo_sm
     const bool writer = staged && blockIdx.x == 0;
     const double *ysrc = staged ? st.stage + (int64_t)st.n * st.d : st.y;
     const double *pmsrc = staged ? (st.sv ? st.stage + (int64_t)st.n * st.d + st.n : nullptr) : st.pm;
+    double staged_y = 0.0, staged_pm = 0.0;
     if (tid < 128) {
         const bool in = tid < st.n;
         if (staged) {
@@ -1083,6 +1113,9 @@ __device__ __forceinline__ void small_model_factor(SmallShared &sh, const cbo_sm
             for (int k = 0; k < CBO_MAX_DIM; ++k) x[k] = 0.0;
             double pvi = 0.0;
             if (in) {
+                // (y and the prior mean are fetched with the points: one trip across the host link, not two)
+                staged_y = ysrc[tid];
+                if (pmsrc) staged_pm = pmsrc[tid];
 #pragma unroll
                 for (int k = 0; k < CBO_MAX_DIM; ++k)
                     if (k < st.d) {
@@ -1119,14 +1152,18 @@ __device__ __forceinline__ void small_model_factor(SmallShared &sh, const cbo_sm
                 const_cast<double *>(st.sq)[tid] = sum;
                 if (st.sv) const_cast<double *>(st.sv)[tid] = svi;
                 if (in) {
-                    const_cast<double *>(st.y)[tid] = ysrc[tid];
+                    const_cast<double *>(st.y)[tid] = staged_y;
                     if (st.sv) {
-                        const_cast<double *>(st.pm)[tid] = pmsrc[tid];
+                        const_cast<double *>(st.pm)[tid] = staged_pm;
                         st.pv[tid] = pvi;
                     }
                 }
             }
         } else {
+            if (in && (phases & 1)) {                     // (with the points: the rhs does not wait for a second trip)
+                staged_y = ysrc[tid];
+                if (pmsrc) staged_pm = pmsrc[tid];
+            }
             for (int k = 0; k < st.d; ++k) sh.xs[k][tid] = in ? st.xs[(int64_t)k * st.ld + tid] : 0.0;
             sh.sq[tid] = in ? st.sq[tid] : 0.0;
             sh.sv[tid] = (in && st.sv) ? st.sv[tid] : 0.0;
@@ -1149,14 +1186,15 @@ __device__ __forceinline__ void small_model_factor(SmallShared &sh, const cbo_sm
         const int rows = 16 * tiles;
         for (int r = tid >> 4; r < rows; r += 16)
             for (int c = rows + (tid & 15); c < kDiagLd; c += 16) {
-                double v = 0.0;
-                if (c == 128 && r < st.n) v = pmsrc ? __dadd_rn(ysrc[r], -pmsrc[r]) : ysrc[r];   // r = y - m(X)
-                sh.blk.S[r][c] = v;
+                if (c == 128 && r < st.n) continue;                                            // (the rhs: below)
+                sh.blk.S[r][c] = 0.0;
             }
+        if (tid < st.n) sh.blk.S[tid][128] = pmsrc ? __dadd_rn(staged_y, -staged_pm) : staged_y;   // r = y - m(X)
     }
     __syncthreads();
     SSTAMP(2);
-    diag128_factor_in_lds(sh.blk, Us, kSmallLd, 0, 128, invs, info_word, nullptr, tiles);
+    diag128_factor_in_lds(sh.blk, Us, kSmallLd, 0, 128, invs, info_word, nullptr, tiles, nullptr,
+                          skip_padding ? (st.n - 16 * (tiles - 1) + 3) / 4 : 4);
     SSTAMP(3);
     // (ends with a barrier.)  Every wave's stores of factor rows / inverses / z are complete before anyone re-reads them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1202,7 +1240,7 @@ __global__ __launch_bounds__(256) void small_sets_kernel(const SmallSetArgs byva
     if (phases == 1) {                                            // one workgroup per set: factor it, nothing else
         double ivx[8][4], zrx[8][4];
         double *fs = scratch + (int64_t)(set * blocks_per_set) * kSmallScratch;
-        small_model_factor(sh, st, (st.n + 15) / 16, fs, fs + 128 * kSmallLd, &info[set], ivx, zrx, 1);
+        small_model_factor(sh, st, (st.n + 15) / 16, fs, fs + 128 * kSmallLd, &info[set], ivx, zrx, 1, true);
         return;
     }
     const int tid = threadIdx.x;
@@ -1219,16 +1257,19 @@ __global__ __launch_bounds__(256) void small_sets_kernel(const SmallSetArgs byva
     double *my = scratch + (int64_t)(phases == 2 ? set * blocks_per_set : slot) * kSmallScratch;
     double *Us = my, *invs = my + 128 * kSmallLd;
 
-    double iv[8][4], zr[8][4];
-    small_model_factor(sh, st, tiles, Us, invs, &info[set], iv, zr, phases);
-    SSTAMP(4);
-    // ---- K(X, X*) of this wave's 16 candidates, straight into the result layout
+    // this wave's 16 candidates: fetched now, used after the factorisation (their latency is off the chain)
     const int64_t c = (int64_t)blk * 64 + wave * 16 + lc;
     const int64_t cc = (c < st.m) ? c : st.m - 1;                  // clamped: lanes beyond the set compute, nobody looks
     double xc[CBO_MAX_DIM];
 #pragma unroll
     for (int k = 0; k < CBO_MAX_DIM; ++k) xc[k] = (k < st.d) ? st.cxs[(int64_t)k * st.cld + cc] : 0.0;
     const double csq = st.csq[cc], csv = st.csv ? st.csv[cc] : 0.0;
+    const double cpm_c = st.cpm ? st.cpm[cc] : 0.0, cpv_c = st.cpv ? st.cpv[cc] : 0.0;
+
+    double iv[8][4], zr[8][4];
+    small_model_factor(sh, st, tiles, Us, invs, &info[set], iv, zr, phases, true);
+    SSTAMP(4);
+    // ---- K(X, X*) of this wave's 16 candidates, straight into the result layout
     const double inv_l2 = 1.0 / (st.lengthscale * st.lengthscale);
     d4 acc[8];
     switch (st.d) {
@@ -1268,7 +1309,7 @@ __global__ __launch_bounds__(256) void small_sets_kernel(const SmallSetArgs byva
     int64_t bi = INT64_MAX;
     if (kq == 0 && c < st.m) {
         double mean, var;
-        posterior_of(qacc, macc, st.cpm ? st.cpm[c] : 0.0, st.cpv ? st.cpv[c] : 0.0, st.sv != nullptr, p, mean, var);
+        posterior_of(qacc, macc, cpm_c, cpv_c, st.sv != nullptr, p, mean, var);
         bv = acquisition_of(mean, var, p);
         bi = c + st.index_offset;
     }
@@ -1445,13 +1486,20 @@ size_t small_sets_scratch_doubles(int n_sets, int blocks_per_set) { return (size
 void launch_small_sets(hipStream_t s, const cbo_small_set *sets, int n_sets, int blocks_per_set, double *scratch,
                        double *part_val, int64_t *part_idx, int *info, int *ticket, cbo_small_result *out, int seq)
 {
-    // per call, on the current device (several devices in one process: see vec_chain_opt_in); only the instantiation used
-    if (n_sets <= kSmallByValue)
-        hipFuncSetAttribute(reinterpret_cast<const void *>(small_sets_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmallShared));
-    else
-        hipFuncSetAttribute(reinterpret_cast<const void *>(small_sets_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmallShared));
+    // once per device and instantiation (several devices in one process each need it; a failed attempt is repeated by
+    // the next call; the launch itself reports what is wrong if it never succeeds) -- the call costs a microsecond of
+    // the forty a reference-scale trial takes
+    {
+        static std::atomic<unsigned long long> opted[2];
+        int dev = 0;
+        const bool byval = n_sets <= kSmallByValue;
+        if (hipGetDevice(&dev) != hipSuccess || !((opted[byval].load(std::memory_order_relaxed) >> (dev & 63)) & 1ull)) {
+            const void *fn = byval ? reinterpret_cast<const void *>(small_sets_kernel<true>)
+                                   : reinterpret_cast<const void *>(small_sets_kernel<false>);
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmallShared)) == hipSuccess)
+                opted[byval].fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
+        }
+    }
     SmallSetArgs args{};
     const dim3 grid((unsigned)blocks_per_set, (unsigned)n_sets);
     // Few candidate blocks per set (the reference's 100-200 candidates): every workgroup factors its set's model itself,

@@ -150,11 +150,13 @@ def winners_to_points(st, models, grids, current_global_best, task):
     only variable costs change the value."""
     costs, batch_cost, vals, idxs = st["costs"], st["batch_cost"], st["vals"], st["idxs"]
     xs, ys = [], []
+    winners, values, batch = idxs.tolist(), vals.tolist(), batch_cost.tolist()
     for i in range(len(models)):
-        x_new = grids[i].points[idxs[i] - grids[i].index_offset][None, :].copy()
+        j = winners[i] - grids[i].index_offset
+        x_new = grids[i].points[j:j + 1].copy()
         point_cost = float(costs[i].evaluate(x_new))
-        if point_cost == batch_cost[i]:
-            y = np.array([[vals[i]]])
+        if point_cost == batch[i]:
+            y = np.array(((values[i],),))
         else:
             y = CausalExpectedImprovement(current_global_best, task, models[i]).sweep(x_new, cost=point_cost,
                                                                                       want_acq=True)["acq"]

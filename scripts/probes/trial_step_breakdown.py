@@ -47,3 +47,35 @@ for name, fn in (("three calls (round 3's pass)", three_calls), ("path.trial_ste
     for i in range(3000):
         t0 = time.perf_counter(); fn(); t[i] = time.perf_counter() - t0
     print(f"{name:34s} median {np.median(t) * 1e6:7.1f} us   mean {t.mean() * 1e6:7.1f}   p99 {np.percentile(t, 99) * 1e6:7.1f}")
+
+# ---- the host glue of path.trial_step, statement by statement (the C call excluded)
+from cbo_with_oop_amd.utils_functions.utils import winners_to_points
+pc = time.perf_counter
+acc = np.zeros(8)
+reps = 3000
+for _ in range(reps):
+    path.last_intervention = 1
+    t0 = pc()
+    s = path.last_intervention
+    stc = path._call_cache.get("sweep_sets")
+    model = path.models[s]
+    fast = (stc is not None and model is not None and path.placement()[0] == "single"
+            and model.mean_function is path.mean_functions[s] and model.variance_adjustment is path.var_functions[s]
+            and model.hyper_is_initial() and stc["cost_table"] is path.costs and len(stc["models"]) == path.es_size
+            and all(a is b for a, b in zip(stc["models"], path.models))
+            and all(path._grids.get(i) is not None and path._grids[i][1] is stc["grids"][i] for i in range(path.es_size)))
+    t1 = pc()
+    model._set_arrays(path.data_x[s], path.data_y[s])
+    t2 = pc()
+    pm, pv = model._prior(model.X)
+    stc["y_best"].fill(best)
+    t3 = pc()
+    a, b = _lib.dptr(model.X), _lib.dptr(model._y_flat)
+    t4 = pc()
+    lib.cbo_trial_step(2, stc["gps"], stc["cds"], 1, 50, a, b, None, None, yb, 0, 0.0, bc, vals, idxs, ctypes.byref(chosen))
+    t5 = pc()
+    xs_, ys_ = winners_to_points(stc, path.models, stc["grids"], best, "min")
+    t6 = pc()
+    acc[:6] += (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)
+print("glue, mean us: conditions %.2f  _set_arrays %.2f  prior+fill %.2f  two pointers %.2f  [C call %.2f]  winners_to_points %.2f"
+      % tuple(acc[:6] / reps * 1e6))

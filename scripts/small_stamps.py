@@ -14,7 +14,8 @@ path = CBOAcquisitionPath(GaussianProcessType.NON_CAUSAL_GP, es, ToyGraph.get_co
 path.update_all_gaussian_processes()
 best = min(float(ys[0].min()), float(ys[1].min()))
 for _ in range(5):
-    path.compute_best_acquisition_values(best)
+    path.last_intervention = 1
+    path.trial_step(best)
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * 16)()
 lib.cbo_diag_small_stamps.argtypes = [ctypes.c_void_p]
@@ -25,3 +26,13 @@ names = ["descriptor + points -> LDS", "K(X,X) + rhs + zero fill", "factorisatio
 for i, nm in enumerate(names):
     print(f"{nm:40s} {st[i + 1] - st[i]:7d} ticks")
 print(f"{'total':40s} {st[8] - st[0]:7d} ticks")
+# the factorisation's own stamps (diag128_factor_in_lds: [wave][interval][slot]; every workgroup of the launch writes them,
+# whoever came last stays), relative to the start of the factorisation of workgroup (0, 0)
+dbuf = (ctypes.c_ulonglong * (4 * 9 * 4))()
+lib.cbo_diag_chol_stamps.argtypes = [ctypes.c_void_p]
+lib.cbo_diag_chol_stamps(dbuf)
+ds = np.frombuffer(dbuf, dtype=np.uint64).astype(np.int64).reshape(4, 9, 4) - st[2]
+print("factorisation, cycles since its start; wave 0: [interval] update done / tile factored / stored / -;"
+      " waves 1-3: [interval] entered / row panel out / rendezvous passed / trailing done")
+for w in range(4):
+    print(f"  wave {w}:", "  ".join(str(ds[w, jb].tolist()) for jb in range(4)))
