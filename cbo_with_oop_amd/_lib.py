@@ -18,7 +18,7 @@ c_int64_p = ctypes.POINTER(ctypes.c_int64)
 c_int_p = ctypes.POINTER(ctypes.c_int)
 c_void_pp = ctypes.POINTER(ctypes.c_void_p)
 
-ABI_VERSION = 3          # include/cbo_hip.h: CBO_HIP_ABI_VERSION
+ABI_VERSION = 4          # include/cbo_hip.h: CBO_HIP_ABI_VERSION
 ABI_DIAG_BASE = 1000     # CBO_HIP_ABI_DIAG_BASE: timing-only builds report ABI_DIAG_BASE + version
 CBO_OK = 0
 CBO_ERR_INVALID = -1
@@ -116,6 +116,7 @@ SIGNATURES = {
                                         c_double_p, c_int64_p, c_int_p, c_double_p]),
     "cbo_acq_sweep_sets": (ctypes.c_int, [ctypes.c_int, c_void_pp, c_void_pp, c_double_p, ctypes.c_int, ctypes.c_double,
                                           c_double_p, c_double_p, c_int64_p]),
+    "cbo_schedule_report": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
     "cbo_trial_step": (ctypes.c_int, [ctypes.c_int, c_void_pp, c_void_pp, ctypes.c_int, ctypes.c_int64, c_double_p, c_double_p,
                                       c_double_p, c_double_p, c_double_p, ctypes.c_int, ctypes.c_double, c_double_p, c_double_p,
                                       c_int64_p, c_int_p]),
@@ -249,6 +250,15 @@ class Context:
 
     def synchronize(self):
         check(load().cbo_synchronize(self.handle))
+
+    def schedule_report(self):
+        """(shapes still exploring, text): what the context has measured and chosen for ``cbo_gp_fit_sweep``, one line per
+        shape (``cbo_schedule_report``)."""
+        buf = ctypes.create_string_buffer(1 << 16)
+        n = load().cbo_schedule_report(self.handle, buf, len(buf))
+        if n < 0:
+            check(-n)
+        return n, buf.value.decode()
 
     def set_profiling(self, enabled):
         check(load().cbo_set_profiling(self.handle, int(bool(enabled))))

@@ -10,9 +10,12 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <map>
+#include <utility>
 #include <vector>
 
 #include "cbo_internal.h"
+#include "schedule_tuner.h"
 
 using namespace cbo;
 
@@ -79,6 +82,8 @@ struct cbo_ctx {
     bool pipe_half_lds = true;
     double pipe_tail_frac = -1.0;    // CBO_HIP_PIPE_TAIL: rows (fraction) left to the closing left-looking launch; < 0 = automatic
     int n_cu = 256;
+    int n_cu_pipe = 256;             // CUs the pipelined sweep's streams may use (the rest is kept for the factorisation)
+    ScheduleTable schedule;          // (padded rows, padded candidates) -> measured schedule of cbo_gp_fit_sweep (schedule_tuner.h)
     int64_t fused_fallbacks = 0;     // factorisations repeated with separate launches after a fused launch gave up
     bool sweep_cache = true;         // CBO_HIP_SWEEP_CACHE=0: never reuse a candidate set's q, mu between sweeps
     bool small_sets = true;          // CBO_HIP_SMALL_SETS=0: cbo_acq_sweep_sets always takes the general path
@@ -322,9 +327,11 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
         for (int b = 0; b < n_cu; ++b)
             if (b / 8 >= reserve) mask[(size_t)b / 32] |= 1u << (b % 32);
         bool masked = false;
+        c->n_cu_pipe = n_cu;
         if (reserve > 0 && reserve * 8 < n_cu) {
             masked = hipExtStreamCreateWithCUMask(&c->sweep_stream, (uint32_t)mask.size(), mask.data()) == hipSuccess &&
                      hipExtStreamCreateWithCUMask(&c->bulk_stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+            if (masked) c->n_cu_pipe = n_cu - reserve * 8;
             if (!masked) {                       // no CU masking on this stack: plain lower-priority streams instead
                 (void)hipGetLastError();
                 if (c->sweep_stream) { hipStreamDestroy(c->sweep_stream); c->sweep_stream = nullptr; }
@@ -1068,56 +1075,7 @@ static bool prefer_right_looking(const cbo_ctx *c, int64_t n_pad, int64_t cols)
     return rounds * c->n_cu * 5 >= strips * 6;
 }
 
-// How many panel pairs of the overlapped refit + sweep go through the right-looking pipeline before the rest is
-// left to one left-looking launch after the factorisation?  The pipeline's work runs on CUs the chain leaves
-// idle, but it is the less efficient schedule (~2.9 us per 32-row stage and strip round, co-scheduled, against
-// 2.33 us for the strip kernel alone) and it slows the chain it shares the device with.  The best split found by
-// measurement (scripts/overlap_crossover.py with CBO_HIP_PIPE_TAIL, N = 2048 / 4096 / 8192 at 16384 candidates; round 2,
-// with the chain's fused launches: 3 of 8, 5 of 16, 12 of 32 pairs) is reproduced by taking pairs while their device
-// time stays within a budget that stands for the chain's own time -- 1.0 / 3.4 / 15.1 ms at 16 / 32 / 64 panels,
-// interpolated in log-log between those and continued with the slope 1.72 outside (the chain stretches with size as
-// more of it turns from launch latency into trailing-update work that shares the CUs).  With fewer strips than CUs the
-// strip kernel could not fill the device, so everything stays in the pipeline.  CBO_HIP_PIPE_TAIL (fraction of rows for
-// the closing launch) overrides.
-static double pipeline_budget_us(int nb)
-{
-    static const double xs[3] = {4.0, 5.0, 6.0};                   // log2(panels)
-    static const double ys[3] = {10.0, 11.75, 13.88};              // log2(budget in us)
-    const double x = std::log2((double)(nb > 1 ? nb : 1));
-    double y;
-    if (x <= xs[0]) y = ys[0] + 1.72 * (x - xs[0]);
-    else if (x >= xs[2]) y = ys[2] + 1.72 * (x - xs[2]);
-    else if (x <= xs[1]) y = ys[0] + (ys[1] - ys[0]) * (x - xs[0]);
-    else y = ys[1] + (ys[2] - ys[1]) * (x - xs[1]);
-    return std::exp2(y);
-}
-
-static int pipeline_pairs(const cbo_ctx *c, int64_t n_pad, int64_t m_pad)
-{
-    const int nb = (int)(n_pad / 128);
-    const int all_pairs = (nb + 1) / 2;
-    if (c->pipe_tail_frac >= 0.0) {
-        int tail_blocks = (int)(c->pipe_tail_frac * nb + 0.5);
-        tail_blocks += (nb - tail_blocks) & 1;
-        return (nb - (tail_blocks > nb ? nb : tail_blocks)) / 2;
-    }
-    if (prefer_right_looking(c, n_pad, m_pad)) return all_pairs;     // the strip kernel would leave CUs idle
-    const double rounds = (double)(m_pad / kStrip) / (double)c->n_cu;
-    const double budget_us = pipeline_budget_us(nb);
-    double used_us = 0.0;
-    int pairs = 0;
-    while (pairs < all_pairs) {
-        const int rows_below = nb - 2 * (pairs + 1);
-        used_us += rounds * 2.9 * (12.0 + 8.0 * (rows_below > 0 ? rows_below : 0));
-        if (used_us > budget_us) break;
-        ++pairs;
-    }
-    // Several rounds of strips per CU and a short chain: the first pair's updates exceed what the chain hides, but they
-    // run at the strip kernel's own efficiency and take a pair of row blocks off the closing launch all the same
-    // (scripts/schedule_scan.py, 2048 x 65536: 5.34 ms with one pair against 5.67 without; profiles/r03_schedule_crossover.txt)
-    if (pairs == 0 && rounds >= 2.0 && nb >= 8 && nb <= 32) pairs = 1;
-    return pairs;
-}
+// ---- the schedule of cbo_gp_fit_sweep is measured on the calls the caller makes: schedule_tuner.h ----------------------
 
 static int enqueue_right_looking(cbo_gp *g, double *V, int64_t ldv, int64_t cols, double *q, double *mu,
                                  bool lower_tri = false)
@@ -1504,15 +1462,49 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
         if (rc != CBO_OK) return rc;
         return cbo_acq_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
     }
-    // below ~1000 rows the chain is a handful of launches and there is nothing to hide it under; above, the number
-    // of pairs that go through the pipeline adapts to the shape (pipeline_pairs); from ~12000 rows on the factorisation
-    // is bound by its bulk updates, not by the chain, and the pipeline's extra passes over V only cost (16384 points:
-    // 1-2 % slower than the two calls, scripts/overlap_crossover.py)
-    const bool overlap = c->overlap_mode == 1 || (c->overlap_mode != 0 && g->n_pad >= 1024 && g->n_pad <= 12288);
-    if (!overlap) {
-        rc = cbo_gp_fit(g, tries_out, jitter_out);
+    // The schedule: forced by the environment (CBO_HIP_OVERLAP / CBO_HIP_PIPE_TAIL / CBO_HIP_PIPE_GROUP: diagnostics and
+    // scripts/schedule_scan.py), or the one this context has measured for the shape (schedule_choose above).  A model of
+    // one panel pair or less has nothing to pipeline.
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t_call = clk::now();
+    auto us_since = [](clk::time_point a) { return std::chrono::duration<double, std::micro>(clk::now() - a).count(); };
+    static const int pipe_group_env = [] {
+        const char *e = std::getenv("CBO_HIP_PIPE_GROUP");           // 1 = never grouped, G >= 2 = groups of G pairs
+        const int v = e ? std::atoi(e) : 0;                          // (groups beyond 4 pairs -- K = 1024 -- are not
+        return v < 0 ? 0 : (v > 4 ? 4 : v);                          //  covered by the tests: clamped)
+    }();
+    const int nb = (int)(g->n_pad / 128);
+    const int all_pairs = (nb + 1) / 2;
+    const bool forced = c->overlap_mode == 0 || c->overlap_mode == 1 || c->pipe_tail_frac >= 0.0 || pipe_group_env != 0 ||
+                        all_pairs < 2;
+    ScheduleEntry *entry = nullptr;
+    ScheduleChoice choice;
+    if (forced) {
+        choice.group = pipe_group_env >= 2 ? pipe_group_env : (pipe_group_env == 0 && k->m_pad / kStrip >= c->n_cu_pipe) ? 2 : 0;
+        if (c->overlap_mode == 0 || (all_pairs < 2 && c->overlap_mode != 1)) choice.pairs = kSequence;
+        else if (c->pipe_tail_frac >= 0.0) {
+            int tail_blocks = (int)(c->pipe_tail_frac * nb + 0.5);
+            tail_blocks += (nb - tail_blocks) & 1;
+            choice.pairs = (nb - (tail_blocks > nb ? nb : tail_blocks)) / 2;
+        } else choice.pairs = all_pairs >= 4 ? all_pairs / 4 : 1;    // (only overlap / grouping forced: a quarter of the rows)
+    } else {
+        entry = &schedule_entry(c->schedule, c->n_cu_pipe, g->n_pad, k->m_pad / kStrip, k->m_pad);
+        choice = schedule_choose(*entry, !c->profiling && !acq_out && !mean_out && !var_out);
+    }
+    if (choice.pairs == kSequence) {
+        int tries = 0;
+        double jitter = 0.0;
+        const clk::time_point t_fit = clk::now();
+        rc = cbo_gp_fit(g, &tries, &jitter);
+        if (tries_out) *tries_out = tries;
+        if (jitter_out) *jitter_out = jitter;
         if (rc != CBO_OK) return rc;
-        return cbo_acq_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
+        const double fact_us = us_since(t_fit);
+        const clk::time_point t_sweep = clk::now();
+        rc = cbo_acq_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
+        if (rc == CBO_OK && entry)
+            schedule_report(c->n_cu, c->n_cu_pipe, *entry, choice, tries == 0, us_since(t_call) * 1e-3, fact_us, us_since(t_sweep));
+        return rc;
     }
     g->fitted = false;
     double *Vws = c->V;
@@ -1535,16 +1527,8 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
     }
     const bool speculate = qbuf == k->q;
     SweepPipe pipe = make_pipe(g, Vws, ldv, k->m_pad, qbuf, mubuf);
-    // updates in groups of pairs where the bulk stream bounds the pipeline (CBO_HIP_PIPE_GROUP: 1 = never, G >= 2 = groups
-    // of G pairs whatever the shape; default: automatic)
-    // (groups beyond 4 pairs -- K = 1024 -- are not covered by the tests: clamped)
-    static const int pipe_group_env = [] {
-        const char *e = std::getenv("CBO_HIP_PIPE_GROUP");
-        const int v = e ? std::atoi(e) : 0;
-        return v < 0 ? 0 : (v > 4 ? 4 : v);
-    }();
-    pipe.group = pipe_group_env >= 2 ? pipe_group_env : (pipe_group_env == 0 && k->m_pad / kStrip >= c->n_cu && g->n_pad >= 4096) ? 2 : 0;
-    int pairs = pipeline_pairs(c, g->n_pad, k->m_pad);
+    pipe.group = choice.group;
+    int pairs = choice.pairs;
     if (pipe.group >= 2 && c->pipe_tail_frac < 0.0 && pairs >= pipe.group && pairs * 256 < (int)g->n_pad)
         pairs -= pairs % pipe.group;                                                    // whole groups
     pipe.tail_begin = pairs * 256;
@@ -1632,9 +1616,13 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
             HIP_TRY(hipStreamSynchronize(c->stream));
         }
         complete_finish(c, best_val, best_idx);
+        if (entry) schedule_report(c->n_cu, c->n_cu_pipe, *entry, choice, tries == 0 && !fallback.active(), us_since(t_call) * 1e-3, 0.0, 0.0);
         return CBO_OK;
     }
-    return finish_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
+    rc = finish_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
+    if (rc == CBO_OK && entry)
+        schedule_report(c->n_cu, c->n_cu_pipe, *entry, choice, tries == 0 && !fallback.active(), us_since(t_call) * 1e-3, 0.0, 0.0);
+    return rc;
 }
 
 // ---- every exploration set of a trial in one call ------------------------------------------------------------------
@@ -1889,6 +1877,43 @@ extern "C" int cbo_trial_step(int n_sets, cbo_gp *const *gps, cbo_cands *const *
     int rc = sweep_sets_impl(n_sets, gps, cands, y_best, task, ei_jitter, costs, best_vals, best_idxs, staged);
     if (rc != CBO_OK) return rc;
     return cbo_argmax_sets(best_vals, n_sets, chosen_out);
+}
+
+// What the context has measured and chosen for cbo_gp_fit_sweep, one line per shape, as text (scripts/schedule_scan.py,
+// profiles/r04_schedule_crossover.txt).  Returns the number of shapes still exploring (0 = every schedule is settled), or a
+// negative error code; `buf` may be NULL (only the count is wanted).
+extern "C" int cbo_schedule_report(cbo_ctx *c, char *buf, int64_t cap)
+{
+    if (!c) return -fail(CBO_ERR_INVALID, "ctx is NULL");
+    static const char *names[] = {"cold", "sequence", "base", "neighbours", "climb", "grouping", "settled"};
+    std::string out;
+    int exploring = 0;
+    char line[512];
+    for (const auto &kv : c->schedule) {
+        const ScheduleEntry &e = kv.second;
+        if (e.state != ScheduleEntry::SETTLED) ++exploring;
+        const int nb = (int)(kv.first.first / 128);
+        const double rounds = std::ceil((double)e.strips / c->n_cu);
+        std::snprintf(line, sizeof(line), "rows %lld candidates %lld: %s after %d calls; pairs %d of %d (%s), updates %s; "
+                      "measured alone: factorisation %.0f us = %.1f us/panel, sweep %.0f us = %.2f us/stage and round;",
+                      (long long)kv.first.first, (long long)kv.first.second, names[(int)e.state], e.calls, e.cur, e.all_pairs,
+                      e.cur < 0 ? "the plain sequence" : e.cur == 0 ? "overlapped, nothing pipelined" :
+                      e.cur == e.all_pairs ? "everything pipelined" : "then one left-looking launch",
+                      e.group >= 2 ? "in groups of two pairs" : "pair by pair", e.fact_alone_us, nb ? e.fact_alone_us / nb : 0.0,
+                      e.sweep_alone_us, nb ? e.sweep_alone_us / (rounds * 2.0 * nb * (nb + 1)) : 0.0);
+        out += line;
+        for (const auto &sv : e.samples) {
+            std::snprintf(line, sizeof(line), " g%d/p%d:%.3fms x%d", sv.first.first, sv.first.second, sv.second.ms(), sv.second.count);
+            out += line;
+        }
+        out += "\n";
+    }
+    if (buf && cap > 0) {
+        const size_t n = out.size() < (size_t)cap - 1 ? out.size() : (size_t)cap - 1;
+        std::memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return exploring;
 }
 
 extern "C" int cbo_acq_sweep_host(cbo_gp *g, int64_t m, const double *Xs, const double *pm, const double *pv,

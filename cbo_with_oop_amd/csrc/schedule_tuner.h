@@ -1,0 +1,315 @@
+// The schedule of cbo_gp_fit_sweep, chosen from this device's own timings.  Host logic only (no HIP): included by
+// cbo_api.hip, and compiled on its own by tests/test_host_logic.py against a simulated device.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <map>
+#include <utility>
+
+// How many panel pairs of the overlapped refit + sweep go through the right-looking pipeline (under the factorisation, on
+// the CUs its chain leaves idle) before the rest is left to one left-looking launch; whether the pipeline's updates go
+// in groups of two pairs (K = 512); whether to overlap at all.  The best answer depends on how long this device's chain
+// takes per panel, how fast its strips go and how the two slow each other down when they share CUs -- rounds 2 and 3
+// fitted a budget curve through three measured shapes (and a row cut-off, and a grouping rule).  Now every shape
+// (padded rows, padded candidates) of a context is measured on the calls the caller makes anyway:
+//   1. two calls run the plain sequence (cbo_gp_fit, then cbo_acq_sweep) and time its two halves: the factorisation
+//      alone (chain us / panel) and the sweep alone (strip us / stage);
+//   2. the first split is the largest number of pairs whose pipeline -- its share of the sweep's strip stages at the
+//      measured rate, on the CUs the sweep streams may use -- ends no later than the factorisation alone would;
+//   3. from there the split climbs on the measured time of the calls themselves: neighbours first, doubling steps while
+//      they pay, single steps to finish; the candidates are the plain sequence, the overlapped call with an empty pipeline,
+//      and the multiples of a pair (or of a group of pairs) up to everything pipelined.  A candidate's time is the
+//      smaller of two calls, the call after a change of schedule not counted (it pays for the change); two candidates
+//      within 1 % of each other get two more calls each before the decision.  Once settled, the other grouping is tried
+//      at the settled split and kept if it is faster.
+// Results do not depend on the schedule (same bits whatever the split: tests/test_parity_gpu.py), so the exploration
+// only costs the few per cent by which a neighbouring split is slower, on the first ~20-30 calls of a shape.  A new
+// shape next to a settled one (the model grew by a panel) starts from that one's split.  CBO_HIP_SCHEDULE_TUNE=0 stops
+// after step 2; CBO_HIP_PIPE_TAIL / CBO_HIP_PIPE_GROUP / CBO_HIP_OVERLAP force a schedule as before (the tuner is
+// bypassed); cbo_schedule_report prints what was measured and chosen.
+
+// a candidate's calls: its time is the median of them (the mean of the middle two) -- an estimate that does not improve
+// with the number of calls, as the smallest of them would
+struct ScheduleSample {
+    double t[8]; int count = 0, need = 2;
+    void add(double ms)
+    {
+        if (count < 8) t[count++] = ms;
+        else { int worst = 0; for (int i = 1; i < 8; ++i) if (t[i] > t[worst]) worst = i; if (ms < t[worst]) t[worst] = ms; }
+    }
+    double ms() const
+    {
+        if (count == 0) return 1e300;
+        double v[8];
+        for (int i = 0; i < count; ++i) v[i] = t[i];
+        for (int i = 1; i < count; ++i) { const double x = v[i]; int j = i - 1; while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; --j; } v[j + 1] = x; }
+        return 0.5 * (v[(count - 1) / 2] + v[count / 2]);
+    }
+};
+constexpr int kSequence = -1;              // the "number of pairs" that stands for the plain sequence (fit, then sweep)
+struct ScheduleEntry {
+    enum State { COLD, SEQUENCE, BASE, NEIGHBOURS, CLIMB, GROUPING, SETTLED };
+    State state = COLD;
+    int64_t n_pad = 0;
+    int all_pairs = 0, strips = 0;
+    int group = 0;                         // 0 = updates pair by pair, 2 = in groups of two pairs
+    int cur = kSequence;                   // pairs in force; 0 = overlapped with an empty pipeline; kSequence = the plain sequence
+    int probe = kSequence, probe_group = 0;   // what the next call runs (states BASE .. GROUPING)
+    int dir = 0, step = 0;
+    int up = kSequence, down = kSequence;  // NEIGHBOURS: the two candidates (== cur: none on that side)
+    int alt_group = 0, alt_pairs = 0;      // GROUPING: the candidate with the other grouping
+    int calls = 0;
+    int last_pairs = kSequence - 1, last_group = 0;   // the previous call's schedule (a call after a change is not sampled)
+    bool group_tried = false;
+    double fact_alone_us = 0.0, sweep_alone_us = 0.0;
+    std::map<std::pair<int, int>, ScheduleSample> samples;   // (group, pairs) -> fastest of its calls
+};
+
+typedef std::map<std::pair<int64_t, int64_t>, ScheduleEntry> ScheduleTable;   // (padded rows, padded candidates) ->
+
+struct ScheduleChoice { int pairs = kSequence, group = 0; bool sample = false; };
+constexpr double kScheduleGain = 0.003;    // a candidate replaces the current one when it is this much faster
+constexpr double kScheduleClose = 0.01;    // two candidates closer than this are sampled twice more before the decision
+constexpr int kScheduleMaxCalls = 96;      // exploration gives up (settles where it is) after this many calls of a shape
+
+static inline bool schedule_tune_enabled()
+{
+    static const bool on = [] { const char *e = std::getenv("CBO_HIP_SCHEDULE_TUNE"); return !(e && std::atoi(e) == 0); }();
+    return on;
+}
+static inline int schedule_unit(int group) { return group >= 2 ? group : 1; }
+// The candidates along the axis, in order: kSequence, 0 (overlapped, empty pipeline), the single pairs below the first
+// group, the multiples of the unit below all_pairs, all_pairs.
+static inline bool schedule_is_candidate(const ScheduleEntry &e, int group, int p)
+{
+    const int u = schedule_unit(group);
+    return p == kSequence || (p >= 0 && p <= e.all_pairs && (p < u || p % u == 0 || p == e.all_pairs));
+}
+// the nearest candidate at or beyond p in direction dir
+static inline int schedule_snap(const ScheduleEntry &e, int group, int p, int dir)
+{
+    if (p < 0) return kSequence;
+    if (p >= e.all_pairs) return e.all_pairs;
+    while (!schedule_is_candidate(e, group, p)) p += dir > 0 ? 1 : -1;
+    return p;
+}
+// `steps` candidates away from p (a candidate) in direction dir, clamped at the ends of the axis; a step down of more
+// than one candidate stops at the empty pipeline (the plain sequence is only ever reached from there)
+static inline int schedule_next(const ScheduleEntry &e, int group, int p, int dir, int steps)
+{
+    p = schedule_snap(e, group, p, -1);
+    for (int k = 0; k < steps; ++k) {
+        if (dir > 0) {
+            if (p >= e.all_pairs) break;
+            p = schedule_snap(e, group, p + 1, +1);
+        } else {
+            if (p == kSequence || (p == 0 && steps > 1)) break;
+            p = p == 0 ? kSequence : schedule_snap(e, group, p - 1, -1);
+        }
+    }
+    return p;
+}
+static inline std::pair<int, int> schedule_key(int group, int pairs) { return {pairs <= 0 ? 0 : group, pairs}; }   // (no updates: no grouping)
+static inline double schedule_ms(const ScheduleEntry &e, int group, int pairs)
+{
+    auto it = e.samples.find(schedule_key(group, pairs));
+    return (it == e.samples.end() || it->second.count < it->second.need) ? 1e300 : it->second.ms();
+}
+static inline void schedule_probe(ScheduleEntry &e, int group, int pairs) { e.probe = pairs; e.probe_group = pairs < 0 ? e.group : group; }
+// two measured candidates too close to call: both are sampled twice more (once), the caller comes back
+static inline bool schedule_close_call(ScheduleEntry &e, int ga, int pa, int gb, int pb)
+{
+    const double ta = schedule_ms(e, ga, pa), tb = schedule_ms(e, gb, pb);
+    if (ta > 1e299 || tb > 1e299 || std::fabs(ta - tb) > kScheduleClose * tb) return false;
+    ScheduleSample &sa = e.samples[schedule_key(ga, pa)], &sb = e.samples[schedule_key(gb, pb)];
+    if (sa.need >= 4 && sb.need >= 4) return false;
+    sa.need = 4; sb.need = 4;
+    if (sa.count < sa.need) schedule_probe(e, ga, pa); else schedule_probe(e, gb, pb);
+    return true;
+}
+// strip stages (32 rows of one 64-column strip) of the pipeline's first `pairs` pairs; the whole sweep has 2 nb (nb + 1)
+static inline double pipeline_stages(int nb, int pairs)
+{
+    double s = 0.0;
+    for (int p = 0; p < pairs; ++p) {
+        const int rows_below = nb - 2 * (p + 1);
+        s += 12.0 + 8.0 * (rows_below > 0 ? rows_below : 0);
+    }
+    return s;
+}
+static inline int schedule_first_split(int n_cu, int n_cu_pipe, const ScheduleEntry &e)
+{
+    const int nb = (int)(e.n_pad / 128);
+    if (e.strips < n_cu_pipe) return e.all_pairs;             // the strip kernel could not fill the device on its own
+    const double total = 2.0 * nb * (nb + 1);
+    int pairs = 0;
+    while (pairs < e.all_pairs) {
+        const double pipe_us = pipeline_stages(nb, pairs + 1) / total * e.sweep_alone_us * (double)n_cu / n_cu_pipe;
+        if (pipe_us > e.fact_alone_us) break;
+        ++pairs;
+    }
+    return pairs;
+}
+static inline ScheduleEntry &schedule_entry(ScheduleTable &table, int n_cu_pipe, int64_t n_pad, int64_t strips, int64_t m_pad)
+{
+    auto key = std::make_pair(n_pad, m_pad);
+    auto it = table.find(key);
+    if (it != table.end()) return it->second;
+    ScheduleEntry e;
+    const int nb = (int)(n_pad / 128);
+    e.n_pad = n_pad;
+    e.all_pairs = (nb + 1) / 2;
+    e.strips = (int)strips;
+    // (a full round of strips: the bulk stream bounds the pipeline, its updates go in groups -- to begin with)
+    e.group = (e.strips >= n_cu_pipe && e.all_pairs >= 4) ? 2 : 0;
+    // a settled shape with the same candidates and a neighbouring row count: start from its split and grouping
+    const ScheduleEntry *seed = nullptr;
+    for (const auto &kv : table)
+        if (kv.first.second == m_pad && kv.second.state == ScheduleEntry::SETTLED &&
+            (!seed || std::llabs(kv.first.first - n_pad) < std::llabs(seed->n_pad - n_pad)))
+            seed = &kv.second;
+    if (seed && std::llabs(seed->n_pad - n_pad) <= 512 && seed->all_pairs > 0) {
+        e.group = seed->group;
+        e.cur = seed->cur <= 0 ? seed->cur
+                               : schedule_snap(e, e.group, (int)((double)seed->cur / seed->all_pairs * e.all_pairs + 0.5), -1);
+        e.fact_alone_us = seed->fact_alone_us; e.sweep_alone_us = seed->sweep_alone_us;
+        e.state = ScheduleEntry::BASE;
+        schedule_probe(e, e.group, e.cur);
+    }
+    return table.emplace(key, e).first->second;
+}
+
+// what this call runs
+static inline ScheduleChoice schedule_choose(ScheduleEntry &e, bool may_sample)
+{
+    ScheduleChoice ch;
+    const bool exploring = may_sample && e.state != ScheduleEntry::SETTLED;
+    if (e.state == ScheduleEntry::COLD || e.state == ScheduleEntry::SEQUENCE) { ch.pairs = kSequence; ch.group = e.group; }
+    else if (exploring) { ch.pairs = e.probe; ch.group = e.probe_group; }
+    else { ch.pairs = e.cur; ch.group = e.group; }
+    ch.sample = exploring;
+    return ch;
+}
+
+static inline void schedule_settle(ScheduleEntry &e) { e.state = ScheduleEntry::SETTLED; schedule_probe(e, e.group, e.cur); }
+
+// after the climb: the other grouping at the settled split, once
+static inline void schedule_try_grouping(ScheduleEntry &e)
+{
+    if (e.group_tried || e.all_pairs < 4 || e.cur < 2) { schedule_settle(e); return; }
+    e.group_tried = true;
+    const int other = e.group >= 2 ? 0 : 2;
+    const int at = schedule_snap(e, other, e.cur, -1);
+    if (at <= 0) { schedule_settle(e); return; }
+    e.alt_group = other; e.alt_pairs = at;
+    schedule_probe(e, other, at);
+    e.state = ScheduleEntry::GROUPING;
+}
+
+static inline void schedule_look_around(ScheduleEntry &e);
+// the climb: from cur in direction dir, `step` candidates at a time, doubling while it pays, single steps to finish
+static inline void schedule_climb(ScheduleEntry &e)
+{
+    e.state = ScheduleEntry::CLIMB;
+    for (int guard = 0; guard < 64; ++guard) {
+        const int cand = schedule_next(e, e.group, e.cur, e.dir, e.step);
+        if (cand == e.cur) {
+            if (e.step > 1) { e.step = 1; continue; }
+            schedule_look_around(e);
+            return;
+        }
+        const double t = schedule_ms(e, e.group, cand);
+        if (t > 1e299) { schedule_probe(e, e.group, cand); return; }
+        if (schedule_ms(e, e.group, e.cur) > 1e299) { schedule_probe(e, e.group, e.cur); return; }
+        if (schedule_close_call(e, e.group, cand, e.group, e.cur)) return;
+        if (t < schedule_ms(e, e.group, e.cur) * (1.0 - kScheduleGain)) { e.cur = cand; e.step *= 2; }
+        else if (e.step > 1) e.step = 1;
+        else { schedule_look_around(e); return; }
+    }
+    schedule_settle(e);
+}
+
+// cur and its two neighbours: stay (then the other grouping), or set off in the better direction
+static inline void schedule_neighbours(ScheduleEntry &e)
+{
+    e.state = ScheduleEntry::NEIGHBOURS;
+    if (schedule_ms(e, e.group, e.cur) > 1e299) { schedule_probe(e, e.group, e.cur); return; }
+    if (e.up != e.cur && schedule_ms(e, e.group, e.up) > 1e299) { schedule_probe(e, e.group, e.up); return; }
+    if (e.down != e.cur && schedule_ms(e, e.group, e.down) > 1e299) { schedule_probe(e, e.group, e.down); return; }
+    const double tu = e.up != e.cur ? schedule_ms(e, e.group, e.up) : 1e300;
+    const double td = e.down != e.cur ? schedule_ms(e, e.group, e.down) : 1e300;
+    const int best = tu < td ? e.up : e.down;
+    if (best == e.cur) { schedule_settle(e); return; }                       // (a one-candidate axis)
+    if (schedule_close_call(e, e.group, best, e.group, e.cur)) return;
+    if (!((tu < td ? tu : td) < schedule_ms(e, e.group, e.cur) * (1.0 - kScheduleGain))) { schedule_try_grouping(e); return; }
+    e.dir = tu < td ? +1 : -1;
+    e.cur = best;
+    e.step = 2;
+    schedule_climb(e);
+}
+
+// the climb has ended: a doubled step may have carried it across the best candidate -- both neighbours of where it
+// stands once more (every move is to a strictly faster candidate: this ends)
+static inline void schedule_look_around(ScheduleEntry &e)
+{
+    e.up = schedule_next(e, e.group, e.cur, +1, 1);
+    e.down = schedule_next(e, e.group, e.cur, -1, 1);
+    schedule_neighbours(e);
+}
+
+// a call has ended: its time, and (the plain sequence) the times of its halves
+static inline void schedule_report(int n_cu, int n_cu_pipe, ScheduleEntry &e, const ScheduleChoice &ch, bool valid, double ms,
+                            double fact_us, double sweep_us)
+{
+    if (!ch.sample) { e.last_pairs = kSequence - 1; return; }    // (an unsampled call in between: the next one is a change)
+    ++e.calls;
+    const bool changed = ch.pairs != e.last_pairs || (ch.pairs > 0 && ch.group != e.last_group);
+    e.last_pairs = ch.pairs; e.last_group = ch.group;
+    if (e.state == ScheduleEntry::COLD) { e.state = ScheduleEntry::SEQUENCE; return; }   // (allocations, code loading)
+    if (e.calls > kScheduleMaxCalls) { schedule_settle(e); return; }
+    if (changed || !valid) return;         // the first call of a schedule pays for the change; a jitter retry is not its time
+    ScheduleSample &sm = e.samples[schedule_key(ch.group, ch.pairs)];
+    sm.add(ms);
+    if (ch.pairs == kSequence && fact_us > 0.0) {
+        if (e.fact_alone_us == 0.0 || fact_us < e.fact_alone_us) e.fact_alone_us = fact_us;
+        if (e.sweep_alone_us == 0.0 || sweep_us < e.sweep_alone_us) e.sweep_alone_us = sweep_us;
+    }
+    if (sm.count < sm.need) return;                              // the same candidate once more
+    switch (e.state) {
+        case ScheduleEntry::SEQUENCE:
+            e.cur = schedule_snap(e, e.group, schedule_first_split(n_cu, n_cu_pipe, e), -1);
+            if (!schedule_tune_enabled()) { schedule_settle(e); return; }
+            e.state = ScheduleEntry::BASE;
+            schedule_probe(e, e.group, e.cur);
+            return;
+        case ScheduleEntry::BASE:
+            if (!schedule_tune_enabled()) { schedule_settle(e); return; }
+            e.up = schedule_next(e, e.group, e.cur, +1, 1);
+            e.down = schedule_next(e, e.group, e.cur, -1, 1);
+            schedule_neighbours(e);
+            return;
+        case ScheduleEntry::NEIGHBOURS:
+            schedule_neighbours(e);
+            return;
+        case ScheduleEntry::CLIMB:
+            schedule_climb(e);
+            return;
+        case ScheduleEntry::GROUPING:
+            if (schedule_ms(e, e.alt_group, e.alt_pairs) > 1e299) { schedule_probe(e, e.alt_group, e.alt_pairs); return; }
+            if (schedule_ms(e, e.group, e.cur) > 1e299) { schedule_probe(e, e.group, e.cur); return; }
+            if (schedule_close_call(e, e.alt_group, e.alt_pairs, e.group, e.cur)) return;
+            if (schedule_ms(e, e.alt_group, e.alt_pairs) < schedule_ms(e, e.group, e.cur) * (1.0 - kScheduleGain)) {
+                e.group = e.alt_group;                           // adopted: its neighbours once more
+                e.cur = e.alt_pairs;
+                e.up = schedule_next(e, e.group, e.cur, +1, 1);
+                e.down = schedule_next(e, e.group, e.cur, -1, 1);
+                schedule_neighbours(e);
+                return;
+            }
+            schedule_settle(e);
+            return;
+        default: return;
+    }
+}
+

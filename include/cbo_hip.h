@@ -26,7 +26,7 @@ extern "C" {
  * cbo_abi_version() returns this value from a product build.  Timing-only builds (CBO_DIAG_KNOBS, or a non-zero
  * F32_DBG mask, whose results may be wrong by construction) return CBO_HIP_ABI_DIAG_BASE + this value, so that a
  * consumer checking the version refuses them as the product. */
-#define CBO_HIP_ABI_VERSION 3
+#define CBO_HIP_ABI_VERSION 4
 #define CBO_HIP_ABI_DIAG_BASE 1000
 #define CBO_MAX_DIM 8
 
@@ -240,6 +240,15 @@ int cbo_gp_fit_sweep(cbo_gp *gp, cbo_cands *cands, double y_best, int task, doub
  * Same numbers as the per-set calls (same device functions, same summation orders).  All pairs on one context. */
 int cbo_acq_sweep_sets(int n_sets, cbo_gp *const *gps, cbo_cands *const *cands, const double *y_best, int task,
                        double ei_jitter, const double *costs, double *best_vals, int64_t *best_idxs);
+
+/* The schedule of cbo_gp_fit_sweep is measured, not tabulated: per shape (padded rows, padded candidates) the context
+ * times the calls it is given anyway -- the plain sequence first (factorisation alone, sweep alone), then neighbouring
+ * splits of the sweep between the pipeline under the factorisation and the closing launch -- and keeps the fastest
+ * (cbo_api.hip, schedule_choose / schedule_report; results are the same bits whatever the schedule).  This call writes
+ * what was measured and chosen, one text line per shape, into buf (NUL-terminated, truncated to cap; buf may be NULL)
+ * and returns the number of shapes still exploring (0 = all settled), or a negated CBO_ERR_* code.
+ * No reference counterpart: the reference's loop (src/CBO.py:143-173) has no device schedule to choose. */
+int cbo_schedule_report(cbo_ctx *ctx, char *buf, int64_t cap);
 
 /* One whole trial of the reference's loop in one call -- what CBO.intervene() (src/CBO.py:143-173) does between two
  * observations, for callers whose models are small enough that three calls' worth of host glue would cost as much as

@@ -1,0 +1,58 @@
+// Drives cbo_with_oop_amd/csrc/schedule_tuner.h against a simulated device: a step-time curve over the candidates (the
+// plain sequence, the empty pipeline, pairs), multiplicative noise, a penalty on the call after a change of schedule.
+// usage: schedule_tuner_sim n_pad m_pad n_cu n_cu_pipe curve noise seed      (tests/test_host_logic.py)
+// prints: "<calls> <pairs> <group> <settled 0/1> <ms of the choice> <ms of the best candidate>"
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include "schedule_tuner.h"
+
+static double step_ms(int curve, const ScheduleEntry &e, int group, int pairs)
+{
+    const double P = e.all_pairs;
+    const double g = (pairs > 0 && group >= 2) ? 0.99 : 1.0;              // grouped updates: 1 % faster
+    switch (curve) {
+        case 0: {                                                        // a valley at a quarter of the pairs
+            if (pairs < 0) return 6.5;
+            const double x = pairs / P - 0.25;
+            return (5.4 + 8.0 * x * x) * g;
+        }
+        case 1: return pairs < 0 ? 20.3 : (19.9 + 0.8 * pairs) * g;       // the empty pipeline is best
+        case 2: return pairs < 0 ? 12.2 : (22.7 - 12.9 * pairs / P) * g;  // everything pipelined is best, the sequence second
+        case 3: return pairs < 0 ? 100.0 : (101.0 + 0.5 * pairs) * g;     // the plain sequence is best
+        default: {                                                       // flat with a far valley (at 3/8)
+            if (pairs < 0) return 24.6;
+            const double x = pairs / P - 0.375;
+            return (22.5 + 30.0 * x * x) * g;
+        }
+    }
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 8) return 2;
+    const int64_t n_pad = std::atoll(argv[1]), m_pad = std::atoll(argv[2]);
+    const int n_cu = std::atoi(argv[3]), n_cu_pipe = std::atoi(argv[4]), curve = std::atoi(argv[5]);
+    const double noise = std::atof(argv[6]);
+    std::mt19937_64 rng((unsigned long long)std::atoll(argv[7]));
+    std::uniform_real_distribution<double> u(0.0, 1.0);
+    ScheduleTable table;
+    ScheduleEntry &e = schedule_entry(table, n_cu_pipe, n_pad, m_pad / 64, m_pad);
+    int calls = 0, last_p = -99, last_g = -99;
+    while (e.state != ScheduleEntry::SETTLED && calls < 400) {
+        const ScheduleChoice ch = schedule_choose(e, true);
+        double ms = step_ms(curve, e, ch.group, ch.pairs) * (1.0 + noise * u(rng));
+        if (ch.pairs != last_p || ch.group != last_g) ms *= 1.05;        // the call after a change pays for it
+        if (calls == 0) ms *= 3.0;                                       // cold
+        last_p = ch.pairs; last_g = ch.group;
+        schedule_report(n_cu, n_cu_pipe, e, ch, true, ms, ch.pairs < 0 ? 1700.0 : 0.0, ch.pairs < 0 ? 5100.0 : 0.0);
+        ++calls;
+    }
+    double best = 1e300;
+    for (int grp = 0; grp <= 2; grp += 2)
+        for (int p = -1; p <= e.all_pairs; ++p)
+            if (schedule_is_candidate(e, grp, p)) { const double t = step_ms(curve, e, grp, p); if (t < best) best = t; }
+    std::printf("%d %d %d %d %.4f %.4f\n", calls, e.cur, e.group, e.state == ScheduleEntry::SETTLED ? 1 : 0,
+                step_ms(curve, e, e.group, e.cur), best);
+    return 0;
+}

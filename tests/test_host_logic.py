@@ -213,3 +213,26 @@ def test_bench_launcher_reports_the_worst_exit_code_of_its_ranks():
     out = _run_bench(["--gpus", "2", "--config", "c3", "--steps", "1"], {"CBO_HIP_LIB": "/nonexistent/libcbo_hip.so"})
     assert out.returncode != 0
     assert "libcbo_hip.so not found" in out.stderr and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_schedule_tuner_settles_near_the_best_candidate_on_a_simulated_device(tmp_path):
+    """cbo_gp_fit_sweep chooses its schedule by timing the caller's own calls (csrc/schedule_tuner.h: host logic, no HIP).
+    Against simulated devices -- step-time curves with the valley at a quarter of the pairs, at three eighths, at the
+    empty pipeline, at the plain sequence, at everything pipelined; 1 % noise; a penalty on the call after a change --
+    it settles within its call budget and within 1.6 % of the best candidate."""
+    import subprocess
+    exe = tmp_path / "schedule_tuner_sim"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "cbo_with_oop_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "support", "schedule_tuner_sim.cpp"), "-o", str(exe)])
+    shapes = [(4096, 16384), (8192, 16384), (2048, 262144), (8192, 4096), (16384, 16384), (512, 16384), (4096, 4096)]
+    for curve in range(5):
+        for n_pad, m_pad in shapes:
+            if curve == 2 and m_pad // 64 >= 224:
+                continue                  # (everything pipelined only wins when the strips cannot fill the device)
+            for seed in (1, 2, 3):
+                out = subprocess.check_output([str(exe), str(n_pad), str(m_pad), "256", "224", str(curve), "0.01", str(seed)],
+                                              text=True).split()
+                calls, pairs, group, settled = (int(t) for t in out[:4])
+                chosen, best = float(out[4]), float(out[5])
+                assert settled == 1 and calls <= 97, (curve, n_pad, m_pad, seed, out)
+                assert chosen <= best * 1.016, (curve, n_pad, m_pad, seed, out)

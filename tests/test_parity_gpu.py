@@ -1031,14 +1031,48 @@ h.update(np.ascontiguousarray(m.posterior_state()[0]).tobytes())
 print("DIGEST", h.hexdigest())
 """ % ROOT
     digests = {}
-    for name, env in (("auto", {}), ("pairs", {"CBO_HIP_PIPE_GROUP": "1"}), ("three", {"CBO_HIP_PIPE_GROUP": "3"}),
-                      ("four", {"CBO_HIP_PIPE_GROUP": "4"}), ("odd split", {"CBO_HIP_PIPE_TAIL": "0.6875"}),
+    for name, env in (("first call", {}), ("quarter", {"CBO_HIP_OVERLAP": "1"}), ("pairs", {"CBO_HIP_PIPE_GROUP": "1"}),
+                      ("three", {"CBO_HIP_PIPE_GROUP": "3"}), ("four", {"CBO_HIP_PIPE_GROUP": "4"}),
+                      ("odd split", {"CBO_HIP_PIPE_TAIL": "0.6875"}), ("all pipelined", {"CBO_HIP_PIPE_TAIL": "0"}),
                       ("two calls", {"CBO_HIP_OVERLAP": "0"})):
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env),
                              capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         digests[name] = [ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][-1]
     assert len(set(digests.values())) == 1, digests
+
+
+def test_measured_schedule_settles_and_every_call_on_the_way_gives_the_same_bits(hip, monkeypatch):
+    """cbo_gp_fit_sweep picks its schedule by timing the calls it is given (cbo_api.hip, schedule_choose): the plain
+    sequence first, then neighbouring splits between the pipeline and the closing launch, groupings included.  Whatever
+    it tries, the results are the same bits; it settles within its call budget and says what it chose."""
+    from cbo_with_oop_amd import CandidateGrid, CausalExpectedImprovement
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    for knob in ("CBO_HIP_OVERLAP", "CBO_HIP_PIPE_TAIL", "CBO_HIP_PIPE_GROUP", "CBO_HIP_SCHEDULE_TUNE"):
+        monkeypatch.delenv(knob, raising=False)
+    ctx = forced_context(monkeypatch)
+    rng = np.random.default_rng(5)
+    X = rng.uniform(-4, 4, (1500, 2)); y = np.sin(X.sum(1, keepdims=True)) + 0.05 * rng.standard_normal((1500, 1))
+    model = HipGaussianProcess(X, y, noise_var=1e-2, fit=False, context=ctx)
+    grid = CandidateGrid(rng.uniform(-4, 4, (16384, 2)), model, context=ctx)
+    ei = CausalExpectedImprovement(float(y.min()), "min", model)
+    first = ei.sweep(grid, refit=True)
+    states, calls = set(), 1
+    while True:
+        exploring, text = ctx.schedule_report()
+        assert "rows 1536 candidates 16384" in text
+        states.add(text.split(": ")[1].split(" ")[0])
+        if exploring == 0:
+            break
+        r = ei.sweep(grid, refit=True)
+        calls += 1
+        assert (r["best_val"], r["best_idx"]) == (first["best_val"], first["best_idx"])
+        assert calls <= 60, text
+    assert "settled" in states and len(states) >= 3, (states, text)
+    full = ei.sweep(grid, refit=True, want_acq=True, want_posterior=True)       # (outputs requested: not sampled)
+    mu, var = model.predict(grid.points[:64])
+    assert np.array_equal(np.ravel(full["mean"])[:64], mu[:, 0]) and full["best_idx"] == first["best_idx"]
+    grid.close(); model.close(); ctx.close()
 
 
 def test_schedule_selection(hip):
