@@ -43,6 +43,7 @@ import json
 import os
 import sys
 import time
+import warnings
 
 import numpy as np
 
@@ -338,6 +339,10 @@ def main():
                          "the full CPU fit)")
     ap.add_argument("--post-steps", type=int, default=3,
                     help="instrumented two-call steps after the timed region (phase timers, isolated kernel; 0 = skip)")
+    ap.add_argument("--ladder-over-ranks", action="store_true",
+                    help="walk jitchol's ladder with one level per rank (sharding.fit_over_ranks) instead of every rank "
+                         "walking all of it: the step is that fit, then cbo_acq_sweep.  Off by default: the factor "
+                         "hand-over (ncclSend / ncclRecv) has only ever run on one rank")
     ap.add_argument("--sequential", action="store_true",
                     help="refit, then sweep (two calls) instead of the one cbo_gp_fit_sweep call")
     args = ap.parse_args()
@@ -370,7 +375,7 @@ def main():
 
     from cbo_with_oop_amd import CandidateGrid, CausalExpectedImprovement, _lib
     from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
-    from cbo_with_oop_amd.sharding import Communicator, exchange_argmax, shard_bounds
+    from cbo_with_oop_amd.sharding import Communicator, exchange_argmax, fit_over_ranks, shard_bounds
 
     ctx = _lib.Context.get(local_rank % max(1, _lib.device_count()))
     lib = _lib.load()
@@ -388,7 +393,13 @@ def main():
     bv, bi = ctypes.c_double(), ctypes.c_int64()
 
     def step():
-        if args.sequential:
+        if args.ladder_over_ranks:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)       # ("Added jitter of ...": the ladder at work)
+                fit_over_ranks(model, comm)
+            _lib.check(lib.cbo_acq_sweep(model._handle, cands._handle, y_best, 0, 0.0, cost, None, None, None,
+                                         ctypes.byref(bv), ctypes.byref(bi)))
+        elif args.sequential:
             _lib.check(lib.cbo_gp_fit(model._handle, None, None))
             _lib.check(lib.cbo_acq_sweep(model._handle, cands._handle, y_best, 0, 0.0, cost, None, None, None,
                                          ctypes.byref(bv), ctypes.byref(bi)))
@@ -412,7 +423,7 @@ def main():
     # splits: cbo_api.hip, schedule_choose): those calls come before the warm-up, untimed and without the exchange (every
     # rank settles on its own)
     settling_calls = 0
-    if not args.sequential:
+    if not args.sequential and not args.ladder_over_ranks:
         _lib.check(lib.cbo_gp_fit_sweep(model._handle, cands._handle, y_best, 0, 0.0, cost, None, None, None,
                                         ctypes.byref(bv), ctypes.byref(bi), None, None))
         while ctx.schedule_report()[0] > 0 and settling_calls < 80:
@@ -467,7 +478,9 @@ def main():
         }
         exchange = (f"RCCL all-gather of (val, idx) over {world} rank(s), inside libcbo_hip.so" if comm is not None
                     else "none (single process)")
-        if args.sequential:
+        if args.ladder_over_ranks:
+            step_mode = "jitchol's ladder one level per rank (fit_over_ranks), then cbo_acq_sweep"
+        elif args.sequential:
             step_mode = "two calls, nothing overlapped"
         elif f32:
             step_mode = "cbo_gp_fit_sweep on an fp32 model: fp64 fit, one down-conversion of the factor, fp32 sweep"

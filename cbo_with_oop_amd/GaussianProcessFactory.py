@@ -113,6 +113,24 @@ class HipGaussianProcess:
         _lib.check(self._lib.cbo_gp_fit(self._handle, ctypes.byref(tries), ctypes.byref(jitter)))
         self._note_jitter(tries.value, jitter.value)
 
+    def fit_level(self, level):
+        """ONE level of jitchol's ladder (``cbo_gp_fit_level``; sharding.fit_over_ranks walks the ladder with one level
+        per rank): ``(outcome, jitter)``, outcome 1 = factored (the model is fitted with ``jitter_tries = level``), 0 =
+        not positive definite at this level, -1 = non-positive diagonal entries."""
+        status = ctypes.c_int(0)
+        jitter = ctypes.c_double(0.0)
+        _lib.check(self._lib.cbo_gp_fit_level(self._handle, int(level), ctypes.byref(status), ctypes.byref(jitter)))
+        if status.value == 1:
+            self._note_jitter(int(level), jitter.value)
+        return status.value, jitter.value
+
+    def adopted_factor(self, level):
+        """The factor at ``level`` has arrived from another rank (``cbo_comm_share_factor``): the host-side state follows."""
+        tries = ctypes.c_int(0)
+        jitter = ctypes.c_double(0.0)
+        _lib.check(self._lib.cbo_gp_jitter(self._handle, ctypes.byref(tries), ctypes.byref(jitter)))
+        self._note_jitter(tries.value, jitter.value)
+
     stale = False      # data uploaded, posterior not yet refitted (set_data(..., fit=False))
 
     @property

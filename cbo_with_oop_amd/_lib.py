@@ -116,6 +116,10 @@ SIGNATURES = {
                                         c_double_p, c_int64_p, c_int_p, c_double_p]),
     "cbo_acq_sweep_sets": (ctypes.c_int, [ctypes.c_int, c_void_pp, c_void_pp, c_double_p, ctypes.c_int, ctypes.c_double,
                                           c_double_p, c_double_p, c_int64_p]),
+    "cbo_gp_fit_level": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int_p, c_double_p]),
+    "cbo_comm_gather_i64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_int64_p]),
+    "cbo_comm_share_factor": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_int_p, ctypes.c_int,
+                                              c_int_p, ctypes.c_int]),
     "cbo_schedule_report": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
     "cbo_trial_step": (ctypes.c_int, [ctypes.c_int, c_void_pp, c_void_pp, ctypes.c_int, ctypes.c_int64, c_double_p, c_double_p,
                                       c_double_p, c_double_p, c_double_p, ctypes.c_int, ctypes.c_double, c_double_p, c_double_p,

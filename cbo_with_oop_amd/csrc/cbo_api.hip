@@ -732,23 +732,16 @@ static int next_jitter(cbo_gp *g, int *tries, double *jitter)
     return CBO_OK;
 }
 
-extern "C" int cbo_gp_fit(cbo_gp *g, int *tries_out, double *jitter_out)
+// one attempt at the factorisation with `jitter` on the diagonal: *pd says whether it went through
+static int attempt_factor(cbo_gp *g, double jitter, bool *pd)
 {
-    if (!g) return fail(CBO_ERR_INVALID, "gp is NULL");
-    if (g->n <= 0 || g->n_pad <= 0) return fail(CBO_ERR_INVALID, "gp holds no data (a previous upload failed)");
     cbo_ctx *c = g->ctx;
-    HIP_TRY(hipSetDevice(c->device));
-    g->fitted = false;
-    // GPy util.linalg.jitchol: plain attempt, then mean(diag)*1e-6 jitter, x10 per retry, <= 5 retries.
-    double jitter = 0.0;
-    int tries = 0;
     FusedFallback fallback;
     for (;;) {
         enqueue_factor(g, jitter);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(c->h_info, g->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (*c->h_info == 0) break;
         if (*c->h_info == kCholFusedTimeout) {
             // a strip of a fused diagonal + panel launch gave up waiting (see potrf_panel_fused_kernel): the same
             // attempt again with the separate-launch kernels -- same bits, no protocol between workgroups
@@ -757,9 +750,15 @@ extern "C" int cbo_gp_fit(cbo_gp *g, int *tries_out, double *jitter_out)
             fallback.engage(c);
             continue;
         }
-        const int rc = next_jitter(g, &tries, &jitter);
-        if (rc != CBO_OK) return rc;
+        *pd = *c->h_info == 0;
+        return CBO_OK;
     }
+}
+
+// the factor in g->A is the model's: what every consumer of a fitted model expects beside it
+static int adopt_factor(cbo_gp *g, int tries, double jitter)
+{
+    cbo_ctx *c = g->ctx;
     // contiguous z = L^-1 (y - m) for the sweep: the posterior mean is (L^-1 k*)^T z, so the backward
     // solve for alpha = L^-T z is not on the sweep's path and is materialised on first use (ensure_alpha)
     HIP_TRY(hipMemcpy2DAsync(g->z, sizeof(double), g->A + g->n_pad, sizeof(double) * g->lda, sizeof(double),
@@ -772,10 +771,91 @@ extern "C" int cbo_gp_fit(cbo_gp *g, int *tries_out, double *jitter_out)
     g->tries = tries;
     g->jitter = jitter;
     if (c->profiling) c->timers.n_fit += 1;
+    return CBO_OK;
+}
+
+extern "C" int cbo_gp_fit(cbo_gp *g, int *tries_out, double *jitter_out)
+{
+    if (!g) return fail(CBO_ERR_INVALID, "gp is NULL");
+    if (g->n <= 0 || g->n_pad <= 0) return fail(CBO_ERR_INVALID, "gp holds no data (a previous upload failed)");
+    cbo_ctx *c = g->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    g->fitted = false;
+    // GPy util.linalg.jitchol: plain attempt, then mean(diag)*1e-6 jitter, x10 per retry, <= 5 retries.
+    double jitter = 0.0;
+    int tries = 0;
+    for (;;) {
+        bool pd = false;
+        int rc = attempt_factor(g, jitter, &pd);
+        if (rc != CBO_OK) return rc;
+        if (pd) break;
+        rc = next_jitter(g, &tries, &jitter);
+        if (rc != CBO_OK) return rc;
+    }
+    const int rc = adopt_factor(g, tries, jitter);
+    if (rc != CBO_OK) return rc;
     if (tries_out) *tries_out = tries;
     if (jitter_out) *jitter_out = jitter;
     return CBO_OK;
 }
+
+// The jitter of level `level` of jitchol's ladder (0: none; k: mean(diag) * 1e-6 * 10^(k-1), by the same repeated
+// multiplication as the retries of cbo_gp_fit): CBO_ERR_NONPOS_DIAG / CBO_ERR_NOT_PD as the ladder reports them.
+static int ladder_jitter(cbo_gp *g, int level, double *jitter)
+{
+    *jitter = 0.0;
+    int tries = 0;
+    while (tries < level) {
+        const int rc = next_jitter(g, &tries, jitter);
+        if (rc != CBO_OK) return rc;
+    }
+    return CBO_OK;
+}
+
+// ONE level of the ladder, for ranks that walk it side by side (cbo_with_oop_amd/sharding.py, fit_over_ranks: with the
+// posterior replicated on G ranks, rank r tries level r while the others try theirs, instead of every rank trying them
+// all in turn).  *status: 1 = factored at this level (the model is fitted, tries = level), 0 = not positive definite at
+// this level, -1 = the diagonal has non-positive entries (jitchol gives up before its first retry: levels >= 1 only).
+// A level beyond jitchol's five retries is CBO_ERR_NOT_PD.
+extern "C" int cbo_gp_fit_level(cbo_gp *g, int level, int *status, double *jitter_out)
+{
+    if (!g || !status) return fail(CBO_ERR_INVALID, "NULL argument");
+    if (g->n <= 0 || g->n_pad <= 0) return fail(CBO_ERR_INVALID, "gp holds no data (a previous upload failed)");
+    if (level < 0) return fail(CBO_ERR_INVALID, "level must be >= 0");
+    cbo_ctx *c = g->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    g->fitted = false;
+    double jitter = 0.0;
+    int rc = ladder_jitter(g, level, &jitter);
+    if (rc == CBO_ERR_NONPOS_DIAG) { *status = -1; return CBO_OK; }
+    if (rc != CBO_OK) return rc;
+    bool pd = false;
+    rc = attempt_factor(g, jitter, &pd);
+    if (rc != CBO_OK) return rc;
+    *status = pd ? 1 : 0;
+    if (jitter_out) *jitter_out = jitter;
+    return pd ? adopt_factor(g, level, jitter) : CBO_OK;
+}
+
+// for cbo_comm_share_factor (cbo_comm.hip): where the factor lives, and its adoption by a rank that received it
+namespace cbo {
+int gp_factor_view(cbo_gp *g, double **A, int64_t *lda, int64_t *n_pad, double **invDt, cbo_ctx **ctx)
+{
+    if (!g) return fail(CBO_ERR_INVALID, "gp is NULL");
+    if (g->n <= 0 || g->n_pad <= 0) return fail(CBO_ERR_INVALID, "gp holds no data");
+    *A = g->A; *lda = g->lda; *n_pad = g->n_pad; *invDt = g->invDt; *ctx = g->ctx;
+    return CBO_OK;
+}
+bool gp_is_fitted_at(const cbo_gp *g, int level) { return g && g->fitted && g->tries == level; }
+int gp_adopt_received_factor(cbo_gp *g, int level)
+{
+    HIP_TRY(hipSetDevice(g->ctx->device));
+    double jitter = 0.0;
+    const int rc = ladder_jitter(g, level, &jitter);
+    if (rc != CBO_OK) return rc;
+    return adopt_factor(g, level, jitter);
+}
+}  // namespace cbo
 
 // GPy's woodbury_vector alpha = Ky^-1 (y - m) = L^-T z (dpotrs): needed by posterior export and by
 // prediction gradients, not by predict / the acquisition sweep.

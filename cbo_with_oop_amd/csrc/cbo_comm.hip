@@ -35,6 +35,8 @@ struct Rccl {
     int (*AllReduce)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;     // (looked up, not required:
+    int (*Recv)(void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;           //  cbo_comm_share_factor only)
     const char *(*GetErrorString)(int) = nullptr;
     std::string load_error;
 };
@@ -69,6 +71,8 @@ Rccl &rccl()
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(r.handle, "ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(r.handle, "ncclRecv"));
         if (!r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.AllReduce ||
             !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
             dlclose(r.handle);
@@ -308,4 +312,96 @@ extern "C" int cbo_comm_barrier(cbo_comm *m)
 {
     double dummy = 0.0;
     return cbo_comm_max_f64(m, 0.0, &dummy);
+}
+
+// One int64 from every rank, in rank order (the ladder's outcome flags, cbo_with_oop_amd/sharding.py fit_over_ranks).
+extern "C" int cbo_comm_gather_i64(cbo_comm *m, int64_t value, int64_t *out)
+{
+    if (!m || !out) return set_error(CBO_ERR_INVALID, "NULL argument");
+    hipError_t e = hipSetDevice(ctx_device(m->ctx));
+    if (e != hipSuccess) return hip_fail("hipSetDevice", e);
+    m->h_send[0] = value;
+    e = hipMemcpyAsync(m->d_send, m->h_send, sizeof(int64_t), hipMemcpyHostToDevice, m->stream);
+    if (e != hipSuccess) return hip_fail("gather upload", e);
+    const int n = rccl().AllGather(m->d_send, m->d_recv, 1, kNcclInt64, m->comm, m->stream);
+    if (n != 0) return comm_fail("ncclAllGather", n);
+    e = hipMemcpyAsync(m->h_recv, m->d_recv, sizeof(int64_t) * (size_t)m->world, hipMemcpyDeviceToHost, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    if (e != hipSuccess) return hip_fail("gather download", e);
+    for (int r = 0; r < m->world; ++r) out[r] = m->h_recv[r];
+    return CBO_OK;
+}
+
+// The rows [begin, end) of the factor that owner number i of n sends (multiples of 128 rows, the first slices one block
+// longer when the blocks do not divide).
+static void factor_slice(int64_t n_pad, int n, int i, int64_t *begin, int64_t *end)
+{
+    const int64_t blocks = n_pad / 128, base = blocks / n, extra = blocks % n;
+    const int64_t b0 = (int64_t)i * base + (i < extra ? i : extra);
+    *begin = 128 * b0;
+    *end = 128 * (b0 + base + (i < extra ? 1 : 0));
+}
+
+// The ranks of `owners` hold model g's factor at `level` of the jitchol ladder (each fitted it itself: the posterior
+// is replicated); the ranks of `needers` do not (they tried a level that failed).  Every needer receives the factor in
+// |owners| row slices, one from each owner -- over xGMI that is |owners| links side by side -- and adopts it (fitted,
+// tries = level).  Called by every rank of the communicator with the same lists; a rank in neither list does nothing.
+// Rows travel whole (the upper triangle, the unused lower part, the right-hand-side column: lda doubles), with the
+// 16x16 diagonal inverses of the same rows.
+extern "C" int cbo_comm_share_factor(cbo_comm *m, cbo_gp *g, int level, const int *owners, int n_owners,
+                                     const int *needers, int n_needers)
+{
+    if (!m || !g || !owners || n_owners <= 0 || (n_needers > 0 && !needers))
+        return set_error(CBO_ERR_INVALID, "bad argument");
+    double *A = nullptr, *invDt = nullptr;
+    int64_t lda = 0, n_pad = 0;
+    cbo_ctx *ctx = nullptr;
+    int rc = gp_factor_view(g, &A, &lda, &n_pad, &invDt, &ctx);
+    if (rc != CBO_OK) return rc;
+    if (ctx != m->ctx) return set_error(CBO_ERR_INVALID, "the model lives on another context than the communicator");
+    int my_owner = -1;
+    bool i_need = false;
+    for (int i = 0; i < n_owners; ++i) {
+        if (owners[i] < 0 || owners[i] >= m->world) return set_error(CBO_ERR_INVALID, "owner rank out of range");
+        if (owners[i] == m->rank) my_owner = i;
+    }
+    for (int i = 0; i < n_needers; ++i) {
+        if (needers[i] < 0 || needers[i] >= m->world) return set_error(CBO_ERR_INVALID, "needer rank out of range");
+        if (needers[i] == m->rank) i_need = true;
+    }
+    if (my_owner >= 0 && i_need) return set_error(CBO_ERR_INVALID, "a rank cannot both hold and need the factor");
+    if (my_owner >= 0 && !gp_is_fitted_at(g, level))
+        return set_error(CBO_ERR_INVALID, "this rank is listed as an owner but does not hold the factor at that level");
+    if (n_needers == 0 || (my_owner < 0 && !i_need)) return CBO_OK;
+    rc = need_rccl();
+    if (rc != CBO_OK) return rc;
+    if (!rccl().Send || !rccl().Recv) return set_error(CBO_ERR_COMM, "this RCCL has no ncclSend / ncclRecv");
+    hipError_t e = hipSetDevice(ctx_device(m->ctx));
+    // the model's own stream has produced (owner) or will consume (needer) the factor: order the exchange behind it
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx_stream(m->ctx));
+    if (e != hipSuccess) return hip_fail("share_factor: stream", e);
+    int n = rccl().GroupStart();
+    if (n != 0) return comm_fail("ncclGroupStart", n);
+    for (int i = 0; i < n_owners && n == 0; ++i) {
+        int64_t r0 = 0, r1 = 0;
+        factor_slice(n_pad, n_owners, i, &r0, &r1);
+        if (r1 <= r0) continue;
+        double *rows = A + r0 * lda, *inv = invDt + (r0 / 16) * 256;
+        const size_t n_rows = (size_t)((r1 - r0) * lda), n_inv = (size_t)((r1 - r0) / 16 * 256);
+        if (i == my_owner) {
+            for (int k = 0; k < n_needers && n == 0; ++k) {
+                n = rccl().Send(rows, n_rows, kNcclFloat64, needers[k], m->comm, m->stream);
+                if (n == 0) n = rccl().Send(inv, n_inv, kNcclFloat64, needers[k], m->comm, m->stream);
+            }
+        } else if (i_need) {
+            n = rccl().Recv(rows, n_rows, kNcclFloat64, owners[i], m->comm, m->stream);
+            if (n == 0) n = rccl().Recv(inv, n_inv, kNcclFloat64, owners[i], m->comm, m->stream);
+        }
+    }
+    const int ge = rccl().GroupEnd();
+    if (n != 0) return comm_fail("ncclSend / ncclRecv", n);
+    if (ge != 0) return comm_fail("ncclGroupEnd", ge);
+    e = hipStreamSynchronize(m->stream);
+    if (e != hipSuccess) return hip_fail("share_factor: wait", e);
+    return i_need ? gp_adopt_received_factor(g, level) : CBO_OK;
 }

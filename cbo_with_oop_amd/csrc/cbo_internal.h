@@ -54,6 +54,11 @@ inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 int set_error(int code, const std::string &msg);          // records the message for cbo_last_error(), returns code
 hipStream_t ctx_stream(cbo_ctx *c);
 int ctx_device(cbo_ctx *c);
+// the factor of a model for cbo_comm_share_factor: where it lives; whether this rank holds it at `level` of the ladder;
+// its adoption by a rank that has received it
+int gp_factor_view(cbo_gp *g, double **A, int64_t *lda, int64_t *n_pad, double **invDt, cbo_ctx **ctx);
+bool gp_is_fitted_at(const cbo_gp *g, int level);
+int gp_adopt_received_factor(cbo_gp *g, int level);
 
 // GPy constants (GPy 1.10.0 exact_gaussian_inference.py / posterior.py); see oracle/gp_oracle.py.
 constexpr double kGpyDiagJitter = 1e-8;

@@ -157,6 +157,22 @@ class Communicator:
     def barrier(self):
         _lib.check(self._lib.cbo_comm_barrier(self._handle))
 
+    def gather(self, value):
+        """One integer from every rank, in rank order (``cbo_comm_gather_i64``)."""
+        out = (ctypes.c_int64 * self.world)()
+        _lib.check(self._lib.cbo_comm_gather_i64(self._handle, int(value), out))
+        return list(out)
+
+    def share_factor(self, model, level, owners, needers):
+        """The ranks of ``needers`` receive ``model``'s factor at ``level`` of the jitchol ladder from the ranks of
+        ``owners``, one row slice from each (``cbo_comm_share_factor``); every rank calls this with the same lists."""
+        own = (ctypes.c_int * max(1, len(owners)))(*owners)
+        need = (ctypes.c_int * max(1, len(needers)))(*needers)
+        _lib.check(self._lib.cbo_comm_share_factor(self._handle, model._handle, int(level), own, len(owners), need,
+                                                   len(needers)))
+        if self.rank in needers:
+            model.adopted_factor(level)
+
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:
             if not self._ctx.closed:
@@ -198,3 +214,86 @@ def sharded_sweep(local_sweep, m_total, world_size, rank, exchange=exchange_argm
     else:
         val, idx = -np.inf, NO_CANDIDATE
     return exchange(val, idx)
+
+
+# ---- jitchol's ladder walked by the ranks side by side --------------------------------------------------------------
+# GPy's util.linalg.jitchol (behind GPRegression, /root/reference/src/GaussianProcessFactory.py:57-73) tries the plain
+# factorisation, then mean(diag) * 1e-6 of jitter, x10 per retry, five retries at most, and keeps the FIRST level that
+# goes through.  With the posterior replicated on G ranks (configs 3-5: candidate shards, one model) every rank repeats
+# that walk: at config 4 a 26 ms attempt that fails, then the 31 ms one that succeeds, on all eight GPUs -- time that
+# does not shrink with G.  Side by side instead: every level below the one expected to succeed gets ONE rank (a
+# verifier: the sequential walk's answer needs those levels to have failed), every other rank tries the expected level
+# (replicas: no transfer needed among them); one small all-gather of the outcomes later every rank knows the lowest
+# level that went through -- the sequential walk's answer, exactly -- and the verifiers receive the factor from the
+# replicas, one row slice from each (|replicas| xGMI links at once).  The expected level is the one the model's last fit
+# needed.  When the expectation is wrong the protocol still ends with the sequential answer: a verifier's level went
+# through (it is the lowest: everybody else receives from it), or nothing did (the next round starts above the levels
+# tried).  One rank: the sequential walk.
+LADDER_LAST_LEVEL = 5          # jitchol: the plain attempt (level 0) and five retries
+
+
+def ladder_plan(world, first_level, expected_level):
+    """Level every rank tries this round: the levels ``first_level .. expected_level - 1`` one verifier rank each, all
+    remaining ranks ``expected_level``; fewer ranks than that needs: consecutive levels from ``first_level``."""
+    expected_level = max(expected_level, first_level)
+    verifiers = expected_level - first_level
+    if world > verifiers:
+        return [first_level + r if r < verifiers else expected_level for r in range(world)]
+    return [first_level + r for r in range(world)]
+
+
+def ladder_resolve(levels, outcomes):
+    """From every rank's level and outcome (1 factored, 0 not positive definite, -1 non-positive diagonal, None: level
+    beyond the ladder, not tried): ``(level, owners, needers, next_first_level)`` -- the lowest level that went through
+    with the ranks that hold / lack its factor, or ``level`` None and where the next round starts.  The levels of a
+    round are consecutive from its first (``ladder_plan``), so the lowest success is the sequential walk's answer.
+    Raises ``numpy.linalg.LinAlgError`` as jitchol does (on every rank alike)."""
+    good = sorted({lv for lv, ok in zip(levels, outcomes) if ok == 1})
+    if good:
+        level = good[0]
+        owners = [r for r, lv in enumerate(levels) if lv == level]
+        if any(outcomes[r] != 1 for r in owners):
+            raise RuntimeError(f"ranks that tried level {level} disagree: {[outcomes[r] for r in owners]}")
+        return level, owners, [r for r, lv in enumerate(levels) if lv != level], None
+    if any(ok == -1 for ok in outcomes):
+        raise np.linalg.LinAlgError("not pd: non-positive diagonal elements")
+    nxt = max(levels) + 1
+    if nxt > LADDER_LAST_LEVEL:
+        raise np.linalg.LinAlgError("not positive definite, even with jitter.")
+    return None, [], [], nxt
+
+
+def fit_over_ranks(model, comm=None, expected_level=None):
+    """Fit ``model`` (replicated on every rank of ``comm``) with jitchol's ladder walked side by side; returns
+    ``(level, jitter)`` -- what ``model.jitter_tries, model.jitter`` are after a plain fit.  ``comm`` needs ``world``,
+    ``rank``, ``gather(int) -> list`` and ``share_factor(model, level, owners, needers)`` (sharding.Communicator over
+    RCCL; the tests drive the same code over threads and over gloo); ``model`` needs ``fit_level(level) -> (outcome,
+    jitter)`` and ``adopted_factor(level)`` (HipGaussianProcess)."""
+    world, rank = (comm.world, comm.rank) if comm is not None else (1, 0)
+    first = 0
+    expected = int(getattr(model, "jitter_tries", 0) or 0) if expected_level is None else int(expected_level)
+    while True:
+        levels = ladder_plan(world, first, min(expected, LADDER_LAST_LEVEL))
+        mine = levels[rank]
+        outcome, jitter = (None, 0.0) if mine > LADDER_LAST_LEVEL else model.fit_level(mine)
+        outcomes = comm.gather(-2 if outcome is None else outcome) if comm is not None else [outcome]
+        outcomes = [None if o == -2 else o for o in outcomes]
+        level, owners, needers, first = ladder_resolve(levels, outcomes)
+        if level is not None:
+            if needers:
+                comm.share_factor(model, level, owners, needers)
+            return level, model.jitter
+        expected = first
+
+
+def factor_slices(n_pad, n_owners):
+    """Rows ``[begin, end)`` of the factor that owner number i sends (``cbo_comm_share_factor``'s split: whole 128-row
+    blocks, the first slices one block longer when the blocks do not divide)."""
+    blocks = n_pad // 128
+    base, extra = divmod(blocks, n_owners)
+    out, b0 = [], 0
+    for i in range(n_owners):
+        b1 = b0 + base + (1 if i < extra else 0)
+        out.append((128 * b0, 128 * b1))
+        b0 = b1
+    return out

@@ -250,6 +250,23 @@ int cbo_acq_sweep_sets(int n_sets, cbo_gp *const *gps, cbo_cands *const *cands, 
  * No reference counterpart: the reference's loop (src/CBO.py:143-173) has no device schedule to choose. */
 int cbo_schedule_report(cbo_ctx *ctx, char *buf, int64_t cap);
 
+/* jitchol's ladder walked by the ranks of a communicator side by side (cbo_with_oop_amd/sharding.py, fit_over_ranks).
+ * GPy's util.linalg.jitchol (reached from src/GaussianProcessFactory.py:57-73 through GPRegression) tries the plain
+ * factorisation, then mean(diag)*1e-6 of jitter, x10 per retry, five retries at most, and keeps the FIRST level that
+ * goes through.  With the posterior replicated on G ranks every rank repeats that walk (at config 4: a failed 26 ms
+ * attempt, then the 31 ms one, on all eight GPUs).  Instead rank r tries ONE level: the levels below the one expected
+ * to succeed get one rank each, all other ranks try the expected level; one small all-gather later every rank knows
+ * the lowest level that went through -- the same answer as the sequential walk -- and the ranks that tried a failing
+ * level receive the factor from the ones that hold it.
+ *   cbo_gp_fit_level: one level (0 = plain, k = the k-th retry's jitter).  *status = 1: factored, the model is fitted
+ *     with tries = level; 0: not positive definite at this level; -1: non-positive diagonal entries (jitchol's
+ *     "not pd: non-positive diagonal elements", raised before its first retry).  level > 5: CBO_ERR_NOT_PD.
+ *   cbo_comm_gather_i64: one integer from every rank, in rank order (out[world]).
+ *   cbo_comm_share_factor: called by every rank with the same lists; the needers receive the factor at `level` in
+ *     |owners| row slices, one from each owner (ncclSend / ncclRecv in one group), and adopt it. */
+int cbo_gp_fit_level(cbo_gp *gp, int level, int *status, double *jitter_out);
+/* (cbo_comm_gather_i64 and cbo_comm_share_factor are declared with the communicator, below) */
+
 /* One whole trial of the reference's loop in one call -- what CBO.intervene() (src/CBO.py:143-173) does between two
  * observations, for callers whose models are small enough that three calls' worth of host glue would cost as much as
  * the device work: (1) the model of the set intervened on last takes its new data, as src/CBO.py:224-235
@@ -303,6 +320,10 @@ int cbo_comm_argmax_all(int n, cbo_comm *const *comms, const double *vals, const
 /* max over the ranks of one double (the slowest rank's time of a benchmark); doubles as a barrier */
 int cbo_comm_max_f64(cbo_comm *comm, double value, double *max_out);
 int cbo_comm_barrier(cbo_comm *comm);
+/* the ladder walked side by side: see cbo_gp_fit_level above */
+int cbo_comm_gather_i64(cbo_comm *comm, int64_t value, int64_t *out);
+int cbo_comm_share_factor(cbo_comm *comm, cbo_gp *gp, int level, const int *owners, int n_owners,
+                          const int *needers, int n_needers);
 
 /* ---- Monte-Carlo interventional target -----------------------------------------
  * Replaces compute_interventions (src/utils_functions/graph_functions.py:48-77): the mean of the target node

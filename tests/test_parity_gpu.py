@@ -908,6 +908,55 @@ def test_bench_lines_of_the_other_configs_carry_the_contract(hip):
     assert 0.5 < c3["roofline"]["isolated"]["frac"] < 1.0
 
 
+def test_ladder_levels_one_at_a_time_equal_the_plain_fit(hip):
+    """cbo_gp_fit_level tries ONE level of jitchol's ladder (what a rank does when the ranks walk the ladder side by side,
+    sharding.fit_over_ranks): on the jitter fixture (duplicate rows, no noise) the levels below the one the plain fit
+    needs report "not positive definite", that level gives the plain fit's factor, jitter and posterior bit for bit, and
+    a level beyond the ladder is jitchol's error.  With one rank fit_over_ranks IS the sequential walk; the single-rank
+    communicator's gather and factor hand-over go through RCCL's entry points."""
+    import warnings
+    from cbo_with_oop_amd import _lib
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    from cbo_with_oop_amd.sharding import Communicator, fit_over_ranks
+    f = load_fixture("jitter_ladder")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        plain = HipGaussianProcess(f["X"], f["y"], noise_var=float(f["noise_var"]), variance=float(f["variance"]),
+                                   lengthscale=f["lengthscale_arg"])
+        need = plain.jitter_tries
+        assert need >= 1
+        ref = [np.array(a) for a in plain.posterior_state()]
+        lvl = HipGaussianProcess(f["X"], f["y"], noise_var=float(f["noise_var"]), variance=float(f["variance"]),
+                                 lengthscale=f["lengthscale_arg"], fit=False)
+        for level in range(need):
+            assert lvl.fit_level(level)[0] == 0
+        outcome, jitter = lvl.fit_level(need)
+        assert outcome == 1 and (lvl.jitter_tries, lvl.jitter) == (need, plain.jitter) and jitter == plain.jitter
+        for a, b in zip(lvl.posterior_state(), ref):
+            assert np.array_equal(np.array(a), b)
+        with pytest.raises(np.linalg.LinAlgError):
+            lvl.fit_level(6)
+        # one rank, no communicator: the sequential walk, whatever level is expected
+        for expected in (None, 0, need, 4):
+            walk = HipGaussianProcess(f["X"], f["y"], noise_var=float(f["noise_var"]), variance=float(f["variance"]),
+                                      lengthscale=f["lengthscale_arg"], fit=False)
+            assert fit_over_ranks(walk, None, expected) == (need, plain.jitter)
+            for a, b in zip(walk.posterior_state(), ref):
+                assert np.array_equal(np.array(a), b)
+            walk.close()
+        # the same through a one-rank RCCL communicator: the outcome travels through ncclAllGather, nobody lacks the factor
+        comm = Communicator.single(_lib.Context.get())
+        assert comm.gather(-7) == [-7]
+        walk = HipGaussianProcess(f["X"], f["y"], noise_var=float(f["noise_var"]), variance=float(f["variance"]),
+                                  lengthscale=f["lengthscale_arg"], fit=False)
+        assert fit_over_ranks(walk, comm, need) == (need, plain.jitter)
+        comm.share_factor(walk, need, [0], [])                       # nobody needs it: no transfer
+        with pytest.raises(_lib.CboHipError):
+            comm.share_factor(walk, need + 1, [0], [])               # an owner must hold the factor at that level
+        comm.close()
+        walk.close(); lvl.close(); plain.close()
+
+
 def test_communicator_through_the_c_abi(hip):
     """cbo_comm_* with one rank (all a one-GPU box can form): both ways of forming the communicator, the arg-max
     exchange, the max reduction, and the empty-shard sentinel."""

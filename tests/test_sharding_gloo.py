@@ -105,3 +105,73 @@ def test_a_failed_rank_wins_every_reduction_with_its_error_record():
     val, idx = reduce_pairs([0.3, float("nan"), 0.9], [5, ERROR_CANDIDATE, 77])
     assert idx == ERROR_CANDIDATE and np.isnan(val)
     assert ERROR_CANDIDATE != NO_CANDIDATE
+
+
+def _ladder_worker(rank, world, port, needs, expected, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from cbo_with_oop_amd.sharding import factor_slices, fit_over_ranks
+    from ladder_support import LadderModel
+    from test_ladder_ranks import matrix_needing
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class GlooComm:
+        """gather / share_factor of sharding.Communicator over gloo: an all-gather of one int64, and point-to-point
+        sends of the factor's row slices (cbo_comm_share_factor's split: one slice from every owner to every needer)."""
+        def __init__(self):
+            self.world, self.rank, self.received = world, rank, []
+
+        def gather(self, value):
+            out = torch.empty(world, dtype=torch.int64)
+            dist.all_gather_into_tensor(out, torch.tensor([int(value)], dtype=torch.int64))
+            return out.tolist()
+
+        def share_factor(self, model, level, owners, needers):
+            n = model.A.shape[0]
+            n_pad = -(-n // 128) * 128
+            slices = factor_slices(n_pad, len(owners))
+            if rank in owners:
+                r0, r1 = slices[owners.index(rank)]
+                block = torch.from_numpy(np.ascontiguousarray(model.L[r0:min(r1, n)]))
+                for dst in needers:
+                    if block.numel():
+                        dist.send(block, dst)
+            elif rank in needers:
+                L = np.zeros((n, n))
+                for (r0, r1), src in zip(slices, owners):
+                    block = torch.empty((max(0, min(r1, n) - r0), n), dtype=torch.float64)
+                    if block.numel():
+                        dist.recv(block, src)
+                        L[r0:min(r1, n)] = block.numpy()
+                        self.received.append(src)
+                model.L = L
+                model.adopted_factor(level)
+
+    comm = GlooComm()
+    model = LadderModel(matrix_needing(needs, seed=needs))
+    level, jitter = fit_over_ranks(model, comm, expected)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), L=model.L, level=level, jitter=jitter, tried=np.array(model.tried),
+             received=np.array(comm.received, dtype=np.int64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,needs,expected", [(2, 1, 1), (2, 2, None), (3, 1, 1), (3, 1, 2)])
+def test_ladder_walked_by_gloo_ranks_equals_the_sequential_walk(tmp_path, world, needs, expected):
+    """sharding.fit_over_ranks over real processes (gloo): every rank ends with the oracle's jitchol result; when the
+    expected level holds, rank 0 only tries the plain factorisation and receives the factor from the other ranks."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import gp_oracle as O
+    from test_ladder_ranks import matrix_needing
+    mp.spawn(_ladder_worker, args=(world, _free_port(), needs, expected, str(tmp_path)), nprocs=world, join=True)
+    L_ref, jit_ref, tries_ref = O.jitchol(matrix_needing(needs, seed=needs))
+    res = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    for r in res:
+        assert int(r["level"]) == tries_ref and float(r["jitter"]) == jit_ref
+        assert np.array_equal(r["L"], L_ref)
+    if expected == needs and world > needs:
+        assert res[0]["tried"].tolist() == [0] and sorted(res[0]["received"].tolist()) == list(range(needs, world))
+        assert all(r["tried"].tolist() == [needs] for r in res[needs:])
