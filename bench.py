@@ -170,7 +170,7 @@ def bench_small_sets(args):
     from cbo_with_oop_amd.graphs import ToyGraph, meshgrid_candidates
     from cbo_with_oop_amd.sharding import Communicator
     ctx = _lib.Context.get(local_rank % max(1, _lib.device_count()))
-    comm = Communicator.from_env(ctx)
+    comm = quiet_communicator(Communicator, ctx)
     steps = args.steps or 2000
     rng = np.random.default_rng(0)
     es = ToyGraph.get_exploration_set("MIS")
@@ -252,6 +252,20 @@ def bench_small_sets(args):
     if comm is not None:
         comm.barrier()
         comm.close()
+
+
+def quiet_communicator(Communicator, ctx):
+    """Communicator.from_env with file descriptor 1 pointed at stderr meanwhile: RCCL greets with a version banner on
+    stdout when a communicator is formed, and stdout carries this program's one JSON line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        return Communicator.from_env(ctx)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def self_launch(n_ranks, argv=None, timeout_s=None):
@@ -381,7 +395,7 @@ def main():
     lib = _lib.load()
     # under a one-process-per-GPU launcher the communicator is always formed (also for one rank, so that the RCCL
     # exchange is exercised on a one-GPU box); a plain `python bench.py` has none
-    comm = Communicator.from_env(ctx)
+    comm = quiet_communicator(Communicator, ctx)
     X, y, Xs, grid, grid_note = make_problem(cfg, world, scaling, args.full_grid)
     n_obs = X.shape[0]
     per_gpu = cfg["grid"]

@@ -1583,7 +1583,7 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
         const clk::time_point t_sweep = clk::now();
         rc = cbo_acq_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
         if (rc == CBO_OK && entry)
-            schedule_report(c->n_cu, c->n_cu_pipe, *entry, choice, tries == 0, us_since(t_call) * 1e-3, fact_us, us_since(t_sweep));
+            schedule_report(c->n_cu, c->n_cu_pipe, *entry, choice, tries, us_since(t_call) * 1e-3, fact_us, us_since(t_sweep));
         return rc;
     }
     g->fitted = false;
@@ -1696,12 +1696,12 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
             HIP_TRY(hipStreamSynchronize(c->stream));
         }
         complete_finish(c, best_val, best_idx);
-        if (entry) schedule_report(c->n_cu, c->n_cu_pipe, *entry, choice, tries == 0 && !fallback.active(), us_since(t_call) * 1e-3, 0.0, 0.0);
+        if (entry) schedule_report(c->n_cu, c->n_cu_pipe, *entry, choice, fallback.active() ? -1 : tries, us_since(t_call) * 1e-3, 0.0, 0.0);
         return CBO_OK;
     }
     rc = finish_sweep(g, k, y_best, task, ei_jitter, cost, acq_out, mean_out, var_out, best_val, best_idx);
     if (rc == CBO_OK && entry)
-        schedule_report(c->n_cu, c->n_cu_pipe, *entry, choice, tries == 0 && !fallback.active(), us_since(t_call) * 1e-3, 0.0, 0.0);
+        schedule_report(c->n_cu, c->n_cu_pipe, *entry, choice, fallback.active() ? -1 : tries, us_since(t_call) * 1e-3, 0.0, 0.0);
     return rc;
 }
 

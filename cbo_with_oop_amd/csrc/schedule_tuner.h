@@ -61,7 +61,8 @@ struct ScheduleEntry {
     int alt_group = 0, alt_pairs = 0;      // GROUPING: the candidate with the other grouping
     int calls = 0;
     int last_pairs = kSequence - 1, last_group = 0;   // the previous call's schedule (a call after a change is not sampled)
-    bool group_tried = false;
+    bool group_tried = false, relooked = false;
+    int retries = -1;                      // jitter retries of the shape's calls (calls with another count are not sampled)
     double fact_alone_us = 0.0, sweep_alone_us = 0.0;
     std::map<std::pair<int, int>, ScheduleSample> samples;   // (group, pairs) -> fastest of its calls
 };
@@ -192,7 +193,30 @@ static inline ScheduleChoice schedule_choose(ScheduleEntry &e, bool may_sample)
     return ch;
 }
 
-static inline void schedule_settle(ScheduleEntry &e) { e.state = ScheduleEntry::SETTLED; schedule_probe(e, e.group, e.cur); }
+static inline void schedule_look_around(ScheduleEntry &e);
+// The climb is local: what it settles on is the fastest of everything it has measured -- the plain sequence included (a
+// shape whose fits need jitter retries repeats its pipeline with every retry: the sequence wins by far, nowhere near the
+// first split).  When that is not where the climb stands, its neighbours get one look (once).
+static inline void schedule_settle(ScheduleEntry &e)
+{
+    double best = schedule_ms(e, e.group, e.cur);
+    bool moved = false;
+    for (const auto &kv : e.samples) {
+        if (kv.second.count < kv.second.need) continue;
+        const double t = kv.second.ms();
+        if (t < best * (1.0 - kScheduleGain)) {
+            best = t; e.cur = kv.first.second; moved = true;
+            if (e.cur > 0) e.group = kv.first.first;
+        }
+    }
+    if (moved && !e.relooked && e.state != ScheduleEntry::SETTLED && e.calls <= kScheduleMaxCalls) {
+        e.relooked = true;
+        schedule_look_around(e);
+        return;
+    }
+    e.state = ScheduleEntry::SETTLED;
+    schedule_probe(e, e.group, e.cur);
+}
 
 // after the climb: the other grouping at the settled split, once
 static inline void schedule_try_grouping(ScheduleEntry &e)
@@ -207,7 +231,6 @@ static inline void schedule_try_grouping(ScheduleEntry &e)
     e.state = ScheduleEntry::GROUPING;
 }
 
-static inline void schedule_look_around(ScheduleEntry &e);
 // the climb: from cur in direction dir, `step` candidates at a time, doubling while it pays, single steps to finish
 static inline void schedule_climb(ScheduleEntry &e)
 {
@@ -259,7 +282,9 @@ static inline void schedule_look_around(ScheduleEntry &e)
 }
 
 // a call has ended: its time, and (the plain sequence) the times of its halves
-static inline void schedule_report(int n_cu, int n_cu_pipe, ScheduleEntry &e, const ScheduleChoice &ch, bool valid, double ms,
+// `retries`: the jitter retries the call needed (every retry repeats the factorisation -- and, overlapped, the pipeline:
+// calls are comparable when they needed the same number; the shape's first sampled call sets it), < 0: not to be sampled
+static inline void schedule_report(int n_cu, int n_cu_pipe, ScheduleEntry &e, const ScheduleChoice &ch, int retries, double ms,
                             double fact_us, double sweep_us)
 {
     if (!ch.sample) { e.last_pairs = kSequence - 1; return; }    // (an unsampled call in between: the next one is a change)
@@ -268,7 +293,9 @@ static inline void schedule_report(int n_cu, int n_cu_pipe, ScheduleEntry &e, co
     e.last_pairs = ch.pairs; e.last_group = ch.group;
     if (e.state == ScheduleEntry::COLD) { e.state = ScheduleEntry::SEQUENCE; return; }   // (allocations, code loading)
     if (e.calls > kScheduleMaxCalls) { schedule_settle(e); return; }
-    if (changed || !valid) return;         // the first call of a schedule pays for the change; a jitter retry is not its time
+    if (changed || retries < 0) return;    // the first call of a schedule pays for the change
+    if (e.retries < 0) e.retries = retries;
+    if (retries != e.retries) return;
     ScheduleSample &sm = e.samples[schedule_key(ch.group, ch.pairs)];
     sm.add(ms);
     if (ch.pairs == kSequence && fact_us > 0.0) {

@@ -20,6 +20,7 @@ static double step_ms(int curve, const ScheduleEntry &e, int group, int pairs)
         case 1: return pairs < 0 ? 20.3 : (19.9 + 0.8 * pairs) * g;       // the empty pipeline is best
         case 2: return pairs < 0 ? 12.2 : (22.7 - 12.9 * pairs / P) * g;  // everything pipelined is best, the sequence second
         case 3: return pairs < 0 ? 100.0 : (101.0 + 0.5 * pairs) * g;     // the plain sequence is best
+        case 5: return pairs < 0 ? 197.0 : (330.0 + 2.0 * std::fabs(pairs - 12.0)) * g;   // retries: the pipeline repeats, the sequence wins by far
         default: {                                                       // flat with a far valley (at 3/8)
             if (pairs < 0) return 24.6;
             const double x = pairs / P - 0.375;
@@ -45,7 +46,7 @@ int main(int argc, char **argv)
         if (ch.pairs != last_p || ch.group != last_g) ms *= 1.05;        // the call after a change pays for it
         if (calls == 0) ms *= 3.0;                                       // cold
         last_p = ch.pairs; last_g = ch.group;
-        schedule_report(n_cu, n_cu_pipe, e, ch, true, ms, ch.pairs < 0 ? 1700.0 : 0.0, ch.pairs < 0 ? 5100.0 : 0.0);
+        schedule_report(n_cu, n_cu_pipe, e, ch, 0, ms, ch.pairs < 0 ? 1700.0 : 0.0, ch.pairs < 0 ? 5100.0 : 0.0);
         ++calls;
     }
     double best = 1e300;
