@@ -1169,6 +1169,7 @@ void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const doubl
         const char *e = getenv("CBO_HIP_STRIP_FORM");
         return e ? atoi(e) : 8;
     }();
+    if (strip_form == 16) half_lds = true;            // (A/B timing: the half-LDS kernel, two workgroups per CU)
     if (!half_lds && strip_form != 4) {
 #ifdef CBO_DIAG_KNOBS
         static const int strip_mask = [] {

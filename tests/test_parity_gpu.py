@@ -1748,6 +1748,80 @@ def test_trial_step_is_the_three_calls_in_one(hip):
     assert one._call_cache.get("sweep_sets") is not None and one.models[a_idx].small
 
 
+@pytest.mark.parametrize("causal,ard", [(False, False), (True, False), (False, True), (True, True)])
+def test_trial_step_with_the_upload_folded_in_equals_the_three_calls(hip, causal, ard):
+    """cbo_trial_step hands the refitted model's NEW data to the sweep's one launch through the staging buffer (every
+    workgroup of the set prepares the points itself, the first one also fills the resident copies).  Against the explicit
+    sequence cbo_gp_upload_data + cbo_acq_sweep_sets + cbo_argmax_sets on twin models: same winners, same values, same
+    pick, bit for bit -- with prior closures (causal GP: prior mean and variance travel too), with per-dimension
+    lengthscales (the points are scaled on the way), d = 3, and a model that grows across a 16-row tile boundary (63 -> 66
+    observations).  Afterwards the resident copies serve a plain fit + predict exactly as uploaded data do."""
+    import ctypes
+    from cbo_with_oop_amd import CandidateGrid, _lib
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    lib = _lib.load()
+    rng = np.random.default_rng(17)
+    d, sizes, cand_sizes = 3, [40, 63, 100], [200, 130, 300]
+    mean_f = (lambda x: 0.3 * np.sin(x[:, :1]) + 0.1 * x[:, 1:2]) if causal else None
+    var_f = (lambda x: 0.05 + 0.02 * np.cos(x[:, 2:3]) ** 2) if causal else None
+    ls = np.array([0.8, 1.7, 1.2]) if ard else 1.3
+    f = lambda x: np.sin(x).sum(1, keepdims=True) + 0.05 * rng.standard_normal((x.shape[0], 1))
+    data = [rng.uniform(-3, 3, (n, d)) for n in sizes]
+    obs = [f(x) for x in data]
+
+    def build():
+        models = [HipGaussianProcess(x, y, variance=1.4, lengthscale=ls, ard=ard, noise_var=1e-3, mean_function=mean_f,
+                                     variance_adjustment=var_f, fit=False) for x, y in zip(data, obs)]
+        grids = [CandidateGrid(g, m) for g, m in zip(cand_points, models)]
+        return models, grids
+    cand_points = [rng.uniform(-3, 3, (m, d)) for m in cand_sizes]
+    one, one_grids = build()
+    three, three_grids = build()
+    S = len(sizes)
+    arr = lambda objs: (ctypes.c_void_p * S)(*[o._handle for o in objs])
+    y_best = np.full(S, min(float(y.min()) for y in obs))
+    costs = np.array([1.0, 2.0, 3.0])
+    for trial in range(5):
+        r = 1 if trial < 3 else trial % S                       # set 1 grows 63 -> 64 -> 65 -> 66, then the others
+        x_new = rng.uniform(-3, 3, (1, d))
+        data[r] = np.vstack([data[r], x_new]); obs[r] = np.vstack([obs[r], f(x_new)])
+        results = []
+        for models, grids, fused in ((one, one_grids, True), (three, three_grids, False)):
+            m = models[r]
+            m._set_arrays(data[r], obs[r])
+            pm, pv = m._prior(m.X)
+            vals, idxs, chosen = np.empty(S), np.empty(S, dtype=np.int64), ctypes.c_int(-1)
+            if fused:
+                _lib.check(lib.cbo_trial_step(S, arr(models), arr(grids), r, m.X.shape[0], _lib.dptr(m.X), _lib.dptr(m._y_flat),
+                                              _lib.dptr(pm), _lib.dptr(pv), _lib.dptr(y_best), 0, 0.0, _lib.dptr(costs),
+                                              _lib.dptr(vals), idxs.ctypes.data_as(_lib.c_int64_p), ctypes.byref(chosen)))
+            else:
+                _lib.check(lib.cbo_gp_upload_data(m._handle, m.X.shape[0], _lib.dptr(m.X), _lib.dptr(m._y_flat),
+                                                  _lib.dptr(pm), _lib.dptr(pv)))
+                _lib.check(lib.cbo_acq_sweep_sets(S, arr(models), arr(grids), _lib.dptr(y_best), 0, 0.0, _lib.dptr(costs),
+                                                  _lib.dptr(vals), idxs.ctypes.data_as(_lib.c_int64_p)))
+                _lib.check(lib.cbo_argmax_sets(_lib.dptr(vals), S, ctypes.byref(chosen)))
+            m.stale = True
+            results.append((vals.copy(), idxs.copy(), chosen.value))
+        (va, ia, ca), (vb, ib, cb) = results
+        assert np.array_equal(va, vb) and np.array_equal(ia, ib) and ca == cb, (trial, va, vb, ia, ib)
+        # the oracle's winners on the same data
+        for s in range(S):
+            post = O.fit(data[s], obs[s], None if not causal else mean_f(data[s]), None if not causal else var_f(data[s]),
+                         1.4, ls, 1e-3)
+            _, val, idx, _, _ = O.acquisition_sweep(post, cand_points[s], float(y_best[s]),
+                                                    None if not causal else mean_f(cand_points[s]),
+                                                    None if not causal else var_f(cand_points[s]), "min", float(costs[s]))
+            assert idx == ia[s] and np.isclose(val, va[s], rtol=1e-6, atol=1e-12), (trial, s, idx, ia[s], val, va[s])
+    # the resident copies the launch filled: a plain fit + predict from them equals the uploaded twin's
+    probe = rng.uniform(-3, 3, (9, d))
+    for a, b in zip(one, three):
+        (ma, sa), (mb, sb) = a.predict(probe), b.predict(probe)
+        assert np.array_equal(ma, mb) and np.array_equal(sa, sb)
+    for o in one_grids + three_grids + one + three:
+        o.close()
+
+
 def test_path_rebuilds_between_sweeps_never_reuse_destroyed_handles(hip):
     """A set rebuilt twice without a sweep in between (two observe trials in a row with one set, or closures that
     change twice): the multi-set call must be handed the handles of the objects that are alive now.  The cache of the
