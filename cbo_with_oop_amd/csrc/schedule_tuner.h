@@ -25,7 +25,7 @@
 //      at the settled split and kept if it is faster.
 // Results do not depend on the schedule (same bits whatever the split: tests/test_parity_gpu.py), so the exploration
 // only costs the few per cent by which a neighbouring split is slower, on the first ~20-30 calls of a shape.  A new
-// shape next to a settled one (the model grew by a panel) starts from that one's split.  CBO_HIP_SCHEDULE_TUNE=0 stops
+// shape near a settled one (the model grew by a panel, a grid of another size) starts from that one's split.  CBO_HIP_SCHEDULE_TUNE=0 stops
 // after step 2; CBO_HIP_PIPE_TAIL / CBO_HIP_PIPE_GROUP / CBO_HIP_OVERLAP force a schedule as before (the tuner is
 // bypassed); cbo_schedule_report prints what was measured and chosen.
 
@@ -164,17 +164,25 @@ static inline ScheduleEntry &schedule_entry(ScheduleTable &table, int n_cu_pipe,
     e.strips = (int)strips;
     // (a full round of strips: the bulk stream bounds the pipeline, its updates go in groups -- to begin with)
     e.group = (e.strips >= n_cu_pipe && e.all_pairs >= 4) ? 2 : 0;
-    // a settled shape with the same candidates and a neighbouring row count: start from its split and grouping
+    // A settled shape nearby (rows and candidates within a factor of two each, on the same side of "a full round of
+    // strips"): start from its split, as a fraction of the pairs, and its grouping -- a model that grew by a panel, a grid
+    // of another size.  A caller whose shapes never repeat then still runs a schedule measured next door instead of the
+    // plain sequence every time; only a context's first shape (and one far from everything seen) pays the two timing calls.
     const ScheduleEntry *seed = nullptr;
-    for (const auto &kv : table)
-        if (kv.first.second == m_pad && kv.second.state == ScheduleEntry::SETTLED &&
-            (!seed || std::llabs(kv.first.first - n_pad) < std::llabs(seed->n_pad - n_pad)))
-            seed = &kv.second;
-    if (seed && std::llabs(seed->n_pad - n_pad) <= 512 && seed->all_pairs > 0) {
-        e.group = seed->group;
+    double seed_dist = 1e300;
+    for (const auto &kv : table) {
+        const ScheduleEntry &o = kv.second;
+        if (o.state != ScheduleEntry::SETTLED || o.all_pairs < 1 || (o.strips >= n_cu_pipe) != (e.strips >= n_cu_pipe)) continue;
+        const double dist = std::fabs(std::log2((double)o.n_pad / (double)n_pad)) +
+                            std::fabs(std::log2((double)(o.strips > 0 ? o.strips : 1) / (double)(e.strips > 0 ? e.strips : 1)));
+        if (dist < seed_dist) { seed_dist = dist; seed = &o; }
+    }
+    if (seed && std::fabs(std::log2((double)seed->n_pad / (double)n_pad)) <= 1.0 &&
+        std::fabs(std::log2((double)(seed->strips > 0 ? seed->strips : 1) / (double)(e.strips > 0 ? e.strips : 1))) <= 1.0) {
+        if (e.all_pairs >= 4) e.group = seed->group;
         e.cur = seed->cur <= 0 ? seed->cur
                                : schedule_snap(e, e.group, (int)((double)seed->cur / seed->all_pairs * e.all_pairs + 0.5), -1);
-        e.fact_alone_us = seed->fact_alone_us; e.sweep_alone_us = seed->sweep_alone_us;
+        e.retries = -1;
         e.state = ScheduleEntry::BASE;
         schedule_probe(e, e.group, e.cur);
     }

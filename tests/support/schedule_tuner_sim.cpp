@@ -49,6 +49,14 @@ int main(int argc, char **argv)
         schedule_report(n_cu, n_cu_pipe, e, ch, 0, ms, ch.pairs < 0 ? 1700.0 : 0.0, ch.pairs < 0 ? 5100.0 : 0.0);
         ++calls;
     }
+    if (argc > 8) {
+        // a second shape next to the settled one (a grid of another size): it must start from the neighbour's split, not
+        // from the plain sequence -- print what its FIRST call would run
+        const int64_t m2 = std::atoll(argv[8]);
+        ScheduleEntry &e2 = schedule_entry(table, n_cu_pipe, n_pad, m2 / 64, m2);
+        const ScheduleChoice first = schedule_choose(e2, true);
+        std::printf("%d %d %d\n", first.pairs, first.group, e2.all_pairs);
+    }
     double best = 1e300;
     for (int grp = 0; grp <= 2; grp += 2)
         for (int p = -1; p <= e.all_pairs; ++p)

@@ -236,3 +236,9 @@ def test_schedule_tuner_settles_near_the_best_candidate_on_a_simulated_device(tm
                 chosen, best = float(out[4]), float(out[5])
                 assert settled == 1 and calls <= 97, (curve, n_pad, m_pad, seed, out)
                 assert chosen <= best * 1.016, (curve, n_pad, m_pad, seed, out)
+    # a shape next to a settled one starts from that one's split (same fraction of the pairs), not from the plain sequence;
+    # a shape far away starts cold (the two timing calls of the plain sequence)
+    near = subprocess.check_output([str(exe), "4096", "16384", "256", "224", "0", "0.01", "1", "24576"], text=True).split()
+    assert int(near[0]) == 4 and int(near[2]) == 16, near                     # 4 of 16 pairs, as settled at 16384 candidates
+    far = subprocess.check_output([str(exe), "4096", "16384", "256", "224", "0", "0.01", "1", "262144"], text=True).split()
+    assert int(far[0]) == -1, far
