@@ -1929,9 +1929,13 @@ extern "C" int cbo_trial_step(int n_sets, cbo_gp *const *gps, cbo_cands *const *
         bool fuse = c->small_sets && g->dtype == CBO_DTYPE_F64 && g->n_pad == kPadN && n > 0 && n <= kPadN && X && y &&
                     ((pm == nullptr) == (pv == nullptr)) && ((pv != nullptr) == (g->X.sv != nullptr)) &&
                     sizeof(double) * (size_t)(n * g->d + n + (pv ? 2 * n : 0)) <= kStageBytes;
-        for (int i = 0; i < n_sets && fuse; ++i) {
-            if (!gps[i] || !cands[i] || gps[i]->ctx != c) fuse = false;
-            else if (gps[i]->dtype == CBO_DTYPE_F64 && gps[i]->n_pad == kPadN && (cands[i]->m + 63) / 64 > 65535) fuse = false;
+        // (everything the sweep would refuse is refused BEFORE the model's host-side state moves to the new data)
+        for (int i = 0; i < n_sets; ++i) {
+            const int rc = check_sweep_args(gps[i], cands[i], task);
+            if (rc != CBO_OK) return rc;
+            if (gps[i]->ctx != c) return fail(CBO_ERR_INVALID, "all sets must live on one context");
+            if (i != refit_set && (gps[i]->n <= 0 || gps[i]->n_pad <= 0)) return fail(CBO_ERR_INVALID, "a gp holds no data");
+            if (gps[i]->dtype == CBO_DTYPE_F64 && gps[i]->n_pad == kPadN && (cands[i]->m + 63) / 64 > 65535) fuse = false;
         }
         if (fuse) {
             HIP_TRY(hipSetDevice(c->device));

@@ -430,6 +430,11 @@ __device__ __forceinline__ void diag_trailing(Diag2Shared &sh, const d4 (&x)[9],
 }
 
 #ifdef CBO_DIAG_KNOBS
+// Timing-only build: bit 1 = the worker waves of the block factorisation skip their trailing tiles, bit 2 = their
+// row-panel thirds as well (what the chain wave's tile factor costs with nothing beside it; results are wrong)
+__device__ int g_diag_knob;
+extern "C" int cbo_diag_set_knob(int v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_diag_knob), &v, sizeof(int)); }
+#define DIAG_KNOB(bit) (g_diag_knob & (bit))
 // Timing-only build: s_memtime stamps of the last diagonal-block launch, [wave][interval][slot] (scripts/diag_stamps.py)
 __device__ unsigned long long g_diag_stamps[4 * 9 * 4];
 #define DSTAMP(wave_, jb_, slot_) do { if ((threadIdx.x & 63) == 0) g_diag_stamps[((wave_) * 9 + (jb_)) * 4 + (slot_)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -444,6 +449,7 @@ extern "C" int cbo_diag_small_stamps(unsigned long long *out)
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_small_stamps), sizeof(unsigned long long) * 16);
 }
 #else
+#define DIAG_KNOB(bit) false
 #define DSTAMP(wave_, jb_, slot_) do { } while (0)
 #define SSTAMP(i_) do { } while (0)
 #endif
@@ -574,7 +580,7 @@ __device__ __forceinline__ void diag_worker(Diag2Shared &sh, double *A, int64_t 
     // trailing tiles T(ti, tj) -= X_ti^T X_tj, jb < ti <= 7, ti <= tj <= 8, except the next diagonal tile (wave 0's).
     // Ownership is by column (a compile-time list per wave), tiles go four at a time with their accumulation chains
     // interleaved; a tile that is not due (ti <= jb) is computed on stale operands and simply not written back.
-    diag_trailing<W>(sh, x, nx, jb, lane, tiles);
+    if (!DIAG_KNOB(1)) diag_trailing<W>(sh, x, nx, jb, lane, tiles);
     DSTAMP(W + 1, jb, 3);
     if (PUBLISH) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have arrived

@@ -12,6 +12,9 @@ X = rng.uniform([-5, -5, -5], [5, 20, 5], (n, 3))
 y = np.sin(X).sum(1, keepdims=True)
 m = HipGaussianProcess(X, y, noise_var=1e-2)
 lib = _lib.load()
+if len(sys.argv) > 2:                    # timing-only knob of the block factorisation (kernels_chol.hip: g_diag_knob)
+    lib.cbo_diag_set_knob.argtypes = [ctypes.c_int]
+    lib.cbo_diag_set_knob(int(sys.argv[2]))
 for _ in range(3):
     _lib.check(lib.cbo_gp_fit(m._handle, None, None))
 _lib.Context.get(0).synchronize()

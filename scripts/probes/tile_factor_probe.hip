@@ -296,10 +296,12 @@ __device__ __forceinline__ d4 factor<5>(d4 din, int lane, d4 &eout)
     return d;
 }
 
+__device__ unsigned long long g_clk[4];
 template <int FORM>
 __global__ void probe(const double *T, double *U, double *E, int reps)
 {
     const int lane = threadIdx.x, lc = lane & 15, kq = lane >> 4;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     d4 t;
     for (int r = 0; r < 4; ++r) t[r] = T[(kq + 4 * r) * 16 + lc];
     d4 u, e, acc = {0, 0, 0, 0};
@@ -312,6 +314,10 @@ __global__ void probe(const double *T, double *U, double *E, int reps)
     for (int r = 0; r < 4; ++r) {
         U[(kq + 4 * r) * 16 + lc] = u[r];
         E[(kq + 4 * r) * 16 + lc] = e[r];
+    }
+    if (lane == 0) {                              // shader cycles and 100 MHz ticks of the whole loop
+        g_clk[0] = __builtin_amdgcn_s_memtime() - c0;
+        g_clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
 }
 
@@ -370,8 +376,10 @@ int main()
         for (int i = 0; i < 16; ++i)
             for (int j = i; j < 16; ++j) same &= (U[i * 16 + j] == U0[i * 16 + j]);
         for (int i = 0; i < 256; ++i) same &= (E[i] == E0[i]) ? 1 : 2 * 0;
-        printf("form %d: %.3f us per 16x16 factor (%.0f ns per pivot); max |U - ref| %.2e, |E L - I| %.2e; bits equal to form 0: %d\n", form,
-               ms * 1e3 / reps, ms * 1e6 / reps / 16, err, ierr, same);
+        unsigned long long clk[4];
+        hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof(clk));
+        printf("form %d: %.3f us per 16x16 factor (%.0f ns per pivot; %.0f shader cycles per factor at %.0f MHz); max |U - ref| %.2e, |E L - I| %.2e; bits equal to form 0: %d\n", form,
+               ms * 1e3 / reps, ms * 1e6 / reps / 16, (double)clk[0] / reps, (double)clk[0] / (double)clk[1] * 100.0, err, ierr, same);
     }
     return 0;
 }

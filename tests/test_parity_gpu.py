@@ -1813,6 +1813,18 @@ def test_trial_step_with_the_upload_folded_in_equals_the_three_calls(hip, causal
                                                     None if not causal else mean_f(cand_points[s]),
                                                     None if not causal else var_f(cand_points[s]), "min", float(costs[s]))
             assert idx == ia[s] and np.isclose(val, va[s], rtol=1e-6, atol=1e-12), (trial, s, idx, ia[s], val, va[s])
+    # a call the sweep would refuse is refused before the model's state moves to the new data
+    m = one[0]
+    n_before = lib.cbo_gp_n(m._handle)
+    bigger = np.vstack([data[0], rng.uniform(-3, 3, (1, d))])
+    pm_b, pv_b = (mean_f(bigger), var_f(bigger)) if causal else (None, None)
+    vals, idxs, chosen = np.empty(S), np.empty(S, dtype=np.int64), ctypes.c_int(-1)
+    rc = lib.cbo_trial_step(S, arr(one), arr(one_grids), 0, bigger.shape[0], _lib.dptr(bigger), _lib.dptr(np.zeros(bigger.shape[0])),
+                            _lib.dptr(None if pm_b is None else np.ascontiguousarray(pm_b[:, 0])),
+                            _lib.dptr(None if pv_b is None else np.ascontiguousarray(pv_b[:, 0])), _lib.dptr(y_best), 7, 0.0,
+                            _lib.dptr(costs), _lib.dptr(vals), idxs.ctypes.data_as(_lib.c_int64_p), ctypes.byref(chosen))
+    assert rc == _lib.CBO_ERR_INVALID
+    assert lib.cbo_gp_n(m._handle) == n_before == data[0].shape[0]
     # the resident copies the launch filled: a plain fit + predict from them equals the uploaded twin's
     probe = rng.uniform(-3, 3, (9, d))
     for a, b in zip(one, three):
