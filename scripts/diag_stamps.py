@@ -1,6 +1,6 @@
 """Timing-only (diagnostic build, CBO_HIP_ALLOW_DIAG=1 CBO_HIP_LIB=.../libcbo_hip_diag.so): s_memtime stamps of the last diagonal-block
 launch of a factorisation -- per interval, wave 0 (loads + row tile + update | tile factor | stores) and waves 1-3
-(own panel tiles | rendezvous wait | trailing tiles).  s_memtime ticks at 100 MHz (10 ns)."""
+(own panel tiles | rendezvous wait | trailing tiles).  s_memtime counts shader cycles."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -23,7 +23,7 @@ lib.cbo_diag_chol_stamps.argtypes = [ctypes.c_void_p]
 lib.cbo_diag_chol_stamps(buf)
 st = np.frombuffer(buf, dtype=np.uint64).reshape(4, 9, 4).astype(np.int64)
 t0 = st[:, 8, 0].min()
-print("ticks of 10 ns, relative to the first wave's start")
+print("shader cycles, relative to the first wave's start")
 print("kernel: start", st[:, 8, 0] - t0, "block loaded", st[:, 8, 1] - t0, "end", st[:, 8, 2] - t0)
 for jb in range(8):
     w0 = st[0, jb] - t0

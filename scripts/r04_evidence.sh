@@ -2,7 +2,7 @@
 # Round-4 evidence run on the GPU box (from the repo root), on the final sources: bench lines for every BASELINE config,
 # rocprofv3 kernel stats of the same commands, the schedule scan, the tolerance report and the auxiliary timings.  Outputs
 # under gpurun_out/r04/ ; the summaries worth keeping are copied to profiles/ afterwards (scripts/pmc_passes.sh is a
-# separate call: one counter set per rocprofv3 run).  usage: scripts/r04_evidence.sh a|b
+# separate call: one counter set per rocprofv3 run).  usage: scripts/r04_evidence.sh a|b|c
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r04
 mkdir -p $OUT
@@ -20,6 +20,15 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p
 rm -rf $OUT/step_trace; timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/step_trace -- python3 bench.py --steps 6 --warmup 2 --cpu-sample 0 --post-steps 0 > $OUT/step_trace.log 2>&1; echo "step trace rc=$?"
 python3 scripts/step_timeline.py $(ls -t $OUT/step_trace/*/*kernel_trace.csv | head -1) > $OUT/step_timeline.txt
 for d in default sequential c1 f32; do cp $OUT/prof_$d/*/*kernel_stats.csv $OUT/kernel_stats_$d.csv; done
+elif [ "$1" = "c" ]; then
+# (the pieces a change of the factorisation's build touches)
+timeout -k 10 200 python3 scripts/chol_timing.py 1024 2048 4096 8192 16384 > $OUT/chol_timing.txt 2>&1; echo "chol rc=$?"
+timeout -k 10 200 python3 scripts/probes/trial_step_breakdown.py > $OUT/trial_step_breakdown.txt 2>&1; echo "trial step rc=$?"
+CBO_HIP_ALLOW_DIAG=1 CBO_HIP_LIB=$GRAFT_REPO_ROOT/cbo_with_oop_amd/libcbo_hip_diag.so timeout -k 10 200 python3 scripts/small_stamps.py > $OUT/small_stamps.txt 2>&1; echo "small stamps rc=$?"
+CBO_HIP_ALLOW_DIAG=1 CBO_HIP_LIB=$GRAFT_REPO_ROOT/cbo_with_oop_amd/libcbo_hip_diag.so timeout -k 10 200 python3 scripts/diag_stamps.py 128 > $OUT/diag_stamps.txt 2>&1; echo "diag stamps rc=$?"
+timeout -k 10 100 ./scripts/probes/tile_factor_probe > $OUT/tile_factor_probe.txt 2>&1; echo "probe rc=$?"
+timeout -k 10 300 python3 scripts/complete_graph_cbo_loop.py 20 > $OUT/loop.txt 2>&1; timeout -k 10 300 python3 scripts/complete_graph_cbo_loop.py 20 --optimize >> $OUT/loop.txt 2>&1; echo "loop rc=$?"
+timeout -k 10 200 python3 scripts/small_config_latency.py > $OUT/small_config_latency.txt 2>&1; echo "small config rc=$?"
 else
 timeout -k 10 900 python3 scripts/schedule_scan.py > $OUT/schedule_crossover.txt 2> $OUT/schedule_crossover.err; echo "schedule scan rc=$?"
 timeout -k 10 600 python3 scripts/tolerance_report.py --large > $OUT/tolerance_report.txt 2> $OUT/tolerance_report.err; echo "tolerance rc=$?"
