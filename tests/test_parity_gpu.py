@@ -1116,7 +1116,7 @@ def test_measured_schedule_settles_and_every_call_on_the_way_gives_the_same_bits
         r = ei.sweep(grid, refit=True)
         calls += 1
         assert (r["best_val"], r["best_idx"]) == (first["best_val"], first["best_idx"])
-        assert calls <= 60, text
+        assert calls <= 110, text                       # (the tuner itself gives up after 96 sampled calls)
     assert "settled" in states and len(states) >= 3, (states, text)
     full = ei.sweep(grid, refit=True, want_acq=True, want_posterior=True)       # (outputs requested: not sampled)
     mu, var = model.predict(grid.points[:64])
