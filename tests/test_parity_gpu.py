@@ -1834,6 +1834,61 @@ def test_trial_step_with_the_upload_folded_in_equals_the_three_calls(hip, causal
         o.close()
 
 
+def test_trial_step_at_the_edges_of_the_one_launch_path(hip):
+    """cbo_trial_step where the folded-in upload does not apply or barely does: no set to refit (refit_set = -1), a model
+    of one observation growing to two, and a model growing 127 -> 128 -> 129 observations -- the last step leaves the
+    one-launch path (padded size 256: a plain upload, the general path for that set).  Always the three calls' answer."""
+    import ctypes
+    from cbo_with_oop_amd import CandidateGrid, _lib
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    lib = _lib.load()
+    rng = np.random.default_rng(23)
+    f = lambda x: np.cos(x).sum(1, keepdims=True) + 0.05 * rng.standard_normal((x.shape[0], 1))
+    for start, steps in ((1, 1), (127, 2)):
+        data = [rng.uniform(-3, 3, (start, 2)), rng.uniform(-3, 3, (30, 2))]
+        obs = [f(x) for x in data]
+        cand = [rng.uniform(-3, 3, (150, 2)), rng.uniform(-3, 3, (70, 2))]
+        twins = []
+        for _ in range(2):
+            models = [HipGaussianProcess(x, y, noise_var=1e-3, fit=False) for x, y in zip(data, obs)]
+            twins.append((models, [CandidateGrid(c, m) for c, m in zip(cand, models)]))
+        arr = lambda objs: (ctypes.c_void_p * 2)(*[o._handle for o in objs])
+        y_best, costs = np.full(2, min(float(y.min()) for y in obs)), np.array([1.0, 2.0])
+
+        def run(models, grids, fused, refit):
+            vals, idxs, chosen = np.empty(2), np.empty(2, dtype=np.int64), ctypes.c_int(-1)
+            m = models[0]
+            if fused:
+                _lib.check(lib.cbo_trial_step(2, arr(models), arr(grids), 0 if refit else -1, m.X.shape[0], _lib.dptr(m.X),
+                                              _lib.dptr(m._y_flat), None, None, _lib.dptr(y_best), 0, 0.0, _lib.dptr(costs),
+                                              _lib.dptr(vals), idxs.ctypes.data_as(_lib.c_int64_p), ctypes.byref(chosen)))
+            else:
+                if refit:
+                    _lib.check(lib.cbo_gp_upload_data(m._handle, m.X.shape[0], _lib.dptr(m.X), _lib.dptr(m._y_flat), None, None))
+                _lib.check(lib.cbo_acq_sweep_sets(2, arr(models), arr(grids), _lib.dptr(y_best), 0, 0.0, _lib.dptr(costs),
+                                                  _lib.dptr(vals), idxs.ctypes.data_as(_lib.c_int64_p)))
+                _lib.check(lib.cbo_argmax_sets(_lib.dptr(vals), 2, ctypes.byref(chosen)))
+            return vals, idxs, chosen.value
+
+        for step in range(steps + 1):
+            refit = step > 0
+            if refit:
+                x_new = rng.uniform(-3, 3, (1, 2))
+                data[0] = np.vstack([data[0], x_new]); obs[0] = np.vstack([obs[0], f(x_new)])
+                for models, _ in twins:
+                    models[0]._set_arrays(data[0], obs[0])
+            (va, ia, ca), (vb, ib, cb) = run(*twins[0], True, refit), run(*twins[1], False, refit)
+            assert np.array_equal(va, vb) and np.array_equal(ia, ib) and ca == cb, (start, step, va, vb)
+            assert lib.cbo_gp_n(twins[0][0][0]._handle) == data[0].shape[0]
+            for s in range(2):
+                _, val, idx, _, _ = O.acquisition_sweep(O.fit(data[s], obs[s], None, None, 1.0, 1.0, 1e-3), cand[s],
+                                                        float(y_best[s]), None, None, "min", float(costs[s]))
+                assert idx == ia[s] and np.isclose(val, va[s], rtol=1e-5, atol=1e-12), (start, step, s)
+        for models, grids in twins:
+            for o in grids + models:
+                o.close()
+
+
 def test_path_rebuilds_between_sweeps_never_reuse_destroyed_handles(hip):
     """A set rebuilt twice without a sweep in between (two observe trials in a row with one set, or closures that
     change twice): the multi-set call must be handed the handles of the objects that are alive now.  The cache of the
