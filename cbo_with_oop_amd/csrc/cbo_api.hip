@@ -1569,7 +1569,7 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
         } else choice.pairs = all_pairs >= 4 ? all_pairs / 4 : 1;    // (only overlap / grouping forced: a quarter of the rows)
     } else {
         entry = &schedule_entry(c->schedule, c->n_cu_pipe, g->n_pad, k->m_pad / kStrip, k->m_pad);
-        choice = schedule_choose(*entry, !c->profiling && !acq_out && !mean_out && !var_out);
+        choice = schedule_choose(*entry, !c->profiling, c->n_cu, c->n_cu_pipe);
     }
     if (choice.pairs == kSequence) {
         int tries = 0;

@@ -957,6 +957,513 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// The strip kernel on 256-row PAIR blocks (round 5).  What a 128-row block of trsm_strip8_kernel costs beyond its regular
+// stages is its diagonal phase -- four stages with 60 / 44 / 28 / 12 MFMAs per SIMD between the same barriers and DMA round
+// trips as a regular stage's 64, in two of which one wave of every SIMD has nothing to do -- and the refill of the DMA ring
+// behind it.  Here two row blocks (b, b+1) go through the ring together and the 128 x 128 square between them is folded
+// into the diagonal phase, where it is the work that keeps the matrix pipe busy:
+//
+//   ownership   wave (cw, h) owns ALL eight row tiles of block b + h for the 16 columns of column group cw (strip8: half
+//               of every block).  Both waves of a SIMD still share every B fragment.
+//   regular     stages of 16 U rows x 256 columns (the pair's columns): 4 k-steps x 8 tiles = 32 MFMAs per wave, as many
+//               as strip8's 8 k-steps x 4 tiles, with ONE B fragment per 8 MFMAs instead of per 4 and half the V re-read
+//               traffic (a V row is fetched once per pair of blocks).  Ring of three slots of 43,008 B.
+//   D0          eight stages, one 16-row tile of block b each (same U tile shape as a regular stage: the block's rows x
+//               the pair's columns).  Wave (cw, 0) solves: x_s = inv(L_ss) r_s, publishes x_s over the inverse it has
+//               just consumed (mid-stage barrier), updates its own tiles below.  Wave (cw, 1) folds x_s into the eight
+//               tiles of block b+1 -- 32 independent MFMAs per tile, the last k-step deferred past the next stage top so
+//               that the solver's serial head (inverse fetch, two dependent MFMA pairs, publication) is covered.
+//   D1          four stages, two tiles of block b+1 each (slot row r = U rows r and r + 16 of the stage, the block's own
+//               128 columns): wave (cw, 1) solves alone, the arithmetic of trsm_strip_kernel's two-tile diagonal stage;
+//               nothing is published.  Wave (cw, 0) has no rows left in the pair: it issues its share of the DMA and
+//               requests its next block's right-hand sides.
+// Per element the operations and their order are those of trsm_strip_kernel / trsm_strip8_kernel / trsm_update_kernel
+// (accumulation over k ascending in k-steps of 4, the solve as two half-sums, updates tile by tile): V, q and mu come out
+// bit for bit the same.  The running (q, mu) lane partials pass from (cw, 0) to (cw, 1) once per pair.
+// n must be a multiple of 256 (launch_trsm_strips falls back to trsm_strip8_kernel otherwise).
+constexpr int kPB = 2 * kRB;                  // rows per pair block
+constexpr int kPKB = 16;                      // U rows per stage
+constexpr int kPLd = kPB + 16;                // U-tile row stride (doubles): k rows kq, kq+1 land 32 banks apart
+constexpr int kPA = kPKB * kPLd;              // doubles per U stage buffer (34,816 B)
+constexpr int kPBd = 4 * kPKB * 16;           // doubles per B stage buffer (4 column groups x [16 k][16 cols], 8,192 B)
+constexpr int kPDma = 5;                      // LDS-DMA instructions per wave and stage: 4 x 1 KiB of U, one B piece
+constexpr int kPD0 = kRB / 16;                // diagonal stages of the pair's first block (one tile each)
+constexpr int kPD1 = kRB / 32;                // ... of its second block (two tiles each)
+
+struct PairCursor {
+    int i0, j, lim;                           // pair origin, stage index within the pair, stages in the pair
+    int ai0, aj;                              // clamped to the last stage once the cursor is past the end
+    const double *a_src;                      // per-lane source of this wave's first U piece
+    int64_t a_cstride;                        // doubles between the two pieces of a slot row
+    const double *b_src;                      // per-lane source of this wave's B piece
+    unsigned b_dst;                           // its place in the B stage buffer (doubles)
+};
+
+template <bool SWEEP>
+__global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict__ U, int64_t ldu,
+                                                        const double *__restrict__ invDt, double *V, int64_t ldv,
+                                                        int n, const double *__restrict__ z,
+                                                        double *__restrict__ q_out, double *__restrict__ mu_out,
+                                                        int accumulate)
+{
+    __shared__ __align__(16) double lds[kNBuf * (kPA + kPBd)];         // 129,024 B
+    __shared__ __align__(16) double zl[SWEEP ? 2 * kPB : 2];           // z rows of the current and the next pair
+    __shared__ __align__(16) double handbuf[SWEEP ? 4 * 64 * 2 : 2];   // (q, mu) lane partials, (cw, 0) -> (cw, 1)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform: LDS bases stay scalar
+    const int cw = wave & 3, h = wave >> 2;                            // column group, block of the pair (waves w, w+4 share a SIMD)
+    const int lc = lane & 15, kq = lane >> 4;
+    const int64_t colw = (int64_t)blockIdx.x * kStrip + cw * 16;       // first column of this wave's column group
+    // V addresses are "per-lane base + wave-uniform row offset": the row offsets stay on the scalar unit and nothing per row
+    // is kept in vector registers across the pair loop
+    double *Vq = V + colw + lc + (int64_t)kq * ldv;                    // row kq of the lane's column
+    double *ldsB = lds + kNBuf * kPA;
+    double *hand = handbuf + (cw * 64 + lane) * 2;
+    const unsigned lds_byte0 = lds_byte_address(lds);
+    const double *ug = U + (int64_t)(2 * wave) * ldu + lane * 2;       // slot rows 2 wave, 2 wave + 1
+    const double *vg = V + (int64_t)((lane >> 3) + 8 * h) * ldv + colw + 2 * (lane & 7);   // B piece h: rows 8h .. 8h+7
+    const double *inv_d0 = invDt + 128 * h + lane * 2;                 // D0: half h of the stage's inverse
+    const double *inv_d1 = invDt + 256 * (cw >> 1) + 128 * (cw & 1) + lane * 2;            // D1: piece cw of its two
+
+    PairCursor ahead{0, 0, kPD0 + kPD1, 0, 0, nullptr, 0, nullptr, 0u};
+    auto locate_a = [&](PairCursor &c) __attribute__((always_inline)) {
+        const bool past = c.i0 >= n;
+        c.ai0 = past ? n - kPB : c.i0;
+        c.aj = past ? (n - kPB) / kPKB + kPD0 + kPD1 - 1 : c.j;
+    };
+    auto locate_b = [&](PairCursor &c) __attribute__((always_inline)) {
+        const int m1 = c.aj - c.ai0 / kPKB - kPD0;                     // >= 0: stage m1 of D1
+        const bool d1 = m1 >= 0;
+        const int64_t row = d1 ? (int64_t)(c.ai0 + kRB + 32 * m1) : (int64_t)kPKB * c.aj;
+        const int64_t col = d1 ? (int64_t)(c.ai0 + kRB) : (int64_t)c.ai0;
+        c.a_src = ug + row * ldu + col;
+        c.a_cstride = d1 ? 16 * ldu : (int64_t)kRB;
+    };
+    auto locate_c = [&](PairCursor &c) __attribute__((always_inline)) {
+        const int nreg = c.ai0 / kPKB;
+        const int m1 = c.aj - nreg - kPD0;
+        const bool d1 = m1 >= 0, reg = c.aj < nreg;
+        const int64_t tile = d1 ? (int64_t)(nreg + kPD0 + 2 * m1) : (int64_t)c.aj;
+        const double *inv_p = (d1 ? inv_d1 : inv_d0) + tile * 256;
+        const double *v_p = vg + (int64_t)(kPKB * c.aj) * ldv;
+        c.b_src = reg ? v_p : inv_p;
+        c.b_dst = d1 ? (unsigned)(cw * 128) : (unsigned)(cw * 256 + 128 * h);
+    };
+    auto step = [&](PairCursor &c) __attribute__((always_inline)) {
+        const int wrap = (c.j + 1 == c.lim) ? 1 : 0;
+        c.i0 += kPB * wrap;
+        c.j = (c.j + 1) * (1 - wrap);
+        c.lim = c.lim + (c.i0 / kPKB + kPD0 + kPD1 - c.lim) * wrap;
+    };
+    auto advance = [&](PairCursor &c) __attribute__((always_inline)) {
+        step(c);
+        locate_a(c);
+        locate_b(c);
+        locate_c(c);
+    };
+    // DMA instruction i of the wave's kPDma for the stage the cursor points at: i < 4: piece i & 1 of slot row
+    // 2 wave + (i >> 1); i = 4: the B piece
+    auto issue_one = [&](const PairCursor &c, int buf, int i) __attribute__((always_inline)) {
+        if (i < 4) {
+            const unsigned la = __builtin_amdgcn_readfirstlane(
+                lds_byte0 + 8u * (unsigned)(buf * kPA + (2 * wave + (i >> 1)) * kPLd + kRB * (i & 1)));
+            glds16(c.a_src + (int64_t)(i >> 1) * ldu + (int64_t)(i & 1) * c.a_cstride, la);
+        } else {
+            const unsigned lb = __builtin_amdgcn_readfirstlane(lds_byte0 + 8u * ((unsigned)(kNBuf * kPA + buf * kPBd) + c.b_dst));
+            glds16(c.b_src, lb);
+        }
+    };
+    auto issue_stage = [&](const PairCursor &c, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < kPDma; ++i) issue_one(c, buf, i);
+    };
+
+    // One code path per role (H = 0: the waves of block b, H = 1: of block b + 1), the whole pair loop: the roles keep different
+    // things in registers through the diagonal phase, and two straight pipelines are what the register allocator handles
+    // without copies or spills.
+    auto run = [&](auto role_tag) __attribute__((always_inline)) {
+        constexpr int H = decltype(role_tag)::value;
+        // acc holds the NEGATED residual of this wave's eight row tiles (block b + h)
+        d4 acc[kT];
+#pragma unroll
+        for (int t = 0; t < kT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] = -Vq[(int64_t)(kRB * H + 16 * t + 4 * r) * ldv];
+        if (SWEEP) {
+            const d2 z0 = *reinterpret_cast<const d2 *>(z + kRB * H + 2 * lane);
+            *reinterpret_cast<d2 *>(zl + kRB * H + 2 * lane) = z0;          // pair 0; published by the first stage barrier
+        }
+        // The next pair's right-hand sides and z rows are requested by hand-issued loads (invisible to the compiler's vmcnt
+        // counting like the LDS-DMA instructions, see trsm_strip8_kernel) during D1 -- wave (cw, 0) in its first stage, where it
+        // has nothing else to do, wave (cw, 1) in its third, when half of its tiles are solved -- ahead of that stage's DMA, so
+        // that the stage top two stages later retires them; they are read back behind the first stage top of the next pair.
+        double accn[kT][4];
+        d2 zn;
+        constexpr int kAhead = kT * 4 + (SWEEP ? 1 : 0);
+        // (scalar base + 32-bit lane offset: one vector register of addressing for all of them)
+        const unsigned vq_off = (unsigned)(((int64_t)kq * ldv + lc) * 8);
+        const unsigned z_off = (unsigned)(lane * 16);
+        auto request_ahead = [&](int i0) __attribute__((always_inline)) {
+            const int nb = (i0 + kPB < n) ? i0 + kPB : i0;               // (the last pair asks for its own rows again: no branch)
+            const double *vb = V + colw + (int64_t)(nb + kRB * H) * ldv;   // wave-uniform
+#pragma unroll
+            for (int t = 0; t < kT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(accn[t][r]) : "v"(vq_off), "s"(vb + (int64_t)(16 * t + 4 * r) * ldv) : "memory");
+            if (SWEEP) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(zn) : "v"(z_off), "s"(z + nb + kRB * H) : "memory");
+        };
+
+        locate_a(ahead);
+        locate_b(ahead);
+        locate_c(ahead);
+        issue_stage(ahead, 0);
+        advance(ahead);
+        issue_stage(ahead, 1);
+        advance(ahead);
+
+        int buf = 0;
+        double qacc = 0.0, macc = 0.0, qtot = 0.0, mtot = 0.0;       // totals live in the h = 1 waves
+        if (SWEEP && accumulate && H == 1) {
+            qtot = q_out[colw + lc];
+            mtot = mu_out[colw + lc];
+        }
+
+        // Stage-top wait, as in trsm_strip8_kernel: this wave's DMA of stage k (issued during stage k-2) has landed once only
+        // what is younger than its last instruction may still be in flight: what stage k-2 issued after its DMA (a2: the
+        // solver's V stores), and all of stage k-1 -- what it issued ahead of its DMA (b1: the hand-issued loads), the DMA, what
+        // it issued after (a1).
+        int a1 = 0, b1 = 0, a2 = 0;
+        auto wait_top = [&]() __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int extra = a1 + b1 + a2;
+#define WAIT_IF(x) if (extra == (x)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPDma + (x)) : "memory")
+            if (extra == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPDma) : "memory");
+            else WAIT_IF(4);
+            else WAIT_IF(8);
+            else WAIT_IF(16);
+            else WAIT_IF(kAhead);
+            else WAIT_IF(kAhead + 4);
+            else WAIT_IF(kAhead + 8);
+            else WAIT_IF(kAhead + 16);
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPDma) : "memory");       // (any other count: the strict wait)
+#undef WAIT_IF
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            a2 = a1;
+            a1 = 0;
+            b1 = 0;
+        };
+        static_assert(kPDma + kAhead + 16 <= 63, "s_waitcnt vmcnt is a 6-bit count");
+
+        double af[2][kT], bf[2];
+        // ---- regular stages: U rows [16 j, 16 j + 16) against the pair's 256 columns; the last k-step's MFMAs are issued
+        // behind the next stage top (barrier skew and the first LDS reads hide under them)
+        auto regular_stage = [&](int i0, auto first_tag) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const int zpar = ((i0 / kPB) & 1) * kPB;                 // this pair's half of zl
+            wait_top();
+            if (FIRST) {
+                // the hand-issued loads of the previous pair's D1 were retired by this wait
+#pragma unroll
+                for (int t = 0; t < kT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        asm volatile("; ahead-pin %0" : "+v"(accn[t][r]));      // (named: scripts/check_hand_issued_loads.py)
+                        acc[t][r] = -accn[t][r];
+                    }
+                if (SWEEP) {
+                    asm volatile("; ahead-pin %0" : "+v"(zn));
+                    *reinterpret_cast<d2 *>(zl + zpar + kRB * H + 2 * lane) = zn;
+                }
+            }
+            const int bnext = (buf >= 1) ? buf - 1 : 2;       // (buf + 2) % 3
+            const double *abase = lds + buf * kPA + kq * kPLd + kRB * H + lc;
+            const double *bbase = ldsB + buf * kPBd + cw * 256 + kq * 16 + lc;
+#pragma unroll
+            for (int t = 0; t < kT; ++t) {
+                if (!FIRST) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
+                if (t < kT / 2) {
+                    af[0][2 * t] = abase[32 * t];
+                    af[0][2 * t + 1] = abase[32 * t + 16];
+                } else if (t == kT / 2) {
+                    bf[0] = bbase[0];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                const double *an = abase + 4 * (jj + 1) * kPLd;
+#pragma unroll
+                for (int t = 0; t < kT; ++t) {
+                    acc[t] = MFMA_F64(af[jj & 1][t], bf[jj & 1], acc[t]);
+                    if (t < kT / 2) {
+                        af[(jj + 1) & 1][2 * t] = an[32 * t];
+                        af[(jj + 1) & 1][2 * t + 1] = an[32 * t + 16];
+                    } else if (t == kT / 2) {
+                        bf[(jj + 1) & 1] = bbase[4 * (jj + 1) * 16];
+                    } else {
+                        const int slot = 3 * jj + (t - (kT / 2 + 1));       // nine slots: five DMA instructions, the cursor
+                        if (slot < kPDma) issue_one(ahead, bnext, slot);
+                        else if (slot == kPDma) step(ahead);
+                        else if (slot == kPDma + 1) locate_a(ahead);
+                        else if (slot == kPDma + 2) locate_b(ahead);
+                        else locate_c(ahead);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            buf = (buf == 2) ? 0 : buf + 1;                   // the last k-step sits in af[1], bf[1]
+        };
+        // the diagonal phase of the pair at i0; P0: the first pair, which has no regular stage before it (nothing deferred)
+        auto diag_phase = [&](int i0, auto first_pair_tag) __attribute__((always_inline)) {
+            constexpr bool P0 = decltype(first_pair_tag)::value;
+            const int zpar = ((i0 / kPB) & 1) * kPB;                     // this pair's half of zl
+            // ---- the diagonal phase, one code path per role (the roles' live registers differ: (cw, 0) carries its next block's
+            // right-hand sides through D1, (cw, 1) the fragments of its solve)
+            // D0: tile m of block b per stage; (cw, 0) solves, (cw, 1) folds into block b + 1
+            // D1: tiles 2m, 2m+1 of block b + 1 per stage; (cw, 1) solves alone
+            if constexpr (H == 0) {
+#pragma unroll
+                for (int m = 0; m < kPD0; ++m) {
+                    wait_top();
+                    const int bnext = (buf >= 1) ? buf - 1 : 2;
+                    const double *abase0 = lds + buf * kPA + kq * kPLd + lc;              // U tile of the stage, all 256 columns
+                    double *xreg = ldsB + buf * kPBd + cw * 256;                          // the inverse in, the solved tile out
+                    double iv[4], uf[kT][4], zr[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) iv[kk] = xreg[(4 * kk + kq) * 16 + lc];
+                    // the regular stages' deferred k-step: the tile about to be solved first
+                    if (m == 0 && !P0) acc[0] = MFMA_F64(af[1][0], bf[1], acc[0]);
+                    d4 x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
+                    x = MFMA_F64(iv[0], -acc[m][0], x);
+                    x2 = MFMA_F64(iv[1], -acc[m][1], x2);
+                    if (m == 0 && !P0) {
+#pragma unroll
+                        for (int t = 1; t < kT; ++t) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
+                    }
+                    x = MFMA_F64(iv[2], -acc[m][2], x);
+                    x2 = MFMA_F64(iv[3], -acc[m][3], x2);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = m + 1; t < kT; ++t)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) uf[t][kk] = abase0[(4 * kk) * kPLd + 16 * t];
+                    if (SWEEP) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zr[r] = zl[zpar + 16 * m + kq + 4 * r];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    x += x2;
+                    asm volatile("" : "+v"(x));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xreg[(kq + 4 * r) * 16 + lc] = x[r];      // B-operand layout [row][column]
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                                       // (cw, 1) may read x now
+                    // the next tile's update is a chain of four dependent MFMAs: the stage's DMA issue and the cursor
+                    // arithmetic sit in its gaps, ahead of the stage's V stores (as the stage-top accounting assumes)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        if (m + 1 < kT) acc[m + 1] = MFMA_F64(uf[m + 1][kk], x[kk], acc[m + 1]);
+                        if (m + 2 < kT) acc[m + 2] = MFMA_F64(uf[m + 2][kk], x[kk], acc[m + 2]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (kk == 0) { issue_one(ahead, bnext, 0); issue_one(ahead, bnext, 1); }
+                        else if (kk == 1) { issue_one(ahead, bnext, 2); issue_one(ahead, bnext, 3); }
+                        else if (kk == 2) issue_one(ahead, bnext, 4);
+                        else advance(ahead);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        Vq[(int64_t)(i0 + 16 * m + 4 * r) * ldv] = x[r];
+                        if (SWEEP) {
+                            qacc = fma(x[r], x[r], qacc);
+                            macc = fma(x[r], zr[r], macc);
+                        }
+                    }
+                    // (the partial sums here and now: left alone the compiler sinks both chains to the end of the phase and keeps every
+                    // solved tile and z row alive -- in scratch -- until then)
+                    if (SWEEP) asm volatile("" : "+v"(qacc), "+v"(macc));
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int t = m + 3; t < kT; ++t) acc[t] = MFMA_F64(uf[t][kk], x[kk], acc[t]);
+                    a1 += 4;
+                    if (SWEEP && m == kPD0 - 1) {                                       // block b done: hand the lane partials over
+                        hand[0] = qacc;
+                        hand[1] = macc;
+                        qacc = 0.0;
+                        macc = 0.0;
+                    }
+                    buf = (buf == 2) ? 0 : buf + 1;
+                }
+#pragma unroll
+                for (int m = 0; m < kPD1; ++m) {
+                    wait_top();
+                    const int bnext = (buf >= 1) ? buf - 1 : 2;
+                    if (m == 0) {
+                        request_ahead(i0);
+                        b1 += kAhead;
+                    }
+                    issue_stage(ahead, bnext);
+                    advance(ahead);
+                    buf = (buf == 2) ? 0 : buf + 1;
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < kPD0; ++m) {
+                    wait_top();
+                    const int bnext = (buf >= 1) ? buf - 1 : 2;
+                    const double *abase0 = lds + buf * kPA + kq * kPLd + lc;              // U tile of the stage, all 256 columns
+                    double *xreg = ldsB + buf * kPBd + cw * 256;                          // the inverse in, the solved tile out
+                    double uf[kT][4], xb[4];
+                    // the deferred k-step (of the last regular stage, or of the previous tile's fold) under this tile's U reads
+#pragma unroll
+                    for (int t = 0; t < kT; ++t) {
+                        if (m > 0 || !P0) acc[t] = MFMA_F64(af[1][t], bf[1], acc[t]);
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) uf[t][kk] = abase0[(4 * kk) * kPLd + kRB + 16 * t];
+                    }
+                    issue_stage(ahead, bnext);
+                    advance(ahead);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                                       // x is published
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) xb[kk] = xreg[(4 * kk + kq) * 16 + lc];
+#pragma unroll
+                    for (int kk = 0; kk < (m + 1 < kPD0 ? 3 : 4); ++kk)
+#pragma unroll
+                        for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(uf[t][kk], xb[kk], acc[t]);
+                    if (m + 1 < kPD0) {
+#pragma unroll
+                        for (int t = 0; t < kT; ++t) af[1][t] = uf[t][3];               // k-step 3: behind the next stage top
+                        bf[1] = xb[3];
+                    }
+                    buf = (buf == 2) ? 0 : buf + 1;
+                }
+#pragma unroll
+                for (int m = 0; m < kPD1; ++m) {
+                    wait_top();
+                    const int bnext = (buf >= 1) ? buf - 1 : 2;
+                    constexpr int kTl = kT;
+                    const int s = 2 * m;
+                    const double *ab = lds + buf * kPA + kq * kPLd + lc;          // rows of tile s: columns 0..127, of s+1: 128..255
+                    const double *ivb = ldsB + buf * kPBd + kq * 16 + lc;         // the stage's two inverses
+                    double iv[2][4], uf[2][kTl][4], zr[2][4];
+                    if (SWEEP && m == 0) {                                        // take over the running lane partials
+                        qacc = hand[0];
+                        macc = hand[1];
+                    }
+                    if (m == 2) {
+                        request_ahead(i0);
+                        b1 += kAhead;
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) iv[0][kk] = ivb[(4 * kk) * 16];
+                    d4 x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
+                    x = MFMA_F64(iv[0][0], -acc[s][0], x);
+                    x2 = MFMA_F64(iv[0][1], -acc[s][1], x2);
+                    x = MFMA_F64(iv[0][2], -acc[s][2], x);
+                    x2 = MFMA_F64(iv[0][3], -acc[s][3], x2);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) iv[1][kk] = ivb[256 + (4 * kk) * 16];
+#pragma unroll
+                    for (int t = s + 1; t < kT; ++t)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) uf[0][t][kk] = ab[(4 * kk) * kPLd + 16 * t];
+                    if (SWEEP) {
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) zr[hh][r] = zl[zpar + kRB + 16 * (s + hh) + kq + 4 * r];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    x += x2;
+                    asm volatile("" : "+v"(x));
+                    auto emit = [&](int hh, const d4 &xx) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            Vq[(int64_t)(i0 + kRB + 16 * (s + hh) + 4 * r) * ldv] = xx[r];
+                            if (SWEEP) {
+                                qacc = fma(xx[r], xx[r], qacc);
+                                macc = fma(xx[r], zr[hh][r], macc);
+                            }
+                        }
+                        if (SWEEP) asm volatile("" : "+v"(qacc), "+v"(macc));
+                    };
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        acc[s + 1] = MFMA_F64(uf[0][s + 1][kk], x[kk], acc[s + 1]);
+                        if (s + 2 < kT) acc[s + 2] = MFMA_F64(uf[0][s + 2][kk], x[kk], acc[s + 2]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (kk == 0) { issue_one(ahead, bnext, 0); issue_one(ahead, bnext, 1); }
+                        else if (kk == 1) { issue_one(ahead, bnext, 2); issue_one(ahead, bnext, 3); }
+                        else if (kk == 2) issue_one(ahead, bnext, 4);
+                        else advance(ahead);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    emit(0, x);
+                    const d4 na = -acc[s + 1];
+                    d4 y1 = {0.0, 0.0, 0.0, 0.0}, y2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        if (kk & 1) y2 = MFMA_F64(iv[1][kk], na[kk], y2);
+                        else y1 = MFMA_F64(iv[1][kk], na[kk], y1);
+#pragma unroll
+                        for (int t = s + 3; t < kT; ++t) acc[t] = MFMA_F64(uf[0][t][kk], x[kk], acc[t]);
+                    }
+                    // (the second tile's U fragments only now: the wave is alone on its SIMD's registers' worth of operands, and
+                    // one LDS round trip per stage is what that costs)
+#pragma unroll
+                    for (int t = s + 2; t < kT; ++t)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) uf[1][t][kk] = ab[(4 * kk) * kPLd + kRB + 16 * t];
+                    const d4 y = y1 + y2;
+                    emit(1, y);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int t = s + 2; t < kT; ++t) acc[t] = MFMA_F64(uf[1][t][kk], y[kk], acc[t]);
+                    a1 += 8;
+                    if (SWEEP && m == kPD1 - 1) {                                 // end of the pair: reduce over the lane groups, add
+                        qacc += __shfl_xor(qacc, 16);
+                        qacc += __shfl_xor(qacc, 32);
+                        macc += __shfl_xor(macc, 16);
+                        macc += __shfl_xor(macc, 32);
+                        qtot += qacc;
+                        mtot += macc;
+                        qacc = 0.0;
+                        macc = 0.0;
+                    }
+                    buf = (buf == 2) ? 0 : buf + 1;
+                }
+            }
+        };
+        // The first pair is peeled: every later pair begins with a regular stage, whose top is where the hand-issued loads of
+        // the pair before are read back -- unconditionally, on every path the loop takes (scripts/check_hand_issued_loads.py).
+        diag_phase(0, std::true_type{});
+        for (int i0 = kPB; i0 < n; i0 += kPB) {
+            const int nst = i0 / kPKB;
+            regular_stage(i0, std::true_type{});
+            for (int j = 1; j < nst; ++j) regular_stage(i0, std::false_type{});
+            diag_phase(i0, std::false_type{});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the clamped tail DMA before the LDS goes away
+        __builtin_amdgcn_s_barrier();
+
+        if (SWEEP && H == 1 && kq == 0) {
+            q_out[colw + lc] = qtot;
+            mu_out[colw + lc] = mtot;
+        }
+    };
+    if (h == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+}
+
+// ------------------------------------------------------------------------------------------------
 // Right-looking companion of the strip kernel, used when the sweep is pipelined with the factorisation
 // (launch_cholesky with a SweepPipe): once rows [k0, k0 + klen) of U and of V are final, every row block below
 // them receives its share of the substitution,
@@ -1167,9 +1674,17 @@ void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const doubl
     // same bits).  Default: two waves per SIMD (trsm_strip8_kernel).
     static const int strip_form = [] {
         const char *e = getenv("CBO_HIP_STRIP_FORM");
-        return e ? atoi(e) : 8;
+        return e ? atoi(e) : 2;
     }();
     if (strip_form == 16) half_lds = true;            // (A/B timing: the half-LDS kernel, two workgroups per CU)
+    // 256-row pair blocks (trsm_pair_kernel) wherever the row count allows; CBO_HIP_STRIP_FORM=8 keeps trsm_strip8_kernel
+    if (!half_lds && strip_form != 4 && strip_form != 8 && n >= kPB && n % kPB == 0) {
+        if (q != nullptr)
+            hipLaunchKernelGGL((trsm_pair_kernel<true>), grid, dim3(512), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, acc);
+        else
+            hipLaunchKernelGGL((trsm_pair_kernel<false>), grid, dim3(512), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, 0);
+        return;
+    }
     if (!half_lds && strip_form != 4) {
 #ifdef CBO_DIAG_KNOBS
         static const int strip_mask = [] {

@@ -63,6 +63,8 @@ struct ScheduleEntry {
     int last_pairs = kSequence - 1, last_group = 0;   // the previous call's schedule (a call after a change is not sampled)
     bool group_tried = false, relooked = false;
     int retries = -1;                      // jitter retries of the shape's calls (calls with another count are not sampled)
+    int retry_mismatch = 0;                // SETTLED: consecutive calls that needed another number of retries than e.retries
+    uint64_t last_use = 0;                 // the table's call counter when the shape was last asked for (eviction)
     double fact_alone_us = 0.0, sweep_alone_us = 0.0;
     std::map<std::pair<int, int>, ScheduleSample> samples;   // (group, pairs) -> fastest of its calls
 };
@@ -73,6 +75,9 @@ struct ScheduleChoice { int pairs = kSequence, group = 0; bool sample = false; }
 constexpr double kScheduleGain = 0.003;    // a candidate replaces the current one when it is this much faster
 constexpr double kScheduleClose = 0.01;    // two candidates closer than this are sampled twice more before the decision
 constexpr int kScheduleMaxCalls = 96;      // exploration gives up (settles where it is) after this many calls of a shape
+constexpr int kScheduleMaxShapes = 64;     // shapes a context keeps; beyond it the one unused for longest goes
+constexpr int kScheduleRetryDrift = 3;     // a settled shape is measured afresh after this many consecutive calls whose
+                                           // jitter retries differ from the ones it was measured with
 
 static inline bool schedule_tune_enabled()
 {
@@ -152,14 +157,53 @@ static inline int schedule_first_split(int n_cu, int n_cu_pipe, const ScheduleEn
     }
     return pairs;
 }
+// Rates of the two halves of the plain sequence for a shape nothing has been measured on yet (round-4 measurements on
+// MI355X, DESIGN.md: the factorisation alone 54 / 92 / 232 us per 128-row panel at 4096 / 8192 / 16384 rows, 37 at 1024; the
+// strip kernel 2.2 us per 32-row stage and round of strips): what a call that may not be sampled -- it runs under the
+// library's profiling timers -- uses for its first split on a COLD shape instead of falling back to the plain sequence.
+static inline void schedule_default_rates(int n_cu, ScheduleEntry &e)
+{
+    const double n = (double)e.n_pad;
+    const double per_panel = n <= 1024.0 ? 37.0
+                             : n <= 4096.0 ? 37.0 + (54.0 - 37.0) * (n - 1024.0) / 3072.0
+                             : n <= 8192.0 ? 54.0 + (92.0 - 54.0) * (n - 4096.0) / 4096.0
+                                           : 92.0 + (232.0 - 92.0) * (n - 8192.0) / 8192.0;
+    const int nb = (int)(e.n_pad / 128);
+    const int rounds = (e.strips + n_cu - 1) / (n_cu > 0 ? n_cu : 1);
+    e.fact_alone_us = per_panel * nb;
+    e.sweep_alone_us = 2.2 * 2.0 * nb * (nb + 1) * (rounds > 0 ? rounds : 1);
+}
+static inline int schedule_first_split(int n_cu, int n_cu_pipe, const ScheduleEntry &e);
+static inline int schedule_snap(const ScheduleEntry &e, int group, int p, int dir);
+// the split of a call that cannot take part in the measurement, on a shape that has not been measured: analytic
+static inline ScheduleChoice schedule_static_choice(int n_cu, int n_cu_pipe, const ScheduleEntry &e)
+{
+    ScheduleEntry d = e;
+    if (d.fact_alone_us <= 0.0 || d.sweep_alone_us <= 0.0) schedule_default_rates(n_cu, d);
+    ScheduleChoice ch;
+    ch.group = e.group;
+    ch.pairs = schedule_snap(e, e.group, schedule_first_split(n_cu, n_cu_pipe, d), -1);
+    ch.sample = false;
+    return ch;
+}
+
 static inline ScheduleEntry &schedule_entry(ScheduleTable &table, int n_cu_pipe, int64_t n_pad, int64_t strips, int64_t m_pad)
 {
     auto key = std::make_pair(n_pad, m_pad);
+    uint64_t now = 0;
+    for (const auto &kv : table) if (kv.second.last_use > now) now = kv.second.last_use;
+    ++now;
     auto it = table.find(key);
-    if (it != table.end()) return it->second;
+    if (it != table.end()) { it->second.last_use = now; return it->second; }
+    if ((int)table.size() >= kScheduleMaxShapes) {          // a caller whose shapes never repeat: the table stays bounded
+        auto oldest = table.begin();
+        for (auto jt = table.begin(); jt != table.end(); ++jt) if (jt->second.last_use < oldest->second.last_use) oldest = jt;
+        table.erase(oldest);
+    }
     ScheduleEntry e;
     const int nb = (int)(n_pad / 128);
     e.n_pad = n_pad;
+    e.last_use = now;
     e.all_pairs = (nb + 1) / 2;
     e.strips = (int)strips;
     // (a full round of strips: the bulk stream bounds the pipeline, its updates go in groups -- to begin with)
@@ -189,12 +233,19 @@ static inline ScheduleEntry &schedule_entry(ScheduleTable &table, int n_cu_pipe,
     return table.emplace(key, e).first->second;
 }
 
-// what this call runs
-static inline ScheduleChoice schedule_choose(ScheduleEntry &e, bool may_sample)
+// what this call runs.  may_sample: the call's wall time means something (it does not run under the library's profiling
+// timers, which serialise the streams).  Whether the caller asks for the per-candidate outputs does not matter: every
+// candidate schedule of the shape pays the same copies.  A call that may not be sampled runs what is in force -- and on a
+// shape nothing is known about yet, the analytic first split (everything pipelined when the strips cannot fill the device),
+// not the plain sequence: a caller that is never sampled must not be left with fit-then-sweep for ever.
+static inline ScheduleChoice schedule_choose(ScheduleEntry &e, bool may_sample, int n_cu = 256, int n_cu_pipe = 224)
 {
     ScheduleChoice ch;
     const bool exploring = may_sample && e.state != ScheduleEntry::SETTLED;
-    if (e.state == ScheduleEntry::COLD || e.state == ScheduleEntry::SEQUENCE) { ch.pairs = kSequence; ch.group = e.group; }
+    if (e.state == ScheduleEntry::COLD || e.state == ScheduleEntry::SEQUENCE) {
+        if (!may_sample) return schedule_static_choice(n_cu, n_cu_pipe, e);
+        ch.pairs = kSequence; ch.group = e.group;
+    }
     else if (exploring) { ch.pairs = e.probe; ch.group = e.probe_group; }
     else { ch.pairs = e.cur; ch.group = e.group; }
     ch.sample = exploring;
@@ -295,6 +346,20 @@ static inline void schedule_look_around(ScheduleEntry &e)
 static inline void schedule_report(int n_cu, int n_cu_pipe, ScheduleEntry &e, const ScheduleChoice &ch, int retries, double ms,
                             double fact_us, double sweep_us)
 {
+    if (e.state == ScheduleEntry::SETTLED) {
+        // The schedule was measured at e.retries jitter retries per fit; a pipelined split repeats its pipeline with every
+        // retry.  When the data drift so that the fits keep needing another number, what was measured no longer describes
+        // the shape: start over (the next sampled calls time the plain sequence again).
+        if (retries >= 0 && e.retries >= 0 && retries != e.retries) {
+            if (++e.retry_mismatch >= kScheduleRetryDrift) {
+                const ScheduleEntry fresh;
+                e.state = ScheduleEntry::COLD; e.samples.clear(); e.calls = 0; e.retries = -1; e.retry_mismatch = 0;
+                e.cur = fresh.cur; e.probe = fresh.probe; e.probe_group = 0; e.group_tried = false; e.relooked = false;
+                e.fact_alone_us = 0.0; e.sweep_alone_us = 0.0; e.last_pairs = fresh.last_pairs;
+            }
+        } else if (retries >= 0) e.retry_mismatch = 0;
+        return;
+    }
     if (!ch.sample) { e.last_pairs = kSequence - 1; return; }    // (an unsampled call in between: the next one is a change)
     ++e.calls;
     const bool changed = ch.pairs != e.last_pairs || (ch.pairs > 0 && ch.group != e.last_group);
