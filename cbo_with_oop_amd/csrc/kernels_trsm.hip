@@ -1010,6 +1010,12 @@ __global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict
     __shared__ __align__(16) double zl[SWEEP ? 2 * kPB : 2];           // z rows of the current and the next pair
     __shared__ __align__(16) double handbuf[SWEEP ? 4 * 64 * 2 : 2];   // (q, mu) lane partials, (cw, 0) -> (cw, 1)
 
+#ifdef CBO_DIAG_KNOBS
+    // timing-only (CBO_HIP_STRIP_MASK=256, diagnostic build): waves 0 and 4 of workgroup 0 stamp every stage -- slot 0 the
+    // stage top passed, 1 the solved tile published / final, 2 the stage's last instruction issued (scripts/pair_timeline.py)
+    const int dmask = accumulate >> 8;
+    accumulate &= 1;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform: LDS bases stay scalar
@@ -1105,15 +1111,20 @@ __global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict
         // (scalar base + 32-bit lane offset: one vector register of addressing for all of them)
         const unsigned vq_off = (unsigned)(((int64_t)kq * ldv + lc) * 8);
         const unsigned z_off = (unsigned)(lane * 16);
-        auto request_ahead = [&](int i0) __attribute__((always_inline)) {
+        // in three batches, one per stage of D1's first three (a burst of all of them at once waits for slots in the memory
+        // pipeline behind the DMA ring's ten instructions: 2900 cycles of the solver's stage in the first timeline)
+        // one at a time, each behind an MFMA of the solver (or a pause of the idle wave): a burst of them at a stage top waits
+        // for room in the CU's memory pipeline behind the DMA ring -- 2300-2900 cycles per burst, of 11 or of 33, in the first
+        // timelines.  D1's first stage issues kL0 of them, its second the rest, both AFTER the stage's DMA: the top of D1's
+        // fourth stage retires the first lot, the first top of the next pair the second.
+        constexpr int kL0 = 16, kL1 = kAhead - kL0;
+        auto request_one = [&](int i0, int sl) __attribute__((always_inline)) {
             const int nb = (i0 + kPB < n) ? i0 + kPB : i0;               // (the last pair asks for its own rows again: no branch)
             const double *vb = V + colw + (int64_t)(nb + kRB * H) * ldv;   // wave-uniform
-#pragma unroll
-            for (int t = 0; t < kT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(accn[t][r]) : "v"(vq_off), "s"(vb + (int64_t)(16 * t + 4 * r) * ldv) : "memory");
-            if (SWEEP) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(zn) : "v"(z_off), "s"(z + nb + kRB * H) : "memory");
+            if (sl < kT * 4)
+                asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(accn[sl >> 2][sl & 3]) : "v"(vq_off), "s"(vb + (int64_t)(4 * sl) * ldv) : "memory");
+            else if (SWEEP)
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(zn) : "v"(z_off), "s"(z + nb + kRB * H) : "memory");
         };
 
         locate_a(ahead);
@@ -1135,6 +1146,20 @@ __global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict
         // what is younger than its last instruction may still be in flight: what stage k-2 issued after its DMA (a2: the
         // solver's V stores), and all of stage k-1 -- what it issued ahead of its DMA (b1: the hand-issued loads), the DMA, what
         // it issued after (a1).
+#ifdef CBO_DIAG_KNOBS
+        const bool stamp_on = SWEEP && (dmask & 256) && blockIdx.x == 0 && lane == 0 && cw == 0;
+        int stamp_i = 0;
+#define PSTAMP(slot)                                                                                       \
+        do {                                                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            if (stamp_on && stamp_i < 4096) g_trsm_stamps[8 * stamp_i + 4 * H + (slot)] = __builtin_amdgcn_s_memtime(); \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+        } while (0)
+#define PSTAMP_NEXT() do { if (stamp_on) ++stamp_i; } while (0)
+#else
+#define PSTAMP(slot)
+#define PSTAMP_NEXT()
+#endif
         int a1 = 0, b1 = 0, a2 = 0;
         auto wait_top = [&]() __attribute__((always_inline)) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1144,10 +1169,12 @@ __global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict
             else WAIT_IF(4);
             else WAIT_IF(8);
             else WAIT_IF(16);
-            else WAIT_IF(kAhead);
-            else WAIT_IF(kAhead + 4);
-            else WAIT_IF(kAhead + 8);
-            else WAIT_IF(kAhead + 16);
+            else WAIT_IF(kL1);
+            else WAIT_IF(kL0 + 4);
+            else WAIT_IF(kL0 + 8);
+            else WAIT_IF(kL0 + kL1);
+            else WAIT_IF(kL1 + 16);
+            else WAIT_IF(kL0 + kL1 + 16);
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPDma) : "memory");       // (any other count: the strict wait)
 #undef WAIT_IF
             __builtin_amdgcn_s_barrier();
@@ -1155,8 +1182,9 @@ __global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict
             a2 = a1;
             a1 = 0;
             b1 = 0;
+            PSTAMP(0);
         };
-        static_assert(kPDma + kAhead + 16 <= 63, "s_waitcnt vmcnt is a 6-bit count");
+        static_assert(kPDma + kL0 + kL1 + 16 <= 63 && kL1 >= kL0, "s_waitcnt vmcnt is a 6-bit count; the cases of wait_top");
 
         double af[2][kT], bf[2];
         // ---- regular stages: U rows [16 j, 16 j + 16) against the pair's 256 columns; the last k-step's MFMAs are issued
@@ -1215,7 +1243,7 @@ __global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            buf = (buf == 2) ? 0 : buf + 1;                   // the last k-step sits in af[1], bf[1]
+            PSTAMP(2); PSTAMP_NEXT(); buf = (buf == 2) ? 0 : buf + 1;                   // the last k-step sits in af[1], bf[1]
         };
         // the diagonal phase of the pair at i0; P0: the first pair, which has no regular stage before it (nothing deferred)
         auto diag_phase = [&](int i0, auto first_pair_tag) __attribute__((always_inline)) {
@@ -1233,6 +1261,7 @@ __global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict
                     const double *abase0 = lds + buf * kPA + kq * kPLd + lc;              // U tile of the stage, all 256 columns
                     double *xreg = ldsB + buf * kPBd + cw * 256;                          // the inverse in, the solved tile out
                     double iv[4], uf[kT][4], zr[4];
+                    __builtin_amdgcn_s_setprio(2);          // the solve is the stage's serial head: ahead of (cw, 1)'s deferred MFMAs
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) iv[kk] = xreg[(4 * kk + kq) * 16 + lc];
                     // the regular stages' deferred k-step: the tile about to be solved first
@@ -1247,6 +1276,19 @@ __global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict
                     x = MFMA_F64(iv[2], -acc[m][2], x);
                     x2 = MFMA_F64(iv[3], -acc[m][3], x2);
                     __builtin_amdgcn_sched_barrier(0);
+                    x += x2;
+                    asm volatile("" : "+v"(x));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xreg[(kq + 4 * r) * 16 + lc] = x[r];      // B-operand layout [row][column]
+                    PSTAMP(3);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                                       // (cw, 1) may read x now
+                    __builtin_amdgcn_s_setprio(0);
+                    PSTAMP(1);
+                    // Its own U fragments only now: the eight waves read the whole 16 x 256 tile once per column group in this
+                    // stage -- 128 KB, a thousand cycles of the LDS -- and ahead of the publication those reads were the stage's
+                    // serial head (1400-2300 cycles from the stage top to this barrier in the first timeline, (cw, 1) waiting).
+                    // The two tiles of the dependent chain first.
 #pragma unroll
                     for (int t = m + 1; t < kT; ++t)
 #pragma unroll
@@ -1255,13 +1297,6 @@ __global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict
 #pragma unroll
                         for (int r = 0; r < 4; ++r) zr[r] = zl[zpar + 16 * m + kq + 4 * r];
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                    x += x2;
-                    asm volatile("" : "+v"(x));
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) xreg[(kq + 4 * r) * 16 + lc] = x[r];      // B-operand layout [row][column]
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();                                       // (cw, 1) may read x now
                     // the next tile's update is a chain of four dependent MFMAs: the stage's DMA issue and the cursor
                     // arithmetic sit in its gaps, ahead of the stage's V stores (as the stage-top accounting assumes)
 #pragma unroll
@@ -1277,7 +1312,9 @@ __global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        Vq[(int64_t)(i0 + 16 * m + 4 * r) * ldv] = x[r];
+                        // (scalar row base + the lane's 32-bit offset: no vector address arithmetic next to the MFMAs, which
+                        // an fp64 MFMA in flight would hold up)
+                        asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(vq_off), "v"(x[r]), "s"(V + colw + (int64_t)(i0 + 16 * m + 4 * r) * ldv) : "memory");
                         if (SWEEP) {
                             qacc = fma(x[r], x[r], qacc);
                             macc = fma(x[r], zr[r], macc);
@@ -1297,19 +1334,23 @@ __global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict
                         qacc = 0.0;
                         macc = 0.0;
                     }
-                    buf = (buf == 2) ? 0 : buf + 1;
+                    PSTAMP(2); PSTAMP_NEXT(); buf = (buf == 2) ? 0 : buf + 1;
                 }
 #pragma unroll
                 for (int m = 0; m < kPD1; ++m) {
                     wait_top();
                     const int bnext = (buf >= 1) ? buf - 1 : 2;
-                    if (m == 0) {
-                        request_ahead(i0);
-                        b1 += kAhead;
-                    }
                     issue_stage(ahead, bnext);
                     advance(ahead);
-                    buf = (buf == 2) ? 0 : buf + 1;
+                    if (m < 2) {                    // nothing else to do in D1: its next block's right-hand sides, unhurried
+#pragma unroll
+                        for (int sl = (m == 0 ? 0 : kL0); sl < (m == 0 ? kL0 : kAhead); ++sl) {
+                            request_one(i0, sl);
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                        a1 += m == 0 ? kL0 : kL1;
+                    }
+                    PSTAMP(2); PSTAMP_NEXT(); buf = (buf == 2) ? 0 : buf + 1;
                 }
             } else {
 #pragma unroll
@@ -1326,22 +1367,34 @@ __global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) uf[t][kk] = abase0[(4 * kk) * kPLd + kRB + 16 * t];
                     }
-                    issue_stage(ahead, bnext);
-                    advance(ahead);
+                    PSTAMP(3);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();                                       // x is published
+                    PSTAMP(1);
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) xb[kk] = xreg[(4 * kk + kq) * 16 + lc];
+                    // the stage's DMA issue and the cursor arithmetic ride behind the fold's MFMAs, one piece each (ahead of the
+                    // mid-stage barrier they made this wave the last to arrive: 1365 cycles after the stage top against the
+                    // solver's 530, second timeline)
 #pragma unroll
                     for (int kk = 0; kk < (m + 1 < kPD0 ? 3 : 4); ++kk)
 #pragma unroll
-                        for (int t = 0; t < kT; ++t) acc[t] = MFMA_F64(uf[t][kk], xb[kk], acc[t]);
+                        for (int t = 0; t < kT; ++t) {
+                            acc[t] = MFMA_F64(uf[t][kk], xb[kk], acc[t]);
+                            const int slot = kk * kT + t;
+                            if (slot < kPDma) issue_one(ahead, bnext, slot);
+                            else if (slot == kPDma) step(ahead);
+                            else if (slot == kPDma + 1) locate_a(ahead);
+                            else if (slot == kPDma + 2) locate_b(ahead);
+                            else if (slot == kPDma + 3) locate_c(ahead);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     if (m + 1 < kPD0) {
 #pragma unroll
                         for (int t = 0; t < kT; ++t) af[1][t] = uf[t][3];               // k-step 3: behind the next stage top
                         bf[1] = xb[3];
                     }
-                    buf = (buf == 2) ? 0 : buf + 1;
+                    PSTAMP(2); PSTAMP_NEXT(); buf = (buf == 2) ? 0 : buf + 1;
                 }
 #pragma unroll
                 for (int m = 0; m < kPD1; ++m) {
@@ -1355,10 +1408,6 @@ __global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict
                     if (SWEEP && m == 0) {                                        // take over the running lane partials
                         qacc = hand[0];
                         macc = hand[1];
-                    }
-                    if (m == 2) {
-                        request_ahead(i0);
-                        b1 += kAhead;
                     }
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) iv[0][kk] = ivb[(4 * kk) * 16];
@@ -1383,10 +1432,11 @@ __global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict
                     __builtin_amdgcn_sched_barrier(0);
                     x += x2;
                     asm volatile("" : "+v"(x));
+                    PSTAMP(1);
                     auto emit = [&](int hh, const d4 &xx) __attribute__((always_inline)) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            Vq[(int64_t)(i0 + kRB + 16 * (s + hh) + 4 * r) * ldv] = xx[r];
+                            asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(vq_off), "v"(xx[r]), "s"(V + colw + (int64_t)(i0 + kRB + 16 * (s + hh) + 4 * r) * ldv) : "memory");
                             if (SWEEP) {
                                 qacc = fma(xx[r], xx[r], qacc);
                                 macc = fma(xx[r], zr[hh][r], macc);
@@ -1413,7 +1463,10 @@ __global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict
                         if (kk & 1) y2 = MFMA_F64(iv[1][kk], na[kk], y2);
                         else y1 = MFMA_F64(iv[1][kk], na[kk], y1);
 #pragma unroll
-                        for (int t = s + 3; t < kT; ++t) acc[t] = MFMA_F64(uf[0][t][kk], x[kk], acc[t]);
+                        for (int t = s + 3; t < kT; ++t) {
+                            acc[t] = MFMA_F64(uf[0][t][kk], x[kk], acc[t]);
+                            if (SWEEP && m == 1 && kk == 0 && t == s + 3) request_one(i0, kT * 4);      // (the z rows)
+                        }
                     }
                     // (the second tile's U fragments only now: the wave is alone on its SIMD's registers' worth of operands, and
                     // one LDS round trip per stage is what that costs)
@@ -1423,11 +1476,17 @@ __global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict
                         for (int kk = 0; kk < 4; ++kk) uf[1][t][kk] = ab[(4 * kk) * kPLd + kRB + 16 * t];
                     const d4 y = y1 + y2;
                     emit(1, y);
+                    // the next pair's right-hand sides, one load behind each of these MFMAs in the first two stages (24 and 16 of
+                    // them): sixteen loads each
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                        for (int t = s + 2; t < kT; ++t) acc[t] = MFMA_F64(uf[1][t][kk], y[kk], acc[t]);
-                    a1 += 8;
+                        for (int t = s + 2; t < kT; ++t) {
+                            acc[t] = MFMA_F64(uf[1][t][kk], y[kk], acc[t]);
+                            const int idx = kk * (kT - s - 2) + (t - s - 2);
+                            if (m < 2 && idx < 16) request_one(i0, 16 * m + idx);
+                        }
+                    a1 += 8 + (m == 0 ? kL0 : m == 1 ? kL1 : 0);
                     if (SWEEP && m == kPD1 - 1) {                                 // end of the pair: reduce over the lane groups, add
                         qacc += __shfl_xor(qacc, 16);
                         qacc += __shfl_xor(qacc, 32);
@@ -1438,7 +1497,7 @@ __global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict
                         qacc = 0.0;
                         macc = 0.0;
                     }
-                    buf = (buf == 2) ? 0 : buf + 1;
+                    PSTAMP(2); PSTAMP_NEXT(); buf = (buf == 2) ? 0 : buf + 1;
                 }
             }
         };
@@ -1461,6 +1520,8 @@ __global__ __launch_bounds__(512) void trsm_pair_kernel(const double *__restrict
     };
     if (h == 0) run(std::integral_constant<int, 0>{});
     else run(std::integral_constant<int, 1>{});
+#undef PSTAMP
+#undef PSTAMP_NEXT
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1679,6 +1740,13 @@ void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const doubl
     if (strip_form == 16) half_lds = true;            // (A/B timing: the half-LDS kernel, two workgroups per CU)
     // 256-row pair blocks (trsm_pair_kernel) wherever the row count allows; CBO_HIP_STRIP_FORM=8 keeps trsm_strip8_kernel
     if (!half_lds && strip_form != 4 && strip_form != 8 && n >= kPB && n % kPB == 0) {
+#ifdef CBO_DIAG_KNOBS
+        static const int pair_mask = [] {
+            const char *e = getenv("CBO_HIP_STRIP_MASK");
+            return e ? atoi(e) : 0;
+        }();
+        const int acc = (accumulate ? 1 : 0) | (pair_mask << 8);
+#endif
         if (q != nullptr)
             hipLaunchKernelGGL((trsm_pair_kernel<true>), grid, dim3(512), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, acc);
         else
