@@ -1798,6 +1798,10 @@ void launch_gemm_update(hipStream_t s, const double *U, int64_t ldu, const doubl
     const unsigned chunks = (unsigned)((i0_end - i0_begin + chunk_rows - 1) / chunk_rows);
     const dim3 grid((unsigned)(m_pad / kStrip), chunks);
     const int up = upper_only ? 1 : 0;
+    // (Round 5: the same update on trsm_pair_kernel's regular stages -- one 512-thread workgroup per CU on 256-row pairs,
+    // hand-issued loads of the next pair's C tile -- gave the same bits and lost in place: C2 step 5.40 -> 5.48 ms, the
+    // 16384-point factorisation 29.5 -> 32.6 ms, worse with more pairs per workgroup (profiles/r05_update_pair_ab.txt):
+    // a workgroup that fills a CU leaves the factorisation's chain no slot beside it.  Removed.)
     // (A two-waves-per-SIMD form of this kernel, rows split over a wave pair as in trsm_strip8_kernel, was measured in
     // round 3 and dropped: its K-loops are only 4-8 stages long between C moves, and two independent half-LDS workgroups
     // per CU hide those block boundaries better -- 16384-point factorisation 32.0 ms with KB = 16 x 2 workgroups,
