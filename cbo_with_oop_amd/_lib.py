@@ -261,7 +261,7 @@ class Context:
         buf = ctypes.create_string_buffer(1 << 16)
         n = load().cbo_schedule_report(self.handle, buf, len(buf))
         if n < 0:
-            check(-n)
+            check(n)
         return n, buf.value.decode()
 
     def set_profiling(self, enabled):

@@ -1570,6 +1570,8 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
     } else {
         entry = &schedule_entry(c->schedule, c->n_cu_pipe, g->n_pad, k->m_pad / kStrip, k->m_pad);
         choice = schedule_choose(*entry, !c->profiling, c->n_cu, c->n_cu_pipe);
+        entry->ran_pairs = choice.pairs;
+        entry->ran_group = choice.pairs > 0 ? choice.group : 0;
     }
     if (choice.pairs == kSequence) {
         int tries = 0;
@@ -1917,6 +1919,8 @@ extern "C" int cbo_trial_step(int n_sets, cbo_gp *const *gps, cbo_cands *const *
     if (n_sets <= 0 || !gps || !chosen_out) return fail(CBO_ERR_INVALID, "bad argument");
     if (refit_set >= n_sets) return fail(CBO_ERR_INVALID, "refit_set out of range");
     int staged = -1;
+    int64_t prev_n = 0;
+    bool prev_fitted = false;
     if (refit_set >= 0) {
         cbo_gp *g = gps[refit_set];
         if (!g) return fail(CBO_ERR_INVALID, "gp is NULL");
@@ -1936,6 +1940,9 @@ extern "C" int cbo_trial_step(int n_sets, cbo_gp *const *gps, cbo_cands *const *
             if (gps[i]->ctx != c) return fail(CBO_ERR_INVALID, "all sets must live on one context");
             if (i != refit_set && (gps[i]->n <= 0 || gps[i]->n_pad <= 0)) return fail(CBO_ERR_INVALID, "a gp holds no data");
             if (gps[i]->dtype == CBO_DTYPE_F64 && gps[i]->n_pad == kPadN && (cands[i]->m + 63) / 64 > 65535) fuse = false;
+            // the same model in two sets: the other copy's workgroups would read the resident arrays while the staged set's
+            // first workgroup rewrites them in the same launch -- the plain upload first, then the sweep
+            if (i != refit_set && gps[i] == g) fuse = false;
         }
         if (fuse) {
             HIP_TRY(hipSetDevice(c->device));
@@ -1949,6 +1956,8 @@ extern "C" int cbo_trial_step(int n_sets, cbo_gp *const *gps, cbo_cands *const *
                 std::memcpy(sb + n * g->d + 2 * n, pv, sizeof(double) * n);
                 g->h_pv.assign(pv, pv + n);
             }
+            prev_n = g->n;
+            prev_fitted = g->fitted;
             g->n = n;
             g->X.n = n;
             g->fitted = false;
@@ -1959,16 +1968,32 @@ extern "C" int cbo_trial_step(int n_sets, cbo_gp *const *gps, cbo_cands *const *
         }
     }
     int rc = sweep_sets_impl(n_sets, gps, cands, y_best, task, ei_jitter, costs, best_vals, best_idxs, staged);
+    if (rc != CBO_OK && staged >= 0) {
+        // The launch that was to carry the new data into the resident arrays failed (or was never queued): the host-side
+        // state already describes the new data, the device arrays may hold either.  Finish the upload from the staging
+        // buffer by the plain path -- it is the caller's data either way -- so that model and arrays agree again; if even
+        // that fails the model is marked as holding nothing (n = 0: every later call refuses it until new data arrive).
+        cbo_gp *g = gps[staged];
+        const int up = cbo_gp_upload_data(g, n, X, y, pm, pv);
+        if (up != CBO_OK) {
+            g->n = 0;
+            g->X.n = 0;
+            g->fitted = false;
+            (void)prev_n;
+            (void)prev_fitted;
+        }
+        return rc;
+    }
     if (rc != CBO_OK) return rc;
     return cbo_argmax_sets(best_vals, n_sets, chosen_out);
 }
 
 // What the context has measured and chosen for cbo_gp_fit_sweep, one line per shape, as text (scripts/schedule_scan.py,
 // profiles/r04_schedule_crossover.txt).  Returns the number of shapes still exploring (0 = every schedule is settled), or a
-// negative error code; `buf` may be NULL (only the count is wanted).
+// CBO_ERR_* code (they are negative); `buf` may be NULL (only the count is wanted).
 extern "C" int cbo_schedule_report(cbo_ctx *c, char *buf, int64_t cap)
 {
-    if (!c) return -fail(CBO_ERR_INVALID, "ctx is NULL");
+    if (!c) return fail(CBO_ERR_INVALID, "ctx is NULL");      // (CBO_ERR_* codes are negative as they are)
     static const char *names[] = {"cold", "sequence", "base", "neighbours", "climb", "grouping", "settled"};
     std::string out;
     int exploring = 0;
@@ -1979,11 +2004,13 @@ extern "C" int cbo_schedule_report(cbo_ctx *c, char *buf, int64_t cap)
         const int nb = (int)(kv.first.first / 128);
         const double rounds = std::ceil((double)e.strips / c->n_cu);
         std::snprintf(line, sizeof(line), "rows %lld candidates %lld: %s after %d calls; pairs %d of %d (%s), updates %s; "
+                      "last call ran pairs %d group %d; "
                       "measured alone: factorisation %.0f us = %.1f us/panel, sweep %.0f us = %.2f us/stage and round;",
                       (long long)kv.first.first, (long long)kv.first.second, names[(int)e.state], e.calls, e.cur, e.all_pairs,
                       e.cur < 0 ? "the plain sequence" : e.cur == 0 ? "overlapped, nothing pipelined" :
                       e.cur == e.all_pairs ? "everything pipelined" : "then one left-looking launch",
-                      e.group >= 2 ? "in groups of two pairs" : "pair by pair", e.fact_alone_us, nb ? e.fact_alone_us / nb : 0.0,
+                      e.group >= 2 ? "in groups of two pairs" : "pair by pair", e.ran_pairs, e.ran_group, e.fact_alone_us,
+                      nb ? e.fact_alone_us / nb : 0.0,
                       e.sweep_alone_us, nb ? e.sweep_alone_us / (rounds * 2.0 * nb * (nb + 1)) : 0.0);
         out += line;
         for (const auto &sv : e.samples) {

@@ -13,10 +13,12 @@
 // takes per panel, how fast its strips go and how the two slow each other down when they share CUs -- rounds 2 and 3
 // fitted a budget curve through three measured shapes (and a row cut-off, and a grouping rule).  Now every shape
 // (padded rows, padded candidates) of a context is measured on the calls the caller makes anyway:
-//   1. two calls run the plain sequence (cbo_gp_fit, then cbo_acq_sweep) and time its two halves: the factorisation
-//      alone (chain us / panel) and the sweep alone (strip us / stage);
-//   2. the first split is the largest number of pairs whose pipeline -- its share of the sweep's strip stages at the
-//      measured rate, on the CUs the sweep streams may use -- ends no later than the factorisation alone would;
+//   1. the first call of a shape runs the analytic split: the largest number of pairs whose pipeline -- its share of the
+//      sweep's strip stages, on the CUs the sweep streams may use -- ends no later than the factorisation alone would, at
+//      the rates round 4 measured on this device (schedule_default_rates); everything pipelined when the strips cannot
+//      fill the device.  (Round 4 timed the plain sequence twice first: a fresh context's first calls, and every call of a
+//      caller whose calls are never sampled, then ran fit-then-sweep.)
+//   2. whenever the climb measures the plain sequence itself, the times of its halves refine those rates;
 //   3. from there the split climbs on the measured time of the calls themselves: neighbours first, doubling steps while
 //      they pay, single steps to finish; the candidates are the plain sequence, the overlapped call with an empty pipeline,
 //      and the multiples of a pair (or of a group of pairs) up to everything pipelined.  A candidate's time is the
@@ -65,6 +67,7 @@ struct ScheduleEntry {
     int retries = -1;                      // jitter retries of the shape's calls (calls with another count are not sampled)
     int retry_mismatch = 0;                // SETTLED: consecutive calls that needed another number of retries than e.retries
     uint64_t last_use = 0;                 // the table's call counter when the shape was last asked for (eviction)
+    int ran_pairs = kSequence, ran_group = 0;   // what the shape's last call ran (cbo_schedule_report: tests assert it)
     double fact_alone_us = 0.0, sweep_alone_us = 0.0;
     std::map<std::pair<int, int>, ScheduleSample> samples;   // (group, pairs) -> fastest of its calls
 };
@@ -242,9 +245,13 @@ static inline ScheduleChoice schedule_choose(ScheduleEntry &e, bool may_sample, 
 {
     ScheduleChoice ch;
     const bool exploring = may_sample && e.state != ScheduleEntry::SETTLED;
-    if (e.state == ScheduleEntry::COLD || e.state == ScheduleEntry::SEQUENCE) {
-        if (!may_sample) return schedule_static_choice(n_cu, n_cu_pipe, e);
-        ch.pairs = kSequence; ch.group = e.group;
+    if (e.state == ScheduleEntry::COLD) {
+        // nothing is known about the shape: the analytic split (round 5; round 4 ran the plain sequence twice here to time its
+        // halves, which left a fresh context's first calls -- and every call of a caller that is never sampled -- with
+        // fit-then-sweep).  A sampled call then starts the climb from it.
+        ch = schedule_static_choice(n_cu, n_cu_pipe, e);
+        ch.sample = may_sample;
+        return ch;
     }
     else if (exploring) { ch.pairs = e.probe; ch.group = e.probe_group; }
     else { ch.pairs = e.cur; ch.group = e.group; }
@@ -364,7 +371,14 @@ static inline void schedule_report(int n_cu, int n_cu_pipe, ScheduleEntry &e, co
     ++e.calls;
     const bool changed = ch.pairs != e.last_pairs || (ch.pairs > 0 && ch.group != e.last_group);
     e.last_pairs = ch.pairs; e.last_group = ch.group;
-    if (e.state == ScheduleEntry::COLD) { e.state = ScheduleEntry::SEQUENCE; return; }   // (allocations, code loading)
+    if (e.state == ScheduleEntry::COLD) {                        // (allocations, code loading: the call itself is not sampled)
+        e.cur = ch.pairs;
+        if (ch.pairs > 0) e.group = ch.group;
+        if (!schedule_tune_enabled()) { e.state = ScheduleEntry::SETTLED; schedule_probe(e, e.group, e.cur); return; }
+        e.state = ScheduleEntry::BASE;
+        schedule_probe(e, e.group, e.cur);
+        return;
+    }
     if (e.calls > kScheduleMaxCalls) { schedule_settle(e); return; }
     if (changed || retries < 0) return;    // the first call of a schedule pays for the change
     if (e.retries < 0) e.retries = retries;
@@ -385,6 +399,12 @@ static inline void schedule_report(int n_cu, int n_cu_pipe, ScheduleEntry &e, co
             return;
         case ScheduleEntry::BASE:
             if (!schedule_tune_enabled()) { schedule_settle(e); return; }
+            // the plain sequence is measured once, right behind the first split: what the climb settles on is the fastest of
+            // everything measured, and where the sequence wins by far (fits that retry with jitter repeat a pipelined
+            // split's pipeline every time) the climb starts next to it instead of walking down to it
+            if (schedule_ms(e, 0, kSequence) > 1e299) { schedule_probe(e, e.group, kSequence); return; }
+            if (schedule_ms(e, e.group, e.cur) > 1e299) { schedule_probe(e, e.group, e.cur); return; }
+            if (e.cur > 0 && schedule_ms(e, 0, kSequence) < 0.7 * schedule_ms(e, e.group, e.cur)) e.cur = 0;
             e.up = schedule_next(e, e.group, e.cur, +1, 1);
             e.down = schedule_next(e, e.group, e.cur, -1, 1);
             schedule_neighbours(e);

@@ -246,7 +246,8 @@ int cbo_acq_sweep_sets(int n_sets, cbo_gp *const *gps, cbo_cands *const *cands, 
  * splits of the sweep between the pipeline under the factorisation and the closing launch -- and keeps the fastest
  * (cbo_api.hip, schedule_choose / schedule_report; results are the same bits whatever the schedule).  This call writes
  * what was measured and chosen, one text line per shape, into buf (NUL-terminated, truncated to cap; buf may be NULL)
- * and returns the number of shapes still exploring (0 = all settled), or a negated CBO_ERR_* code.
+ * and returns the number of shapes still exploring (0 = all settled), or a CBO_ERR_* code (negative as they are).  Every
+ * line also says what the shape's last call ran ("last call ran pairs P group G", P = -1: the plain sequence).
  * No reference counterpart: the reference's loop (src/CBO.py:143-173) has no device schedule to choose. */
 int cbo_schedule_report(cbo_ctx *ctx, char *buf, int64_t cap);
 

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
 #include "schedule_tuner.h"
 
 static double step_ms(int curve, const ScheduleEntry &e, int group, int pairs)
@@ -29,8 +30,57 @@ static double step_ms(int curve, const ScheduleEntry &e, int group, int pairs)
     }
 }
 
+// "unsampled n_pad m_pad n_cu n_cu_pipe": a caller none of whose calls may be sampled (it runs under the library's profiling
+// timers) on a shape nothing is known about: every call must run the analytic split, never the plain sequence; prints
+// "<pairs> <group> <all_pairs> <state>" of the 1st and the 30th call.
+// "drift ...": a settled shape whose fits start needing another number of jitter retries is measured afresh after
+// kScheduleRetryDrift such calls in a row; prints "<state before> <state after two> <state after three> <state after a sampled call>".
+// "bounded": more shapes than kScheduleMaxShapes leave the table at its bound; prints the table's size.
+static int special(int argc, char **argv)
+{
+    const std::string mode = argv[1];
+    if (mode == "bounded") {
+        ScheduleTable table;
+        for (int i = 0; i < 3 * kScheduleMaxShapes; ++i) schedule_entry(table, 224, 1024 + 128 * i, 256, 16384);
+        std::printf("%d\n", (int)table.size());
+        return 0;
+    }
+    if (argc < 6) return 2;
+    const int64_t n_pad = std::atoll(argv[2]), m_pad = std::atoll(argv[3]);
+    const int n_cu = std::atoi(argv[4]), n_cu_pipe = std::atoi(argv[5]);
+    ScheduleTable table;
+    ScheduleEntry &e = schedule_entry(table, n_cu_pipe, n_pad, m_pad / 64, m_pad);
+    if (mode == "unsampled") {
+        for (int call = 0; call < 30; ++call) {
+            const ScheduleChoice ch = schedule_choose(e, false, n_cu, n_cu_pipe);
+            if (call == 0 || call == 29) std::printf("%d %d %d %d\n", ch.pairs, ch.group, e.all_pairs, (int)e.state);
+            schedule_report(n_cu, n_cu_pipe, e, ch, 0, 5.0, 0.0, 0.0);
+        }
+        return 0;
+    }
+    if (mode == "drift") {
+        int calls = 0;
+        while (e.state != ScheduleEntry::SETTLED && calls++ < 400) {
+            const ScheduleChoice ch = schedule_choose(e, true, n_cu, n_cu_pipe);
+            schedule_report(n_cu, n_cu_pipe, e, ch, 0, step_ms(0, e, ch.group, ch.pairs), ch.pairs < 0 ? 1700.0 : 0.0, ch.pairs < 0 ? 5100.0 : 0.0);
+        }
+        const int s0 = (int)e.state;
+        int st[3];
+        for (int k = 0; k < 3; ++k) {
+            const ScheduleChoice ch = schedule_choose(e, true, n_cu, n_cu_pipe);
+            schedule_report(n_cu, n_cu_pipe, e, ch, 1, 9.0, 0.0, 0.0);            // the fits now retry once
+            st[k] = (int)e.state;
+        }
+        const ScheduleChoice ch = schedule_choose(e, true, n_cu, n_cu_pipe);
+        std::printf("%d %d %d %d\n", s0, st[1], st[2], ch.pairs);
+        return 0;
+    }
+    return 2;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 2 && (argv[1][0] < '0' || argv[1][0] > '9')) return special(argc, argv);
     if (argc < 8) return 2;
     const int64_t n_pad = std::atoll(argv[1]), m_pad = std::atoll(argv[2]);
     const int n_cu = std::atoi(argv[3]), n_cu_pipe = std::atoi(argv[4]), curve = std::atoi(argv[5]);

@@ -237,8 +237,22 @@ def test_schedule_tuner_settles_near_the_best_candidate_on_a_simulated_device(tm
                 assert settled == 1 and calls <= 97, (curve, n_pad, m_pad, seed, out)
                 assert chosen <= best * 1.016, (curve, n_pad, m_pad, seed, out)
     # a shape next to a settled one starts from that one's split (same fraction of the pairs), not from the plain sequence;
-    # a shape far away starts cold (the two timing calls of the plain sequence)
+    # a shape far away starts from the analytic split (round 4: from two timing calls of the plain sequence)
     near = subprocess.check_output([str(exe), "4096", "16384", "256", "224", "0", "0.01", "1", "24576"], text=True).split()
     assert int(near[0]) == 4 and int(near[2]) == 16, near                     # 4 of 16 pairs, as settled at 16384 candidates
     far = subprocess.check_output([str(exe), "4096", "16384", "256", "224", "0", "0.01", "1", "262144"], text=True).split()
-    assert int(far[0]) == -1, far
+    assert int(far[0]) == 0, far              # 4096 strips in 17 rounds: not one pair's pipeline fits beside the factorisation
+    # a caller that is never sampled (every call under the profiling timers) on a shape nothing is known about runs the
+    # analytic split from its first call to its thirtieth -- not the plain sequence (round 4's tuner left such a caller with
+    # fit-then-sweep for ever); with fewer strips than CUs that split is "everything pipelined"
+    first, last = (l.split() for l in subprocess.check_output([str(exe), "unsampled", "4096", "16384", "256", "224"], text=True).splitlines())
+    assert first == last and 1 <= int(first[0]) < int(first[2]) and int(first[3]) == 0, (first, last)   # some pairs of 16, still COLD
+    first, last = (l.split() for l in subprocess.check_output([str(exe), "unsampled", "4096", "4096", "256", "224"], text=True).splitlines())
+    assert first == last and int(first[0]) == int(first[2]) == 16, (first, last)                        # 64 strips: all 16 pairs
+    # a settled shape whose fits begin to need another number of jitter retries is measured afresh after three such calls
+    # (a pipelined split repeats its pipeline with every retry): SETTLED (6), still SETTLED after two, COLD (0) after the
+    # third, and the next call starts over from the analytic split (the sequence is timed again right behind it)
+    drift = subprocess.check_output([str(exe), "drift", "4096", "16384", "256", "224"], text=True).split()
+    assert drift[:3] == ["6", "6", "0"] and int(drift[3]) >= 1, drift
+    # the per-context table of shapes is bounded
+    assert int(subprocess.check_output([str(exe), "bounded"], text=True)) == 64

@@ -279,6 +279,9 @@ def test_full_size_properties(hip):
     assert fused["best_idx"] == full["best_idx"] and fused["best_val"] == full["best_val"]
     for key in ("mean", "var", "acq"):
         assert np.array_equal(fused[key], full[key]), key
+    if not any(os.environ.get(k) for k in ("CBO_HIP_OVERLAP", "CBO_HIP_PIPE_TAIL", "CBO_HIP_PIPE_GROUP")):
+        from cbo_with_oop_amd import _lib
+        assert last_schedule(_lib.Context.get(), 4096, 16384)[0] >= 0      # it WAS an overlapped call (-1: fit, then sweep)
 
 
 # ---------------------------------------------------------------------------------- edge cases
@@ -548,6 +551,9 @@ def test_c4_bench_problem_against_oracle_and_arbiter(hip):
     m = HipGaussianProcess(X, y, fit=False)                        # unfitted: the sweep below is the bench's one call
     res = CausalExpectedImprovement(y_best, "min", m).sweep(Xs, cost=cost, want_acq=True, want_posterior=True, refit=True)
     assert not m.stale and int(np.argmax(res["acq"][:, 0])) == res["best_idx"]
+    if not any(os.environ.get(k) for k in ("CBO_HIP_OVERLAP", "CBO_HIP_PIPE_TAIL", "CBO_HIP_PIPE_GROUP")):
+        from cbo_with_oop_amd import _lib
+        assert last_schedule(_lib.Context.get(), 16384, 32768)[0] >= 0     # an overlapped call, its pipeline repeated by the retry
     post = O.fit(X, y)
     assert m.jitter_tries == post.tries and post.tries >= 1, (m.jitter_tries, post.tries)      # the retry IS exercised
     assert np.isclose(m.jitter, post.jitter, rtol=1e-12, atol=0.0), (m.jitter, post.jitter)
@@ -998,6 +1004,16 @@ def test_communicator_through_the_c_abi(hip):
     assert "code -8" in out.stdout, (out.stdout, out.stderr[-500:])          # CBO_ERR_COMM
 
 
+def last_schedule(ctx, rows, candidates):
+    """(pairs, group) the last cbo_gp_fit_sweep call of the shape ran, from cbo_schedule_report (pairs = -1: the plain
+    sequence, fit then sweep)."""
+    import re
+    _, text = ctx.schedule_report()
+    line = next(l for l in text.splitlines() if l.startswith(f"rows {rows} candidates {candidates}:"))
+    m = re.search(r"last call ran pairs (-?\d+) group (\d+)", line)
+    return int(m.group(1)), int(m.group(2))
+
+
 def forced_context(monkeypatch, **env):
     """A fresh context whose schedule knobs are pinned (they are read when the context is created)."""
     from cbo_with_oop_amd import _lib
@@ -1118,10 +1134,47 @@ def test_measured_schedule_settles_and_every_call_on_the_way_gives_the_same_bits
         assert (r["best_val"], r["best_idx"]) == (first["best_val"], first["best_idx"])
         assert calls <= 110, text                       # (the tuner itself gives up after 96 sampled calls)
     assert "settled" in states and len(states) >= 3, (states, text)
-    full = ei.sweep(grid, refit=True, want_acq=True, want_posterior=True)       # (outputs requested: not sampled)
+    full = ei.sweep(grid, refit=True, want_acq=True, want_posterior=True)       # (outputs requested: the settled schedule)
     mu, var = model.predict(grid.points[:64])
     assert np.array_equal(np.ravel(full["mean"])[:64], mu[:, 0]) and full["best_idx"] == first["best_idx"]
     grid.close(); model.close(); ctx.close()
+
+
+def test_first_call_of_a_fresh_context_is_overlapped_whatever_outputs_it_asks_for(hip, monkeypatch):
+    """Round 4's tuner ran the plain sequence (fit, then sweep) on every call that could not be sampled -- every call that
+    asked for the per-candidate outputs, every call under the profiling timers -- as long as the shape was cold: a caller of
+    CausalExpectedImprovement.evaluate() on a stale model never left it.  Now the first call of a shape runs the analytic
+    split, outputs or not, profiling or not, and the calls with outputs take part in the measurement.  At the headline
+    shape: the first call of a fresh context, with every output requested, reports a pipelined schedule and returns the bits
+    of the two calls; so does a fresh context that is never sampled (profiling on)."""
+    from cbo_with_oop_amd import CandidateGrid, CausalExpectedImprovement
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    for knob in ("CBO_HIP_OVERLAP", "CBO_HIP_PIPE_TAIL", "CBO_HIP_PIPE_GROUP", "CBO_HIP_SCHEDULE_TUNE"):
+        monkeypatch.delenv(knob, raising=False)
+    rng = np.random.default_rng(11)
+    X = rng.uniform([-5, -5, -5], [5, 20, 5], (4096, 3))
+    y = np.sin(X).sum(1, keepdims=True) + 0.1 * rng.standard_normal((4096, 1))
+    Xs = rng.uniform([-5, -5, -5], [5, 20, 5], (16384, 3))
+    ref_ctx = forced_context(monkeypatch, CBO_HIP_OVERLAP=0)                       # the two calls
+    m0 = HipGaussianProcess(X, y, context=ref_ctx)
+    g0 = CandidateGrid(Xs, m0, context=ref_ctx)
+    two = CausalExpectedImprovement(float(y.min()), "min", m0).sweep(g0, cost=3.0, want_acq=True, want_posterior=True)
+    for profiling in (False, True):
+        ctx = forced_context(monkeypatch)
+        ctx.set_profiling(profiling)
+        model = HipGaussianProcess(X, y, fit=False, context=ctx)
+        grid = CandidateGrid(Xs, model, context=ctx)
+        ei = CausalExpectedImprovement(float(y.min()), "min", model)
+        for call in range(3 if profiling else 1):
+            one = ei.sweep(grid, cost=3.0, want_acq=True, want_posterior=True, refit=True)
+            pairs, group = last_schedule(ctx, 4096, 16384)
+            assert 1 <= pairs < 16, (profiling, call, pairs, group)              # some pairs pipelined, then the closing launch
+            assert one["best_idx"] == two["best_idx"] and one["best_val"] == two["best_val"]
+            for key in ("mean", "var", "acq"):
+                assert np.array_equal(one[key], two[key]), (profiling, call, key)
+        ctx.set_profiling(False)
+        grid.close(); model.close(); ctx.close()
+    g0.close(); m0.close(); ref_ctx.close()
 
 
 def test_schedule_selection(hip):
