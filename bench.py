@@ -102,6 +102,17 @@ def make_problem(cfg, world, scaling, full_grid):
     return X, y, Xs, g, f"the fixed {g[0]}x{g[1]}x{g[2]} grid cut into {world} contiguous shard(s)"
 
 
+def strong_shard(cfg, world, rank):
+    """c2 over ranks, strong scaling: the config's ONE grid (16384 candidates) cut into `world` contiguous shards -- what
+    the north_star's "the candidate-intervention grid shards across the GPUs" says (src/CBO.py:237-260: one loop over the
+    candidates of a set).  Returns (candidates of the whole grid, begin, end of this rank's shard)."""
+    from cbo_with_oop_amd.graphs import meshgrid_candidates
+    from cbo_with_oop_amd.sharding import shard_bounds
+    Xs = meshgrid_candidates(cfg["box"], cfg["grid"])
+    begin, end = shard_bounds(Xs.shape[0], world, rank)
+    return Xs, int(begin), int(end)
+
+
 def cpu_baseline(X, y, Xs, y_best, cost, sample):
     """numpy/scipy restatement of the GPy/emukit path (oracle/gp_oracle.py) timed on this box's host
     cores: the full fit, and the sweep on the first `sample` candidates scaled to the full grid."""
@@ -328,7 +339,12 @@ def dry_rank_report(cfg, world, rank, local_rank, scaling, full_grid):
     from cbo_with_oop_amd.sharding import shard_bounds
     X, y, Xs, grid, note = make_problem(cfg, world, scaling, full_grid)
     begin, end = shard_bounds(Xs.shape[0], world, rank)
+    strong = None
+    if cfg is CONFIGS["c2"] and scaling == "weak" and world > 1:      # the line carries a strong-scaling object as well
+        Xg, sb, se = strong_shard(cfg, world, rank)
+        strong = {"shard": [sb, se], "candidates_total": int(Xg.shape[0])}
     print(json.dumps({"dry_rank": rank, "world": world, "local_rank": local_rank, "shard": [int(begin), int(end)],
+                      "strong": strong,
                       "candidates_total": int(Xs.shape[0]), "n_obs": int(X.shape[0]), "scaling": scaling,
                       "master": [os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")],
                       "launcher_pid": os.getppid(), "lib_loaded": "cbo_with_oop_amd._lib" in sys.modules and
@@ -457,6 +473,42 @@ def main():
     if comm is not None:
         elapsed = comm.max(elapsed)            # the slowest rank's time
 
+    # c2 over several ranks: `value` above is the weak-scaling figure (one 16384-candidate grid per GPU, as measured since
+    # round 1).  The same step on the config's ONE grid cut into `world` shards is timed here as well, by the same rules
+    # (schedule settled first, warm-up, barrier + device synchronisation on both sides, the slowest rank's time): with the
+    # posterior replicated, every rank still factors all 4096 rows -- the Amdahl term of this design.
+    strong = None
+    if args.config == "c2" and scaling == "weak" and world > 1 and not args.sequential and not args.ladder_over_ranks:
+        Xg, sb, se = strong_shard(cfg, world, rank)
+        cands_s = CandidateGrid(Xg[sb:se], model, index_offset=sb, context=ctx)
+
+        def strong_step():
+            _lib.check(lib.cbo_gp_fit_sweep(model._handle, cands_s._handle, y_best, 0, 0.0, cost, None, None, None,
+                                            ctypes.byref(bv), ctypes.byref(bi), None, None))
+            return exchange_argmax(bv.value, bi.value, comm)
+        strong_settling = 0
+        strong_step()
+        while ctx.schedule_report()[0] > 0 and strong_settling < 80:
+            strong_step()
+            strong_settling += 1
+        for _ in range(max(1, args.warmup)):
+            strong_winner = strong_step()
+        fence()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            strong_winner = strong_step()
+        fence()
+        strong_elapsed = comm.max(time.perf_counter() - ts) if comm is not None else time.perf_counter() - ts
+        strong = {"scaling": "strong", "candidates_total": int(Xg.shape[0]), "candidates_per_gpu": int(-(-Xg.shape[0] // world)),
+                  "shard_of_rank_0": [sb, se], "ms_per_step": strong_elapsed / args.steps * 1e3,
+                  "value": Xg.shape[0] / (strong_elapsed / args.steps), "unit": "acquisitions/s",
+                  "winner": {"index": int(strong_winner[1]), "acq": float(strong_winner[0])},
+                  "schedule_settling_calls": strong_settling,
+                  "what": "the config's ONE 32x32x16 grid cut into contiguous shards, one per rank; the posterior (the "
+                          "4096-row factorisation) is replicated on every rank, so the step cannot fall below the "
+                          "factorisation's own time: DESIGN.md 6 has the modelled curve"}
+        cands_s.close()
+
     # instrumented pass, outside the timed region: the same work as two calls, per-phase event timers on
     timers, post_winner = None, None
     if args.post_steps > 0:
@@ -514,6 +566,8 @@ def main():
             "schedule_settling_calls": settling_calls, "schedule": ctx.schedule_report()[1].strip(),
             "parallelism": f"candidate shards x{world}, replicated posterior"}
         out["winner"] = {"index": int(winner[1]), "acq": float(winner[0])}
+        if strong is not None:
+            out["strong"] = strong                    # (c2, several ranks: the one-grid figure beside the weak `value`)
         out["kernel_sources_sha"] = kernel_sources_sha()
         if f32:
             # the sweep kernel runs alone on the device (nothing overlaps on this dtype): its own launch duration is
@@ -539,9 +593,9 @@ def main():
             step_tflops = step_flops / (region_ms / args.steps * 1e-3) / 1e12
             traffic, note = pmc_traffic(("step_sequential" if args.sequential else "step") if args.config == "c2" else None)
             out["roofline"] = {
-                "kernel": "whole step: trsm_update_kernel<16> (dominant) + trsm_strip_kernel<*,16> + trsm_strip8_kernel + "
+                "kernel": "whole step: trsm_update_kernel<16> (dominant) + trsm_strip_kernel<*,16> + trsm_pair_kernel + "
                           "syrk_kernel<64> + potrf_panel_fused_kernel (diagonal block + row panel), co-scheduled" if not args.sequential else
-                          "whole step: trsm_strip8_kernel<true> (dominant), then the factorisation's kernels",
+                          "whole step: trsm_pair_kernel<true> (dominant), then the factorisation's kernels",
                 "bound": "mfma", "achieved": step_tflops, "peak": peak, "unit": "TFLOP/s",
                 "frac": step_tflops / peak, "traffic": traffic, "traffic_source": note,
                 "per": "step", "avg_step_ms_events": region_ms / args.steps,
@@ -552,8 +606,9 @@ def main():
             achieved = timers["trsm_flops"] / launches / (trsm_ms * 1e-3) / 1e12 if trsm_ms > 0 else 0.0
             traffic, note = pmc_traffic("strip_kernel" if args.config == "c2" else None)
             out["roofline"]["isolated"] = {
-                "kernel": "trsm_strip8_kernel<true> (V = L^-1 K*, fused sum V^2 and V^T z; two waves per SIMD): the sweep of "
-                          "every set that is not refitted, alone on the device (instrumented pass after the timed region)",
+                "kernel": "trsm_pair_kernel<true> (V = L^-1 K*, fused sum V^2 and V^T z; 256-row pair blocks, two waves per "
+                          "SIMD): the sweep of every set that is not refitted, alone on the device (instrumented pass after "
+                          "the timed region)",
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": traffic, "traffic_source": note,
                 "avg_launch_ms": trsm_ms, "algorithmic_flops_per_launch": timers["trsm_flops"] / launches}

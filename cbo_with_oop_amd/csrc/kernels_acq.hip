@@ -36,6 +36,10 @@ __device__ __forceinline__ void block_argmax(double v, int64_t i, double *out_v,
 
 constexpr int64_t kNoIndex = INT64_MAX;
 
+// Two consecutive candidates per lane and iteration (16-byte loads and stores), the next iteration's operands requested
+// before this one's arithmetic: with one candidate per lane and the load at the top of the loop body the pass was bound by
+// memory LATENCY -- 32 KB in flight per CU -- and ran at 0.29 of the HBM roofline whatever the arithmetic cost (round 5: halving
+// the transcendental work changed nothing until the loads were decoupled).
 __global__ __launch_bounds__(256) void acq_kernel(const double *__restrict__ q, const double *__restrict__ mu,
                                                   const double *__restrict__ pm, const double *__restrict__ pv,
                                                   int64_t m, AcqParams p, double *__restrict__ mean_out,
@@ -45,17 +49,57 @@ __global__ __launch_bounds__(256) void acq_kernel(const double *__restrict__ q, 
 {
     double bv = -INFINITY;
     int64_t bi = kNoIndex;
-    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < m; c += (int64_t)gridDim.x * blockDim.x) {
-        double mean, var;
-        posterior_of(q[c], mu[c], pm ? pm[c] : 0.0, pv ? pv[c] : 0.0, pv != nullptr, p, mean, var);
-        if (mean_out) mean_out[c] = mean;
-        if (var_out) var_out[c] = var;
-        if (p.want_ei) {
-            const double acq = acquisition_of(mean, var, p);
-            if (acq_out) acq_out[c] = acq;
-            const int64_t gi = c + index_offset;
-            if (better(acq, gi, bv, bi)) { bv = acq; bi = gi; }
+    const bool causal = pv != nullptr;
+    const int64_t stride = 2 * (int64_t)gridDim.x * blockDim.x;
+    int64_t c = 2 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    // operands of the pair at c (the second of an odd tail: a copy of the first, never stored)
+    auto fetch = [&](int64_t at, d2 &q2, d2 &mu2, d2 &pm2, d2 &pv2) __attribute__((always_inline)) {
+        if (at + 1 < m) {
+            q2 = *reinterpret_cast<const d2 *>(q + at);
+            mu2 = *reinterpret_cast<const d2 *>(mu + at);
+            if (causal) {
+                pm2 = *reinterpret_cast<const d2 *>(pm + at);
+                pv2 = *reinterpret_cast<const d2 *>(pv + at);
+            }
+        } else if (at < m) {
+            q2 = d2{q[at], q[at]};
+            mu2 = d2{mu[at], mu[at]};
+            if (causal) {
+                pm2 = d2{pm[at], pm[at]};
+                pv2 = d2{pv[at], pv[at]};
+            }
         }
+    };
+    d2 qn = {0.0, 0.0}, mun = {0.0, 0.0}, pmn = {0.0, 0.0}, pvn = {0.0, 0.0};
+    fetch(c, qn, mun, pmn, pvn);
+    while (c < m) {
+        const d2 q2 = qn, mu2 = mun, pm2 = pmn, pv2 = pvn;
+        fetch(c + stride, qn, mun, pmn, pvn);
+        const bool two = c + 1 < m;
+        d2 mean2, var2, acq2 = {0.0, 0.0};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            double mean, var;
+            posterior_of(q2[e], mu2[e], causal ? pm2[e] : 0.0, causal ? pv2[e] : 0.0, causal, p, mean, var);
+            mean2[e] = mean;
+            var2[e] = var;
+            if (p.want_ei) {
+                const double acq = acquisition_of(mean, var, p);
+                acq2[e] = acq;
+                const int64_t gi = c + e + index_offset;
+                if ((e == 0 || two) && better(acq, gi, bv, bi)) { bv = acq; bi = gi; }
+            }
+        }
+        if (two) {
+            if (mean_out) *reinterpret_cast<d2 *>(mean_out + c) = mean2;
+            if (var_out) *reinterpret_cast<d2 *>(var_out + c) = var2;
+            if (p.want_ei && acq_out) *reinterpret_cast<d2 *>(acq_out + c) = acq2;
+        } else {
+            if (mean_out) mean_out[c] = mean2[0];
+            if (var_out) var_out[c] = var2[0];
+            if (p.want_ei && acq_out) acq_out[c] = acq2[0];
+        }
+        c += stride;
     }
     if (p.want_ei) block_argmax(bv, bi, &part_val[blockIdx.x], &part_idx[blockIdx.x]);
 }
@@ -174,7 +218,7 @@ void launch_pred_gradients(hipStream_t s, const PointSet &X, int64_t n_pad, cons
 
 int acq_blocks_for(int64_t m)
 {
-    int64_t b = (m + 255) / 256;
+    int64_t b = (m + 511) / 512;                      // two candidates per lane
     if (b > 2048) b = 2048;
     if (b < 1) b = 1;
     return (int)b;

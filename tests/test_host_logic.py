@@ -206,6 +206,18 @@ def test_bench_starts_its_own_ranks_for_a_plain_multi_gpu_invocation():
     assert out.returncode == 0, out.stderr[-2000:]
     shards = sorted(json.loads(ln)["shard"] for ln in (out.stdout + out.stderr).splitlines() if ln.startswith("{"))
     assert shards == [[32768 * r, 32768 * (r + 1)] for r in range(4)]
+    # the headline config over four ranks carries both figures: the weak-scaling shards (one 16384-candidate grid per GPU,
+    # `value`) and the strong-scaling shards of the config's ONE grid (the `strong` object of the line)
+    out = _run_bench(["--gpus", "4"], {"CBO_BENCH_DRY_RANKS": "1", "CBO_HIP_LIB": "/nonexistent/libcbo_hip.so"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    ranks = sorted((json.loads(ln) for ln in (out.stdout + out.stderr).splitlines() if ln.startswith("{")), key=lambda r: r["dry_rank"])
+    assert [r["shard"] for r in ranks] == [[16384 * r, 16384 * (r + 1)] for r in range(4)]
+    assert all(r["scaling"] == "weak" and r["candidates_total"] == 65536 for r in ranks)
+    assert [r["strong"]["shard"] for r in ranks] == [[4096 * r, 4096 * (r + 1)] for r in range(4)]
+    assert all(r["strong"]["candidates_total"] == 16384 for r in ranks)
+    # one rank: nothing to cut
+    out = _run_bench(["--gpus", "1"], {"CBO_BENCH_DRY_RANKS": "1", "CBO_BENCH_SELF_LAUNCH": "1", "CBO_HIP_LIB": "/nonexistent/libcbo_hip.so"})
+    assert out.returncode == 0 and json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])["strong"] is None
 
 
 def test_bench_launcher_reports_the_worst_exit_code_of_its_ranks():
