@@ -5,6 +5,14 @@ The reference samples ``num_anchor_points`` uniform random anchors, scores them 
 ``acquisition.evaluate`` (:52-55), keeps the best and refines it with L-BFGS (:59-65).  Here the batched
 scoring IS the optimiser: a deterministic regular grid over the space (BASELINE.json's "N-candidate sweep",
 SURVEY.md §0.7), scored on the GPU, arg-max taken on the GPU.  Gradient refinement is SURVEY.md §8 f3.
+
+``anchors="uniform"`` is the reference's own mode, for use under runCBO.py where the trajectory of numpy's global
+generator matters (``--seed``, src/ArgumentParser.py:47): ``num_anchor_points`` (100) uniform anchors drawn from the
+GLOBAL generator in emukit's order, scored by one batched ``acquisition.evaluate`` (one device sweep), the top one by
+``argsort()[::-1][:1]`` as emukit takes it, then L-BFGS from that anchor (scipy ``fmin_l_bfgs_b``, bounds, maxfun=1000 --
+emukit's ``OptLbfgs``), whose result is returned as it comes (:59-65: no comparison with the anchor's own value).
+emukit is absent here: its order of draws -- ``ParameterSpace.sample_uniform`` samples parameter by
+parameter, each ``np.random.uniform(low, high, (n, 1))`` -- is recalled from emukit 0.4.10, parity unpinned.
 """
 from __future__ import annotations
 
@@ -15,16 +23,33 @@ from .causal_acquisition_functions import CandidateGrid
 
 
 class CausalGradientAcquisitionOptimizer:
-    def __init__(self, space, num_anchor_points=None, grid_shape=None):
-        """``space``: emukit ParameterSpace / object with ``parameters`` / list of (lo, hi).  ``grid_shape``
-        (points per dimension) defaults to ``default_grid_shape``; ``num_anchor_points``, if given, is used as
-        the candidate budget instead of 16384."""
+    def __init__(self, space, num_anchor_points=None, grid_shape=None, anchors="grid"):
+        """``space``: emukit ParameterSpace / object with ``parameters`` / list of (lo, hi).  ``anchors="grid"``
+        (default): ``grid_shape`` (points per dimension) defaults to ``default_grid_shape``; ``num_anchor_points``, if
+        given, is used as the candidate budget instead of 16384.  ``anchors="uniform"``: the reference's 100 (or
+        ``num_anchor_points``) uniform random anchors and L-BFGS from the best (module docstring)."""
         from .utils import default_grid_shape, space_bounds
+        if anchors not in ("grid", "uniform"):
+            raise ValueError(f"anchors must be 'grid' or 'uniform', not {anchors!r}")
         self.space = space
         self.bounds = space_bounds(space)
+        self.anchors = anchors
+        self.num_anchor_points = 100 if num_anchor_points is None else int(num_anchor_points)    # (causal_optimizer.py:19)
         self.grid_shape = list(grid_shape) if grid_shape is not None else default_grid_shape(
             len(self.bounds), budget=num_anchor_points)
         self._grid, self._grid_model = None, None
+
+    def sample_uniform(self, point_count):
+        """emukit ``ParameterSpace.sample_uniform`` on the GLOBAL numpy generator: one ``np.random.uniform(low, high,
+        (point_count, 1))`` per parameter, in the parameters' order, stacked as columns."""
+        return np.hstack([np.random.uniform(low=lo, high=hi, size=(point_count, 1)) for lo, hi in self.bounds])
+
+    def optimize_from_uniform_anchors(self, acquisition):
+        """The reference's ``_optimize`` (:26-65) for a space without context or constraints."""
+        x_anchors = self.sample_uniform(self.num_anchor_points)
+        scores = np.asarray(acquisition.evaluate(x_anchors), dtype=np.float64)[:, 0]      # ONE batched device sweep (:52-55)
+        anchor = x_anchors[np.argsort(scores)[::-1][:1]]                                # emukit AnchorPointsGenerator.get
+        return self.refine(acquisition, anchor)                                         # OptLbfgs from it (:59-65)
 
     def candidates(self):
         return meshgrid_candidates(self.bounds, self.grid_shape)
@@ -57,6 +82,8 @@ class CausalGradientAcquisitionOptimizer:
         ``CausalExpectedImprovement``.  ``refine=True`` adds the reference's gradient stage: from the best grid point
         with scipy's L-BFGS-B (``num_starts=1``, what the reference does with its best anchor), or from the
         ``num_starts`` best grid points at once (``refine_batched``)."""
+        if self.anchors == "uniform":
+            return self.optimize_from_uniform_anchors(acquisition)
         # the grid of this optimiser stays on the device while the model object is the same (no allocation per call)
         model = acquisition.model
         if self._grid is None or self._grid_model is not model:

@@ -66,12 +66,21 @@ def default_grid_shape(d, budget=None):
 
 
 def find_next_y_point(space, model, current_global_best, evaluated_set, costs_functions, task='min',
-                      grid_shape=None, candidates=None):
+                      grid_shape=None, candidates=None, anchors="grid", num_anchor_points=None):
     """utils.py:29-37.  Returns (y_acquisition (1,1), x_new (1,d)).
 
     ``candidates`` (optional (M,d) array or CandidateGrid) overrides the regular grid over ``space``.
+    ``anchors="uniform"``: the reference's own optimiser instead of the grid -- 100 uniform anchors from numpy's global
+    generator, one batched device sweep over them, L-BFGS from the best (causal_optimizer.py:26-65), then the
+    acquisition re-evaluated at the point found (utils.py:36) -- the four lines of the reference's function.
     """
     cost_acquisition = Cost(costs_functions, evaluated_set)
+    if anchors == "uniform":
+        from .causal_optimizer import CausalGradientAcquisitionOptimizer
+        optimizer = CausalGradientAcquisitionOptimizer(space, num_anchor_points=num_anchor_points, anchors="uniform")
+        acquisition = CausalExpectedImprovement(current_global_best, task, model) / cost_acquisition
+        x_new, _ = optimizer.optimize(acquisition)
+        return acquisition.evaluate(x_new), x_new
     ei = CausalExpectedImprovement(current_global_best, task, model)
     own = False
     if candidates is None:

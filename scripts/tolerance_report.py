@@ -55,7 +55,7 @@ for name in FIXTURES:
     m.close()
 
 if "--large" in sys.argv:
-    # The two 16384-observation configurations on bench.py's own data (a 257-candidate subsample of the rank's shard).  The
+    # The two 16384-observation configurations on bench.py's own data (every 128th candidate of the rank's shard plus the device's 64 best).  The
     # 80-bit restatement is not affordable there; the arbiter of the mean is oracle/truth.py:refined_mean (exact kernel
     # entries, iterative refinement with long-double residuals), the acquisition is taken from the arbiter's mean and the
     # oracle's variance, and the variance is quoted against the oracle itself.
@@ -68,7 +68,14 @@ if "--large" in sys.argv:
         X, y, Xs, grid, note = bench.make_problem(bench.CONFIGS[cname], 1, "strong", False)
         y_best, cost = float(y.min()), 3.0
         post = O.fit(X, y)
-        sub = np.arange(0, Xs.shape[0], 128)
+        # every 128th candidate of the shard AND the fp64 device path's 64 best: on these boxes the acquisition is ~1e-123 of
+        # its maximum almost everywhere (the winner sits in a corner of the grid), and a subsample without the top would
+        # compare zeros in the acquisition column
+        m0 = HipGaussianProcess(X, y)
+        a0 = CausalExpectedImprovement(y_best, "min", m0).sweep(Xs, cost=cost, want_acq=True)["acq"][:, 0]
+        m0.close()
+        top64 = np.argsort(-a0, kind="stable")[:64]
+        sub = np.unique(np.concatenate([np.arange(0, Xs.shape[0], 128), top64]))
         acq, _, _, mu, var = O.acquisition_sweep(post, Xs[sub], y_best, cost=cost)
         tm, _ = refined_mean(post, Xs[sub], exact_entries=True)
         acq_t = O.expected_improvement(tm, var, y_best, "min", 0.0) / cost
@@ -83,5 +90,6 @@ if "--large" in sys.argv:
                   f"{np.max(np.abs(mu - tm)) / scale:10.2e} {np.max(np.abs(res['mean'][sub] - mu)) / scale:10.2e} | "
                   f"{np.max(np.abs(res['var'][sub] - var)):19.2e} {np.max(np.abs(res['var'][sub] - var) / var):9.2e} | "
                   f"{np.max(np.abs(res['acq'][sub] - acq_t)) / amax:23.2e} {np.max(np.abs(acq - acq_t)) / amax:10.2e} | "
-                  f"{'same' if o_best == d_best else 'DIFFERS'} (on the subsample)")
+                  f"{'same' if o_best == d_best else 'DIFFERS'} (subsample + the device's top 64: {int(np.sum(np.abs(acq[:, 0]) > 1e-6 * np.abs(acq).max()))} "
+                  f"candidates with an acquisition above 1e-6 of the maximum)")
             m.close()

@@ -230,8 +230,15 @@ def test_f32_config5_shard_at_full_size(hip):
         problems.append(f"acq vs fp64 device path: {np.max(np.abs(res['acq'] - ref['acq'])):.3e} > {ACQ_TOL_FULL:.1e} * {amax:.3e}")
     if np.max(np.abs(res["mean"] - ref["mean"])) > MEAN_RTOL * np.max(np.abs(y)):
         problems.append(f"mean vs fp64 device path: {np.max(np.abs(res['mean'] - ref['mean'])):.3e}")
-    if ref["best_idx"] not in top32:
-        problems.append(f"fp64 arg-max {ref['best_idx']} not in the fp32 top {TOP_K}: {top32}")
+    # SURVEY.md 7 asks for arg-max EQUALITY at config 5: asserted.  Should an fp32 rounding ever swap two candidates whose
+    # fp64 acquisitions are closer than the path's stated tolerance, the message says by how much, and whether the fp64
+    # winner is still among the fp32 top 8 (the stated fallback of the module docstring) -- it is a failure either way.
+    if ref["best_idx"] != res["best_idx"]:
+        a64 = ref["acq"][:, 0]
+        margin = (a64[ref["best_idx"]] - a64[res["best_idx"]]) / abs(a64[ref["best_idx"]])
+        problems.append(f"fp32 arg-max {res['best_idx']} != fp64 arg-max {ref['best_idx']}: the fp64 path separates them by "
+                        f"{margin:.3e} of the winner's value; fp64 winner {'in' if ref['best_idx'] in top32 else 'NOT in'} the "
+                        f"fp32 top {TOP_K} {top32}")
     if abs(res["best_val"] - ref["best_val"]) > BEST_RTOL * abs(ref["best_val"]):
         problems.append(f"best value {res['best_val']:.9e} vs {ref['best_val']:.9e}")
     m64.close()

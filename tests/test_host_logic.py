@@ -144,6 +144,51 @@ def test_lockstep_lbfgs_reaches_scipys_optima_in_one_call_per_round():
     assert np.allclose(Xb, [[3.0, 0.0]]) and np.isclose(Fb[0], 3.0)
 
 
+def test_uniform_anchor_mode_consumes_the_global_generator_as_the_reference_does():
+    """``CausalGradientAcquisitionOptimizer(space, anchors="uniform")`` is the reference's optimiser
+    (src/utils_functions/causal_optimizer.py:19,52-65): 100 anchors from numpy's GLOBAL generator, drawn parameter by
+    parameter as emukit's ``ParameterSpace.sample_uniform`` draws them, ONE batched ``evaluate`` over all of them, the top
+    one by ``argsort()[::-1][:1]``, L-BFGS (scipy ``fmin_l_bfgs_b``, bounds, maxfun=1000) from it, its result returned as it
+    comes.  Checked against a scripted replay of those steps on a smooth stand-in acquisition (no device): the draws
+    consumed, the anchor chosen, the state the generator is left in."""
+    from scipy.optimize import fmin_l_bfgs_b
+    from cbo_with_oop_amd.utils_functions.causal_optimizer import CausalGradientAcquisitionOptimizer
+    bounds = [(-5.0, 4.0), (-5.0, 5.0), (-6.0, 3.0)]
+    centre = np.array([1.0, -2.0, 0.5])
+
+    class Acq:
+        calls = []
+
+        def evaluate(self, x):
+            Acq.calls.append(np.array(x, copy=True))
+            return np.exp(-0.5 * np.sum((x - centre) ** 2, axis=1, keepdims=True))
+
+        def evaluate_with_gradients(self, x):
+            f = np.exp(-0.5 * np.sum((x - centre) ** 2, axis=1, keepdims=True))
+            return f, -f * (x - centre)
+
+    np.random.seed(9)                                          # (--seed 9, src/ArgumentParser.py:24,47)
+    opt = CausalGradientAcquisitionOptimizer(bounds, anchors="uniform")
+    x, fx = opt.optimize(Acq())
+    after = np.random.uniform()
+    # the scripted replay
+    np.random.seed(9)
+    cols = [np.random.uniform(low=lo, high=hi, size=(100, 1)) for lo, hi in bounds]
+    anchors = np.hstack(cols)
+    assert np.random.uniform() == after                        # exactly 300 draws were consumed, nothing else
+    assert len(Acq.calls) == 1 and np.array_equal(Acq.calls[0], anchors)       # ONE batched evaluate, over exactly these
+    scores = np.exp(-0.5 * np.sum((anchors - centre) ** 2, axis=1))
+    start = anchors[np.argsort(scores)[::-1][:1]]
+    xr, fr, _ = fmin_l_bfgs_b(lambda v: (-float(np.exp(-0.5 * np.sum((v - centre) ** 2))),
+                                         float(np.exp(-0.5 * np.sum((v - centre) ** 2))) * (v - centre)),
+                              start.reshape(-1), bounds=bounds, maxfun=1000)
+    assert np.array_equal(x, xr[None, :]) and fx[0, 0] == -fr and np.allclose(x, centre, atol=1e-4)
+    # the default stays the grid; anything else is refused
+    assert CausalGradientAcquisitionOptimizer(bounds).anchors == "grid"
+    with pytest.raises(ValueError):
+        CausalGradientAcquisitionOptimizer(bounds, anchors="sobol")
+
+
 def test_bench_configs_are_the_baseline_shapes_and_shard_as_stated():
     """bench.py --config c2..c5: BASELINE.json's sizes, the reference's interventional ranges, weak scaling stacks one
     grid per rank, strong scaling cuts the ONE grid, and an 8-GPU config on fewer ranks keeps 1/8 per rank unless told."""

@@ -356,6 +356,34 @@ def test_c3_size_against_oracle_subsample(hip):
     assert int(np.argmax(res["acq"][:, 0])) == res["best_idx"]
 
 
+def test_c3_bench_problem_against_the_oracle(hip):
+    """BASELINE config 3 on the data ``bench.py --config c3`` benches (``bench.make_problem``: complete_graph (B, D, E)
+    ranges, 8192 observations, the fixed 64x32x32 grid), one GPU: the one call the bench times, against the oracle on a
+    512-candidate subsample plus the device's 64 best candidates -- variance and mean at the plain 1e-5, acquisition 1e-4
+    where it is not negligible, the oracle's best of those candidates = the device's arg-max."""
+    import bench
+    from cbo_with_oop_amd import CausalExpectedImprovement
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    X, y, Xs, grid, note = bench.make_problem(bench.CONFIGS["c3"], 1, "strong", False)
+    assert X.shape == (8192, 3) and Xs.shape == (65536, 3) and tuple(grid) == (64, 32, 32)
+    y_best, cost = float(y.min()), 3.0
+    m = HipGaussianProcess(X, y, fit=False)                        # unfitted: the sweep below is the bench's one call
+    res = CausalExpectedImprovement(y_best, "min", m).sweep(Xs, cost=cost, want_acq=True, want_posterior=True, refit=True)
+    assert not m.stale and int(np.argmax(res["acq"][:, 0])) == res["best_idx"]
+    post = O.fit(X, y)
+    assert m.jitter_tries == post.tries
+    top64 = np.argsort(-res["acq"][:, 0], kind="stable")[:64]
+    sub = np.unique(np.concatenate([np.arange(0, 65536, 128), top64]))
+    acq, _, _, mu, var = O.acquisition_sweep(post, Xs[sub], y_best, cost=cost)
+    assert np.max(np.abs(res["var"][sub] - var) / var) < 1e-5
+    assert np.max(np.abs(res["mean"][sub] - mu)) < 1e-5 * np.max(np.abs(y))
+    big = acq[:, 0] > 1e-6 * acq.max()
+    assert big.sum() >= 32                                         # (the top 64 are in: the column is not a comparison of zeros)
+    assert np.max(np.abs(res["acq"][sub][big] - acq[big]) / acq[big]) < 1e-4
+    assert int(sub[np.argmax(acq[:, 0])]) == res["best_idx"]
+    m.close()
+
+
 # ---------------------------------------------------------------------------------- do-calculus prior (f1)
 def test_do_calculus_prior_matches_oracle(hip):
     """Graph-level GP (ARD RBF, noise 1e-2) -> do-calculus mean/variance closures -> causal GP -> sweep,
@@ -746,6 +774,49 @@ def test_optimizer_class_and_quotient_mirror_the_reference_call_sequence(hip):
     y2, x2 = find_next_y_point(space, model, float(f["y_best"]), ["Z"], costs, grid_shape=[200])
     assert np.array_equal(x_new, x2) and np.array_equal(x_new[0], f["Xs"][int(f["best_idx"])])
     assert np.allclose(y_acquisition, y2, rtol=1e-14) and np.isclose(y2[0, 0], float(f["best_val"]), rtol=1e-5)
+
+
+def test_uniform_anchor_mode_against_the_oracle_on_the_same_anchors(hip):
+    """The reference's own optimiser mode (``anchors="uniform"``, src/utils_functions/causal_optimizer.py:19,52-65) on the
+    device: the 100 anchors drawn from numpy's global generator are scored by ONE device sweep -- against the oracle's
+    acquisition on the same anchors, same top anchor --, L-BFGS from it lands where the same scipy call on the oracle's
+    function and gradient lands, and ``find_next_y_point(anchors="uniform")`` re-evaluates the acquisition at the point
+    found (src/utils_functions/utils.py:33-36)."""
+    from scipy.optimize import fmin_l_bfgs_b
+    from cbo_with_oop_amd.graphs import CompleteGraph
+    from cbo_with_oop_amd.utils_functions import (CausalExpectedImprovement, CausalGradientAcquisitionOptimizer, Cost,
+                                                  find_next_y_point)
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    rng = np.random.default_rng(33)
+    bounds = [(-5.0, 4.0), (-5.0, 5.0)]                              # complete_graph (B, D)
+    X = rng.uniform([-5, -5], [4, 5], (60, 2))
+    y = np.sin(X[:, :1]) + 0.1 * X[:, 1:] ** 2 + 0.05 * rng.standard_normal((60, 1))
+    m = HipGaussianProcess(X, y, noise_var=1e-4)
+    post = O.fit(X, y, noise_var=1e-4)
+    y_best = float(y.min())
+    costs = CompleteGraph.get_cost_structure(1)
+    acquisition = CausalExpectedImprovement(y_best, "min", m) / Cost(costs, ["B", "D"])
+    np.random.seed(9)
+    anchors = np.hstack([np.random.uniform(low=lo, high=hi, size=(100, 1)) for lo, hi in bounds])
+    np.random.seed(9)
+    x_new, fx = CausalGradientAcquisitionOptimizer(bounds, anchors="uniform").optimize(acquisition)
+    # the anchors' scores: device against oracle, same winner
+    scores = acquisition.evaluate(anchors)[:, 0]
+    ref = O.acquisition_sweep(post, anchors, y_best, cost=2.0)[0].reshape(-1)
+    big = np.abs(ref) > 1e-6 * np.abs(ref).max()
+    assert np.allclose(scores[big], ref[big], rtol=1e-6) and int(np.argmax(scores)) == int(np.argmax(ref))
+    start = anchors[np.argsort(ref)[::-1][:1]]
+
+    def f_df(v):
+        f, df = O.expected_improvement_with_gradients(post, v[None, :], y_best)
+        return -float(f[0, 0]) / 2.0, -df[0] / 2.0
+    xo, fo, _ = fmin_l_bfgs_b(f_df, start.reshape(-1), bounds=bounds, maxfun=1000)
+    assert np.allclose(x_new[0], xo, atol=2e-4) and np.isclose(fx[0, 0], -fo, rtol=1e-5)
+    assert fx[0, 0] >= scores.max() * (1 - 1e-9)                     # L-BFGS improved on (or kept) the best anchor
+    np.random.seed(9)
+    y2, x2 = find_next_y_point(bounds, m, y_best, ["B", "D"], costs, anchors="uniform")
+    assert np.array_equal(x2, x_new) and np.isclose(y2[0, 0], fx[0, 0], rtol=1e-9)
+    m.close()
 
 
 # ---------------------------------------------------------------------------------- gradients + refinement (f3)
