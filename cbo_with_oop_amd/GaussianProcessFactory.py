@@ -131,6 +131,14 @@ class HipGaussianProcess:
         _lib.check(self._lib.cbo_gp_jitter(self._handle, ctypes.byref(tries), ctypes.byref(jitter)))
         self._note_jitter(tries.value, jitter.value)
 
+    def take_factor_slices(self, source, level, n_owners):
+        """The receiving side of ``cbo_comm_share_factor`` with device copies in the place of the transfers
+        (``cbo_gp_take_factor_slices``): this model takes ``source``'s factor at ``level`` in the ``n_owners`` row slices
+        the owners would send, and adopts it.  For tests on one GPU."""
+        _lib.check(self._lib.cbo_gp_take_factor_slices(self._handle, source._handle, int(level), int(n_owners)))
+        self.adopted_factor(level)
+        self.stale = False
+
     stale = False      # data uploaded, posterior not yet refitted (set_data(..., fit=False))
 
     @property

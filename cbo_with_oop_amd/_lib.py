@@ -18,7 +18,7 @@ c_int64_p = ctypes.POINTER(ctypes.c_int64)
 c_int_p = ctypes.POINTER(ctypes.c_int)
 c_void_pp = ctypes.POINTER(ctypes.c_void_p)
 
-ABI_VERSION = 4          # include/cbo_hip.h: CBO_HIP_ABI_VERSION
+ABI_VERSION = 5          # include/cbo_hip.h: CBO_HIP_ABI_VERSION
 ABI_DIAG_BASE = 1000     # CBO_HIP_ABI_DIAG_BASE: timing-only builds report ABI_DIAG_BASE + version
 CBO_OK = 0
 CBO_ERR_INVALID = -1
@@ -120,6 +120,7 @@ SIGNATURES = {
     "cbo_comm_gather_i64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_int64_p]),
     "cbo_comm_share_factor": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_int_p, ctypes.c_int,
                                               c_int_p, ctypes.c_int]),
+    "cbo_gp_take_factor_slices": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "cbo_schedule_report": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
     "cbo_trial_step": (ctypes.c_int, [ctypes.c_int, c_void_pp, c_void_pp, ctypes.c_int, ctypes.c_int64, c_double_p, c_double_p,
                                       c_double_p, c_double_p, c_double_p, ctypes.c_int, ctypes.c_double, c_double_p, c_double_p,

@@ -78,7 +78,7 @@ struct cbo_ctx {
     std::vector<hipEvent_t> pipe_events;      // factorisation -> sweep dependencies
     hipEvent_t ev_join = nullptr, ev_join2 = nullptr, ev_fork = nullptr;
     hipEvent_t region_a = nullptr, region_b = nullptr;
-    int pipe_chunk_blocks = 1;        // row blocks per update workgroup (CBO_HIP_PIPE_CHUNK; 1 since the updates go in K = 512 groups: profiles/r03_schedule_crossover.txt)
+    int pipe_chunk_blocks = 1;        // row blocks per update workgroup (1 since the updates go in K = 512 groups: profiles/r03_schedule_crossover.txt)
     bool pipe_half_lds = true;
     double pipe_tail_frac = -1.0;    // CBO_HIP_PIPE_TAIL: rows (fraction) left to the closing left-looking launch; < 0 = automatic
     int n_cu = 256;
@@ -293,28 +293,10 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
     int prio_low = 0, prio_high = 0;
     hipError_t e = hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_high);
-    // The look-ahead stream of the factorisation carries the bulk trailing updates.  CBO_HIP_CHAIN_RESERVE = k keeps
-    // k CUs per XCD away from it (for the chain's one-workgroup diagonal kernel); measured neutral at N = 4096 and
-    // -4 % at N = 16384, so the default is 0 = an ordinary high-priority stream.
-    if (e == hipSuccess) {
-        int keep = 0;
-        const char *cr = std::getenv("CBO_HIP_CHAIN_RESERVE");
-        if (cr) keep = std::atoi(cr);
-        const int n_cu = prop.multiProcessorCount;
-        bool made = false;
-        if (keep > 0 && keep * 8 < n_cu) {
-            std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
-            for (int b = 0; b < n_cu; ++b)
-                if (b / 8 >= keep) mask[(size_t)b / 32] |= 1u << (b % 32);
-            made = hipExtStreamCreateWithCUMask(&c->side_stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
-            if (!made) { (void)hipGetLastError(); c->side_stream = nullptr; }
-        }
-        if (!made) {
-            const char *sp = std::getenv("CBO_HIP_SIDE_PRIORITY");      // 1 = as high as the chain (round 1), default: normal
-            e = hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking,
-                                            (sp && std::atoi(sp) == 1) ? prio_high : (prio_low + prio_high) / 2);
-        }
-    }
+    // The look-ahead stream of the factorisation carries the bulk trailing updates: an ordinary stream one priority below
+    // the chain's (keeping CUs away from it, or raising it to the chain's priority, measured neutral to -4 %: NOTES.md).
+    if (e == hipSuccess)
+        e = hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, (prio_low + prio_high) / 2);
     // The sweep streams leave a few CUs per XCD to the factorisation: its diagonal-block kernel needs a whole
     // CU's LDS and would otherwise wait behind a queue of half-LDS sweep workgroups that keep every CU partly
     // occupied.  CU-mask bit b is CU b/8 of XCD b%8 on this device (scripts/probes/cumask_probe.hip).
@@ -361,8 +343,6 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
     }
     const char *ws = std::getenv("CBO_HIP_WORKSPACE_MB");
     if (ws) c->max_ws_bytes = (size_t)std::atoll(ws) << 20;
-    const char *cb = std::getenv("CBO_HIP_PIPE_CHUNK");
-    if (cb && std::atoi(cb) >= 1) c->pipe_chunk_blocks = std::atoi(cb);
     c->n_cu = prop.multiProcessorCount;
     const char *sm = std::getenv("CBO_HIP_SWEEP");
     if (sm) c->sweep_mode = std::atoi(sm);
@@ -374,8 +354,6 @@ extern "C" int cbo_init(int device_id, cbo_ctx **out)
     if (om) c->overlap_mode = std::atoi(om);
     const char *tf = std::getenv("CBO_HIP_PIPE_TAIL");
     if (tf) c->pipe_tail_frac = std::atof(tf);
-    const char *kb = std::getenv("CBO_HIP_PIPE_KB");
-    if (kb && std::atoi(kb) == 32) c->pipe_half_lds = false;
     {
         static std::once_flag once;
         std::call_once(once, [] { std::atexit(shutdown_all_at_exit); });
@@ -1635,20 +1613,6 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
         }
         {
             PhaseScope ps(c, PH_CHOL);
-#ifdef CBO_DIAG_KNOBS
-            // timing-only: factor first, then the same right-looking sweep launches with nothing beside them
-            if (std::getenv("CBO_DBG_PIPE_SERIAL")) {
-                launch_cholesky(c->stream, c->side_stream, c->chol_events, g->A, g->lda, g->n_pad, g->invDt, g->info);
-                hipMemcpy2DAsync(g->z, sizeof(double), g->A + g->n_pad, sizeof(double) * g->lda, sizeof(double),
-                                 (size_t)g->n_pad, hipMemcpyDeviceToDevice, c->stream);
-                int pr = 0;
-                for (int r0 = 0; r0 < pipe.tail_begin; r0 += 256, ++pr)
-                    sweep_pipe_pair(pipe, c->stream, g->A, g->lda, g->invDt, g->n_pad, pr, r0,
-                                    (r0 + 256 <= (int)g->n_pad) ? 256 : 128);
-                if (pipe.tail_begin < (int)g->n_pad)
-                    sweep_pipe_tail(pipe, c->stream, g->A, g->lda, g->invDt, g->n_pad, pr);
-            } else
-#endif
             launch_cholesky(c->stream, c->side_stream, c->chol_events, g->A, g->lda, g->n_pad, g->invDt, g->info, &pipe);
         }
         // join: everything the sweep streams were given is done before the main stream goes on (the last

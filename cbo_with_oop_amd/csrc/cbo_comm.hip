@@ -370,12 +370,25 @@ extern "C" int cbo_comm_share_factor(cbo_comm *m, cbo_gp *g, int level, const in
         if (needers[i] == m->rank) i_need = true;
     }
     if (my_owner >= 0 && i_need) return set_error(CBO_ERR_INVALID, "a rank cannot both hold and need the factor");
-    if (my_owner >= 0 && !gp_is_fitted_at(g, level))
-        return set_error(CBO_ERR_INVALID, "this rank is listed as an owner but does not hold the factor at that level");
-    if (n_needers == 0 || (my_owner < 0 && !i_need)) return CBO_OK;
+    if (n_needers == 0) return CBO_OK;                    // (the same lists on every rank: everybody returns here together)
+    // What only THIS rank can know -- it is listed as an owner but does not hold the factor, its RCCL lacks the point-to-point
+    // calls -- must not make it leave while its peers enter the send / receive group and wait for it for ever: every rank of
+    // the communicator exchanges a status word first (one all-gather of one integer), and all refuse together.
+    int64_t status = 0;
+    if (my_owner >= 0 && !gp_is_fitted_at(g, level)) status = 1;
     rc = need_rccl();
     if (rc != CBO_OK) return rc;
-    if (!rccl().Send || !rccl().Recv) return set_error(CBO_ERR_COMM, "this RCCL has no ncclSend / ncclRecv");
+    if (!rccl().Send || !rccl().Recv) status = 2;
+    std::vector<int64_t> all((size_t)m->world, 0);
+    rc = cbo_comm_gather_i64(m, status, all.data());
+    if (rc != CBO_OK) return rc;
+    for (int r = 0; r < m->world; ++r) {
+        if (all[(size_t)r] == 1)
+            return set_error(CBO_ERR_INVALID, "rank " + std::to_string(r) + " is listed as an owner but does not hold the factor at that level");
+        if (all[(size_t)r] == 2)
+            return set_error(CBO_ERR_COMM, "the RCCL of rank " + std::to_string(r) + " has no ncclSend / ncclRecv");
+    }
+    if (my_owner < 0 && !i_need) return CBO_OK;
     hipError_t e = hipSetDevice(ctx_device(m->ctx));
     // the model's own stream has produced (owner) or will consume (needer) the factor: order the exchange behind it
     if (e == hipSuccess) e = hipStreamSynchronize(ctx_stream(m->ctx));
@@ -404,4 +417,36 @@ extern "C" int cbo_comm_share_factor(cbo_comm *m, cbo_gp *g, int level, const in
     e = hipStreamSynchronize(m->stream);
     if (e != hipSuccess) return hip_fail("share_factor: wait", e);
     return i_need ? gp_adopt_received_factor(g, level) : CBO_OK;
+}
+
+// The needer's side of cbo_comm_share_factor with device copies standing in for ncclRecv: `dst` (the same data and
+// hyper-parameters as `src`, not fitted at `level`) takes the factor of `src` in the n_owners row slices of factor_slice --
+// whole rows of lda doubles and the 16x16 diagonal inverses of the same rows, slice by slice into the places the receives
+// write -- and adopts it.  A one-GPU box cannot run the transfer between ranks (with one rank nobody lacks the factor); this
+// pins everything around it: the split, the layout of what travels, the adoption (tests/test_parity_gpu.py).
+extern "C" int cbo_gp_take_factor_slices(cbo_gp *dst, cbo_gp *src, int level, int n_owners)
+{
+    if (!dst || !src || n_owners <= 0) return set_error(CBO_ERR_INVALID, "bad argument");
+    double *As = nullptr, *invs = nullptr, *Ad = nullptr, *invd = nullptr;
+    int64_t ldas = 0, ns = 0, ldad = 0, nd = 0;
+    cbo_ctx *cs = nullptr, *cd = nullptr;
+    int rc = gp_factor_view(src, &As, &ldas, &ns, &invs, &cs);
+    if (rc == CBO_OK) rc = gp_factor_view(dst, &Ad, &ldad, &nd, &invd, &cd);
+    if (rc != CBO_OK) return rc;
+    if (cs != cd || ldas != ldad || ns != nd) return set_error(CBO_ERR_INVALID, "the two models do not have the same shape and context");
+    if (!gp_is_fitted_at(src, level)) return set_error(CBO_ERR_INVALID, "the source does not hold the factor at that level");
+    hipError_t e = hipSetDevice(ctx_device(cs));
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx_stream(cs));
+    for (int i = 0; i < n_owners && e == hipSuccess; ++i) {
+        int64_t r0 = 0, r1 = 0;
+        factor_slice(ns, n_owners, i, &r0, &r1);
+        if (r1 <= r0) continue;
+        e = hipMemcpyAsync(Ad + r0 * ldad, As + r0 * ldas, sizeof(double) * (size_t)((r1 - r0) * ldas), hipMemcpyDeviceToDevice, ctx_stream(cs));
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(invd + (r0 / 16) * 256, invs + (r0 / 16) * 256, sizeof(double) * (size_t)((r1 - r0) / 16 * 256),
+                               hipMemcpyDeviceToDevice, ctx_stream(cs));
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx_stream(cs));
+    if (e != hipSuccess) return hip_fail("take_factor_slices", e);
+    return gp_adopt_received_factor(dst, level);
 }

@@ -13,8 +13,7 @@
 //                                 Choleskys, three waves solve the block's row panel and update its trailing tiles) and
 //                                 publishes finished row tiles; the other workgroups are the panel's 64-column strips
 //                                 and follow tile by tile.  Separate launches (CBO_HIP_PANEL_FORM=2):
-//                                 potrf_diag128_v2_kernel + panel_trsm_kernel; round 1's forms: potrf_diag128_kernel,
-//                                 trsm_strip_kernel as panel solver
+//                                 potrf_diag128_v2_kernel + panel_trsm_kernel
 //   2. syrk_rows_kernel           the next panel's (pair's) own rows  -= P^T P   (the piece of the update on the chain)
 //   3. syrk_kernel<64> / trsm_update_kernel   the bulk of  A[below, below] -= P^T P  on a second stream (fp64 MFMA),
 //                                 rhs -= P^T z  along with it
@@ -35,21 +34,6 @@ namespace cbo {
 
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-// Timing-only build (make DIAG=1 -> libcbo_hip_diag.so): CBO_DBG_CHOL is a bit mask of phases to skip so
-// that rocprofv3 --stats prices each one; results are wrong by construction.  Not compiled into the product.
-#ifdef CBO_DIAG_KNOBS
-#include <cstdlib>
-static int chol_dbg_mask()
-{
-    static int m = -1;
-    if (m < 0) { const char *e = std::getenv("CBO_DBG_CHOL"); m = e ? std::atoi(e) : 0; }
-    return m;
-}
-#define DBG_SKIP(bit) (dbg & (bit))
-#else
-#define DBG_SKIP(bit) false
-#endif
-
 __device__ __forceinline__ double readlane_f64(double v, int lane)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -59,202 +43,6 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 
 // ------------------------------------------------------------------------------------------------
 constexpr int kDiagLd = 144;   // LDS row stride (doubles): rows kq and kq+1 of a fragment are 32 banks apart
-
-struct DiagShared {
-    double S[128][kDiagLd];    // the block; upper triangle is meaningful
-    double rz[128];            // rhs column
-    double Yt[16][16];         // inverse of the current 16x16 diagonal factor: Yt[k][i] = inv(L_d)[i][k]
-};
-
-// Register Cholesky of the 16x16 tile at (o, o), executed by one wave with the tile in the fp64-MFMA
-// accumulator layout: lane (kq = lane>>4, lc = lane&15) holds d[r] = D[kq + 4r][lc].  Rows 4b..4b+3 are
-// then register d[b] of the four lane groups, so after the four pivots of sub-block b that register IS
-// both MFMA operands of the rank-4 update  D -= U_b^T U_b  (A[i][k] = U[4b+k][i], B[k][j] = U[4b+k][j]).
-// Per pivot: one broadcast of the pivot (readlane), one reciprocal square root, two lane permutes.
-__device__ __forceinline__ void diag_tile_factor(DiagShared &sh, int o, int lane, int pivot_base, int *info,
-                                                 double *__restrict__ invDt_tile)
-{
-    const int lc = lane & 15, kq = lane >> 4;
-    // d: the tile; e: the identity carried through the same row operations, ending as inv(L_d) = inv(U_d)^T
-    d4 d, e;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        d[r] = (kq + 4 * r <= lc) ? sh.S[o + kq + 4 * r][o + lc] : 0.0;
-        e[r] = (kq + 4 * r == lc) ? 1.0 : 0.0;
-    }
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int piv = 4 * b + j;                          // row (kq == j, register b), column lc == piv
-            double pj = readlane_f64(d[b], 16 * j + piv);
-            if (!(pj > 0.0)) {                                  // LAPACK: ajj <= 0 or NaN -> info = j
-                if (lane == 0) atomicCAS(info, 0, pivot_base + o + piv + 1);
-                pj = 1.0;                                       // keep the arithmetic finite; result is discarded
-            }
-            // d = sqrt(p) and 1/d from one reciprocal square root (1-2 ulp; the row is scaled by the same 1/d)
-            const double inv = rsqrt(pj);
-            const double dj = pj * inv;
-            const double scaled = (lc > piv) ? d[b] * inv : ((lc == piv) ? dj : 0.0);
-            if (kq == j) {                                       // row piv is final (zeros left of the diagonal)
-                d[b] = scaled;
-                e[b] *= inv;
-            }
-            if (j < 3) {
-                const double ujc = __shfl(d[b], 16 * j + lc);            // U[piv][lc]
-                const double ejc = __shfl(e[b], 16 * j + lc);            // E[piv][lc]
-                const double ujr = __shfl(d[b], 16 * j + 4 * b + kq);    // U[piv][row of this lane]
-                if (kq > j) {                                            // rows piv+1 .. 4b+3
-                    d[b] = fma(-ujr, ujc, d[b]);
-                    e[b] = fma(-ujr, ejc, e[b]);
-                }
-            }
-        }
-        if (b < 3) {
-            const d4 keep = d, keep_e = e;
-            const double na = -d[b];
-            d = MFMA_F64(na, d[b], d);                           // rows below the sub-block: D -= U_b^T U_b
-            e = MFMA_F64(na, e[b], e);                           //                           E -= U_b^T E_b
-#pragma unroll
-            for (int r = 0; r <= b; ++r) { d[r] = keep[r]; e[r] = keep_e[r]; }   // finished rows stay
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        sh.S[o + kq + 4 * r][o + lc] = d[r];
-        sh.Yt[lc][kq + 4 * r] = e[r];                            // Yt[k][i] = E[i][k]
-        invDt_tile[lc * 16 + kq + 4 * r] = e[r];                 // = inv(U_d) row-major, what the strip TRSM reads
-    }
-}
-
-// One 16x16 tile of the rank-16 update: S[r0.., c0..] -= U[o.., r0..]^T U[o.., c0..]
-__device__ __forceinline__ void diag_tile_update(DiagShared &sh, int o, int r0, int c0, int lc, int kq)
-{
-    d4 acc;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = sh.S[r0 + kq + 4 * r][c0 + lc];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const double a = sh.S[o + 4 * kk + kq][r0 + lc];
-        const double b = sh.S[o + 4 * kk + kq][c0 + lc];
-        acc = MFMA_F64(a, -b, acc);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sh.S[r0 + kq + 4 * r][c0 + lc] = acc[r];
-}
-
-__global__ __launch_bounds__(256) void potrf_diag128_kernel(double *A, int64_t lda, int r0, int rcol,
-                                                            double *__restrict__ invDt, int *info, int dbg,
-                                                            double *__restrict__ zvec)
-{
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    DiagShared &sh = *reinterpret_cast<DiagShared *>(smem_raw);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int lc = lane & 15, kq = lane >> 4;
-
-    // load the block by LDS-DMA: one 1 KiB row per instruction, 32 rows per wave, all in flight at once
-    // (the part below the diagonal comes along and is never read)
-    {
-        const int wv = __builtin_amdgcn_readfirstlane(wave);
-        const unsigned s0 = lds_byte_address(&sh.S[0][0]);
-        const double *g = A + (int64_t)(r0 + wv * 32) * lda + r0 + lane * 2;
-#pragma unroll 8
-        for (int p = 0; p < 32; ++p)
-            glds16(g + (int64_t)p * lda, __builtin_amdgcn_readfirstlane(s0 + 8u * (unsigned)((wv * 32 + p) * kDiagLd)));
-    }
-    if (tid < 128) sh.rz[tid] = A[(int64_t)(r0 + tid) * lda + rcol];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (wave == 0 && !DBG_SKIP(1)) diag_tile_factor(sh, 0, lane, r0, info, invDt + (int64_t)(r0 / 16) * 256);
-    __syncthreads();
-
-    for (int jb = 0; jb < 8; ++jb) {
-        if (DBG_SKIP(32)) break;
-        const int o = 16 * jb;
-        // ---- B: row panel  X = inv(L_d) S[o:o+16, o+16:]  by MFMA (16x16 tiles round-robin over the waves)
-        //         and the rhs rows by 16 threads
-        if (!DBG_SKIP(2)) {
-            double af[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) af[kk] = sh.Yt[4 * kk + kq][lc];
-            for (int ct = jb + 1 + wave; ct < 8; ct += 4) {
-                d4 x = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) x = MFMA_F64(af[kk], sh.S[o + 4 * kk + kq][16 * ct + lc], x);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sh.S[o + kq + 4 * r][16 * ct + lc] = x[r];
-            }
-            if (tid >= 240) {                                   // last 16 lanes of wave 3: z_blk = inv(L_d) r_blk
-                const int i = tid - 240;
-                double s = 0.0;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) s = fma(sh.Yt[k][i], sh.rz[o + k], s);
-                // every lane has read the old rhs rows before any lane overwrites them (same wave, in order)
-                sh.rz[o + i] = s;
-            }
-        }
-        __syncthreads();
-        if (jb == 7) break;
-        // ---- C: rank-16 update of the trailing upper tiles; wave 0 takes the next diagonal tile and
-        //         factors it right away while waves 1-3 update the rest
-        if (wave == 0) {
-            diag_tile_update(sh, o, o + 16, o + 16, lc, kq);
-            // its rhs rows:  rz[o+16 .. o+32) -= U[o.., r]^T z[o..]
-            if (lane < 16) {
-                double s = sh.rz[o + 16 + lane];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) s = fma(-sh.S[o + k][o + 16 + lane], sh.rz[o + k], s);
-                sh.rz[o + 16 + lane] = s;
-            }
-            __builtin_amdgcn_s_waitcnt(0xC07F);    // lgkmcnt(0): the LDS stores above are visible to this wave's reads
-            if (!DBG_SKIP(1)) diag_tile_factor(sh, o + 16, lane, r0, info, invDt + (int64_t)(r0 / 16 + jb + 1) * 256);
-        } else if (!DBG_SKIP(4)) {
-            int idx = 0;
-            for (int ti = jb + 1; ti < 8; ++ti)
-                for (int tj = ti; tj < 8; ++tj) {
-                    if (ti == jb + 1 && tj == jb + 1) continue;
-                    if (idx % 3 == wave - 1) diag_tile_update(sh, o, 16 * ti, 16 * tj, lc, kq);
-                    ++idx;
-                }
-            // rhs rows below the next tile
-            const int t = tid - 64;                // 0..191
-            const int r = o + 32 + t;
-            if (r < 128) {
-                double s = sh.rz[r];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) s = fma(-sh.S[o + k][r], sh.rz[o + k], s);
-                sh.rz[r] = s;
-            }
-            // rows o .. o+15 of the factor are final: write them out now, off the critical path of wave 0
-            for (int idx = t; idx < 16 * 64; idx += 192) {
-                const int i = o + (idx >> 6), j2 = (idx & 63) * 2;
-                if (j2 + 1 >= i) {
-                    d2 v;
-                    v[0] = (j2 >= i) ? sh.S[i][j2] : 0.0;
-                    v[1] = sh.S[i][j2 + 1];
-                    *reinterpret_cast<d2 *>(&A[(int64_t)(r0 + i) * lda + r0 + j2]) = v;
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- outputs: the last 16 rows of the factor (the others left during the loop) and z
-    for (int idx = tid; idx < 16 * 64 && !DBG_SKIP(16); idx += 256) {
-        const int i = 112 + (idx >> 6), j2 = (idx & 63) * 2;
-        if (j2 + 1 >= i) {
-            d2 v;
-            v[0] = (j2 >= i) ? sh.S[i][j2] : 0.0;
-            v[1] = sh.S[i][j2 + 1];
-            *reinterpret_cast<d2 *>(&A[(int64_t)(r0 + i) * lda + r0 + j2]) = v;
-        }
-    }
-    if (tid < 128) {
-        A[(int64_t)(r0 + tid) * lda + rcol] = sh.rz[tid];
-        if (zvec) zvec[r0 + tid] = sh.rz[tid];          // contiguous copy for a sweep that runs alongside
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Second form of the diagonal-block kernel: the same arithmetic per tile, decoupled waves.
@@ -1538,7 +1326,7 @@ void launch_small_sets(hipStream_t s, const cbo_small_set *sets, int n_sets, int
 // Extra blocks (blockIdx.x == nt) update the rhs column: r[i] -= sum_k P[k][i] z[k].
 template <int TS>
 __global__ __launch_bounds__(256) void syrk_kernel(double *A, int64_t lda, int r0, int n1, int c0, int nt, int rcol,
-                                                   int ti_begin, int dbg, const int *__restrict__ skip_if)
+                                                   int ti_begin, const int *__restrict__ skip_if)
 {
     if (__builtin_nontemporal_load(skip_if) != 0) return;
     const int tj = blockIdx.x, ti = blockIdx.y + ti_begin;
@@ -1620,15 +1408,11 @@ __global__ __launch_bounds__(256) void syrk_kernel(double *A, int64_t lda, int r
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             cv[m][r] = *reinterpret_cast<const d2 *>(&A[(ib + 2 * (kq + 4 * r) + m) * lda + jb + 2 * lc]);
-    for (int k0 = 0; k0 < n1 && !DBG_SKIP(64); k0 += 8 * CH) {
+    for (int k0 = 0; k0 < n1; k0 += 8 * CH) {
         if (k0 + 4 * CH < n1) load_chunk(k0 + 4 * CH, a[1], b[1]);
         mfma_chunk(a[0], b[0]);
         if (k0 + 8 * CH < n1) load_chunk(k0 + 8 * CH, a[0], b[0]);
         if (k0 + 4 * CH < n1) mfma_chunk(a[1], b[1]);
-    }
-    if (DBG_SKIP(128)) {
-        if (acc[0][0][0] == 12345.678) A[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];   // keep acc live
-        return;
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -1749,14 +1533,8 @@ static void launch_syrk(hipStream_t s, double *A, int64_t lda, int r0, int n1, i
     const int nt = n2 / 64;
     if (ti_end > nt) ti_end = nt;
     if (ti_end <= ti_begin) return;
-#ifdef CBO_DIAG_KNOBS
-    const int dbg = chol_dbg_mask();
-    if (dbg & 256) return;
-#else
-    const int dbg = 0;
-#endif
     hipLaunchKernelGGL(syrk_kernel<64>, dim3(nt + 1, ti_end - ti_begin), dim3(256), 0, s, A, lda, r0, n1, c0, nt, rcol,
-                       ti_begin, dbg, skip_if);
+                       ti_begin, skip_if);
 }
 
 // Rows [r0, r0 + klen) of U (all columns) and of z are final on stream `chain`: hand them to the sweep.
@@ -1874,8 +1652,6 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
 {
     // > 64 KiB of dynamic LDS needs the opt-in on the current device (cheap; done per call so that several
     // devices in one process are all covered)
-    hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)sizeof(DiagShared));
     hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag128_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)sizeof(Diag2Shared));
     hipFuncSetAttribute(reinterpret_cast<const void *>(panel_trsm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1888,18 +1664,13 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     const int panel_form = g_panel_form_override > 0 ? g_panel_form_override : panel_form_env;
     // polls a strip of a fused launch makes before it gives up (read per factorisation: a test sets it to -1)
     const int spin_limit = [] { const char *e = std::getenv("CBO_HIP_FUSED_SPIN_LIMIT"); return e ? std::atoi(e) : kFusedSpinLimit; }();
-    static const int syrk_gemm_rows = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_ROWS"); return e ? std::atoi(e) : 6144; }();
-    static const int syrk_gemm_chunk = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_CHUNK"); return e ? std::atoi(e) : 1; }();
-    static const bool syrk_gemm_half = [] { const char *e = std::getenv("CBO_HIP_SYRK_GEMM_KB"); return !(e && std::atoi(e) == 32); }();
-    static const int syrk_rows_form = [] { const char *e = std::getenv("CBO_HIP_SYRK_ROWS_FORM"); return e ? std::atoi(e) : 2; }();
-    static const int diag_form = [] { const char *e = std::getenv("CBO_HIP_DIAG_FORM"); return e ? std::atoi(e) : 2; }();
+    // the bulk trailing update takes the LDS-staged GEMM form (trsm_update_kernel<16>, one row block per workgroup) while
+    // at least this many rows lie below the pair, the 64x64-tile SYRK from L2 fragments below that (round-2 scan)
+    constexpr int syrk_gemm_rows = 6144, syrk_gemm_chunk = 1;
+    constexpr bool syrk_gemm_half = true;
     auto launch_diag = [&](int rr) {
-        if (diag_form == 1)
-            hipLaunchKernelGGL(potrf_diag128_kernel, dim3(1), dim3(256), sizeof(DiagShared), s, A, lda, rr, (int)n_pad, invDt,
-                               info_dev, 0, pipe ? pipe->zvec : nullptr);
-        else
-            hipLaunchKernelGGL(potrf_diag128_v2_kernel, dim3(1), dim3(256), sizeof(Diag2Shared), s, A, lda, rr, (int)n_pad,
-                               invDt, info_dev, pipe ? pipe->zvec : nullptr);
+        hipLaunchKernelGGL(potrf_diag128_v2_kernel, dim3(1), dim3(256), sizeof(Diag2Shared), s, A, lda, rr, (int)n_pad,
+                           invDt, info_dev, pipe ? pipe->zvec : nullptr);
     };
     const int np = (int)(n_pad / 128);
     // info_dev[0] is the status word; info_dev[1 + 2p], [2 + 2p] the publication counts of panel p's fused launch
@@ -1909,11 +1680,6 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(256), 0, s, info_dev, fused ? 1 + 2 * np : 1);
     int *flags = info_dev + 1;
     const int rcol = (int)n_pad;
-#ifdef CBO_DIAG_KNOBS
-    const int dbg = chol_dbg_mask();
-#else
-    const int dbg = 0;
-#endif
     while ((int)events.size() < 2 * np + 2) {
         hipEvent_t e;
         hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence);
@@ -1955,14 +1721,14 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     // per group) are the price: they run on the chain stream beside the bulk update.  Groups are used while both
     // pairs' bulk updates would take the GEMM form anyway; the last ~6000 rows go pair by pair as before.
     static const int bulk_group = [] { const char *e = std::getenv("CBO_HIP_BULK_GROUP"); return e ? std::atoi(e) : 2; }();
-    static const bool group_split = [] { const char *e = std::getenv("CBO_HIP_GROUP_SPLIT"); return !(e && std::atoi(e) == 0); }();
+    constexpr bool group_split = true;     // inside groups the strips of a fused launch go as an LDS-free launch of their own
     bool second_of_group = false;          // this pair closes a group whose first pair went without a bulk update
     int pending_big_a = -1;                // event index of the last bigA
     for (int k = 0; k < np; k += 2) {
         const int r0 = 128 * k;
         const int n2 = (int)n_pad - r0 - 128;
         const int n3_pair = (int)n_pad - r0 - 256;                   // rows below this pair
-        const bool first_of_group = !second_of_group && bulk_group == 2 && (fused || lean_panel) && syrk_rows_form == 2 &&
+        const bool first_of_group = !second_of_group && bulk_group == 2 && (fused || lean_panel) &&
                                     n3_pair - 512 >= syrk_gemm_rows && n3_pair - 512 >= 512;
         const bool grouped = first_of_group || second_of_group;
         // beside a bulk update that fills the device the strips go as an LDS-free launch of their own (launch_panel_fused)
@@ -1976,14 +1742,13 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         launch_trsm_strips(s, A + (int64_t)r0 * lda + r0, lda, invDt + (int64_t)(r0 / 16) * 256,
                            A + (int64_t)r0 * lda + r0 + 128, lda, 128, n2, nullptr, nullptr, nullptr, false, half_lds);
         // rows of the pair's second panel: K = 128 update with the first panel
-        if (syrk_rows_form == 2) launch_syrk_rows(s, A, lda, r0, 128, n2, rcol, info_dev);
-        else launch_syrk(s, A, lda, r0, 128, n2, rcol, 0, 2, info_dev);
+        launch_syrk_rows(s, A, lda, r0, 128, n2, rcol, info_dev);
         const int r1 = r0 + 128;
         const int n3 = (int)n_pad - r1 - 128;
         const bool bulk = n3 > 256;
         const bool gemm_form = bulk && n3 - 256 >= syrk_gemm_rows;
         // the event the side stream waits for completes WITH the launch it follows (no marker packet on the chain)
-        const bool carried = bulk && (fused || lean_panel) && syrk_rows_form == 2;
+        const bool carried = bulk && (fused || lean_panel);
         const hipEvent_t ev_panel = (carried && gemm_form && !first_of_group) ? events[2 * k] : nullptr;
         const hipEvent_t ev_rows = (carried && !gemm_form) ? events[2 * k] : nullptr;
         if (fused && n3 > 0)
@@ -2046,8 +1811,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         };
         if (gemm_form) launch_bulk();
         if (prev >= 0) hipStreamWaitEvent(s, events[prev], 0);
-        if (syrk_rows_form == 2) launch_syrk_rows(s, A, lda, r0, 256, n3, rcol, info_dev, 256, ev_rows);
-        else launch_syrk(s, A, lda, r0, 256, n3, rcol, 0, 4, info_dev);
+        launch_syrk_rows(s, A, lda, r0, 256, n3, rcol, info_dev, 256, ev_rows);
         if (bulk && !gemm_form) launch_bulk();
     }
     // nothing is left on the side stream that the main stream has not waited for (the last bulk update is

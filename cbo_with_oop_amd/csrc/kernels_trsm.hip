@@ -57,27 +57,12 @@ struct StageGeom {
     static_assert(kParts <= kKS - 2, "the DMA groups and the cursor update ride under the first k-steps");
 };
 #ifdef CBO_DIAG_KNOBS
-// Timing-only build: workgroup 0 / wave 0 stamps s_memtime around the barrier and at the end of every stage
-// (3 stamps per stage) into a debug buffer read back by cbo_diag_trsm_stamps (scripts/trsm_timeline.py).
+// Timing-only build (make DIAG=1 -> libcbo_hip_diag.so): waves 0 and 4 of workgroup 0 of trsm_pair_kernel stamp s_memtime at
+// the milestones of every stage into a debug buffer read back by cbo_diag_trsm_stamps (scripts/pair_timeline.py).
 __device__ unsigned long long g_trsm_stamps[8 * 4096];
-#define STAMP(slot)                                                                          \
-    do {                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        if (stamp_on && stamp_i < 4096) g_trsm_stamps[8 * stamp_i + (slot)] = __builtin_amdgcn_s_memtime(); \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-    } while (0)
-#define STAMP_NEXT() do { if (stamp_on) ++stamp_i; } while (0)
-__device__ unsigned long long g_trsm_fine[4 * 16];      // [diagonal stage][point] of one block, solver wave of column group 0
-extern "C" int cbo_diag_trsm_fine(unsigned long long *out)
+extern "C" int cbo_diag_trsm_stamps(unsigned long long *out, int n)
 {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trsm_fine), sizeof(unsigned long long) * 4 * 16);
-}
-// Timing-only: every workgroup of the last trsm_strip8_kernel launch leaves its lifetime in shader cycles (s_memtime) and in
-// s_memrealtime's 100 MHz ticks: the shader clock under the kernel (scripts/strip_scaling.py prints it in a diagnostic build)
-__device__ unsigned long long g_strip_clock[2 * 4096];
-extern "C" int cbo_diag_strip_clock(unsigned long long *out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_strip_clock), sizeof(unsigned long long) * 2 * 4096);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trsm_stamps), sizeof(unsigned long long) * (size_t)n);   // 8 per stage
 }
 // Timing-only: every workgroup of the last trsm_update_kernel launch leaves [start, end, hw id | xcc id << 32, start, end in
 // s_memrealtime's 100 MHz] (s_memtime runs at the shader clock), and
@@ -90,13 +75,6 @@ extern "C" int cbo_diag_upd_stamps(unsigned long long *wg, unsigned long long *s
     if (rc == 0) rc = (int)hipMemcpyFromSymbol(stage, HIP_SYMBOL(g_upd_stage), sizeof(unsigned long long) * 128);
     return rc;
 }
-extern "C" int cbo_diag_trsm_stamps(unsigned long long *out, int n)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trsm_stamps), sizeof(unsigned long long) * (size_t)n);   // 8 per stage
-}
-#else
-#define STAMP(slot)
-#define STAMP_NEXT()
 #endif
 
 // One continuous software pipeline over "stages" of KB U-rows (described for KB = 32).  Row block b (rows
@@ -218,10 +196,6 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
     advance(ahead);
     issue_stage(ahead, 1);
     advance(ahead);
-#ifdef CBO_DIAG_KNOBS
-    const bool stamp_on = SWEEP && blockIdx.x == 0 && tid == 0;
-    int stamp_i = 0;
-#endif
     int buf = 0;                 // buffer of the current stage; stage g+2 goes to (buf + 2) % 3
     int extra_prev = 0;          // VMEM operations the previous stage issued after its DMA (its V stores)
     // q = sum V^2 and mu = V^T z: lane partials over a PAIR of row blocks (256 rows), reduced over the four
@@ -253,11 +227,8 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
         for (int j = 0; j < nst; ++j) {
             // every LDS read this wave issued for the previous stage has returned: after the barrier other
             // waves' DMA may overwrite that buffer
-            STAMP(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            STAMP(3);
             STAGE_TOP();
-            STAMP(1);
             __builtin_amdgcn_sched_barrier(0);
             const int bnext = (buf >= 1) ? buf - 1 : 2;       // (buf + 2) % 3
             extra_prev = 0;
@@ -280,7 +251,6 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            STAMP(4);
 #pragma unroll
             for (int jj = 0; jj < kKS - 1; ++jj) {
                 const double *an = abase + 4 * (jj + 1) * kLdsLd;
@@ -308,8 +278,6 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
                 }
             }
             deferred = true;                                              // the last k-step sits in af[1], bf[1]
-            STAMP(2);
-            STAMP_NEXT();
             buf = (buf == 2) ? 0 : buf + 1;
         }
         if (deferred) {
@@ -320,9 +288,7 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
         // ---- diagonal stages (KB rows each): X_s = inv(L_ss) R_s, then R_t -= L_ts X_s for the tiles below
 #pragma unroll
         for (int m = 0; m < kDS; ++m) {
-            STAMP(0);
             STAGE_TOP();
-            STAMP(1);
             if (m == 0 && i0 + kRB < n) {
                 // next block's right-hand sides (K* rows) -- issued before this stage's DMA so that the
                 // DMA waits further down never have to cover them early
@@ -425,8 +391,6 @@ __global__ __launch_bounds__(256) void trsm_strip_kernel(const double *__restric
                 }
             }
             extra_prev = 1;
-            STAMP(2);
-            STAMP_NEXT();
             buf = (buf == 2) ? 0 : buf + 1;
         }
 #pragma unroll
@@ -489,16 +453,6 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
     __shared__ __align__(16) double lds[kNBuf * (kABuf + kBBuf)];      // 159,744 B
     __shared__ __align__(16) double zl[SWEEP ? 2 * kRB : 2];           // z rows of the current and the next block
 
-#ifdef CBO_DIAG_KNOBS
-    // timing-only masks (CBO_HIP_STRIP_MASK, results are wrong): 1 = no arithmetic in the diagonal stages (barriers, DMA
-    // and loads stay), 2 = no hand-issued loads for the next block, 4 = no V stores, 8 / 16 = the V pieces / U tiles of every stage come from one fixed place (no HBM traffic),
-    // 256 = stage stamps on (they perturb the run: the stamp stores are not in the stage-top accounting)
-    const int dmask = accumulate >> 8;
-    accumulate &= 1;
-    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
-#else
-    constexpr int dmask = 0;
-#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform: LDS bases stay scalar
@@ -524,7 +478,6 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
     };
     auto locate_b = [&](StageCursor &c) __attribute__((always_inline)) {
         c.a_src = ug + (int64_t)(KB * c.aj) * ldu + c.ai0;
-        if (dmask & 16) c.a_src = ug;                          // timing only: every U tile from the same (cached) rows
     };
     auto locate_c = [&](StageCursor &c) __attribute__((always_inline)) {
         const int nreg = c.ai0 / KB;
@@ -534,7 +487,6 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
         const uintptr_t base = (uintptr_t)vg + ((uintptr_t)inv_lane - (uintptr_t)vg) * (uintptr_t)diag;
         c.b_src = reinterpret_cast<const double *>(base) + (off_reg + (off_diag - off_reg) * diag);
         c.b_stride = 8 * ldv + (128 - 8 * ldv) * diag;
-        if (dmask & 8) c.b_src = vg;                           // timing only: every V piece from the same (cached) rows
     };
     auto step = [&](StageCursor &c) __attribute__((always_inline)) {
         const int wrap = (c.j + 1 == c.lim) ? 1 : 0;
@@ -605,10 +557,8 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
 
     // block 0 has no regular stage to spread block 1's ahead loads over: they go first, ahead of the whole DMA stream
     // (the first stage top retires them)
-    if (!(dmask & 2)) {
 #pragma unroll
-        for (int sl = 0; sl < kAhead; ++sl) request_one(0, sl);
-    }
+    for (int sl = 0; sl < kAhead; ++sl) request_one(0, sl);
     locate_a(ahead);
     locate_b(ahead);
     locate_c(ahead);
@@ -618,28 +568,6 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
     advance(ahead);
 
     int buf = 0;
-#ifdef CBO_DIAG_KNOBS
-    // waves 0 (upper half) and 4 (lower half) of workgroup 0 stamp slots 0..2 / 4..6 of each stage's record
-    const bool stamp_on = SWEEP && (dmask & 256) && blockIdx.x == 0 && lane == 0 && cw == 0;    // CBO_HIP_STRIP_MASK=256
-    const int stamp_base = 4 * h;
-    int stamp_i = 0;
-#define STAMP8(slot)                                                                                    \
-    do {                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                              \
-        if (stamp_on && stamp_i < 4096) g_trsm_stamps[8 * stamp_i + stamp_base + (slot)] = __builtin_amdgcn_s_memtime(); \
-        __builtin_amdgcn_sched_barrier(0);                                                              \
-    } while (0)
-#define FINE(pt)                                                                                        \
-    do {                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                              \
-        if ((dmask & 512) && blockIdx.x == 0 && lane == 0 && cw == 0 && i0 == 2048)                     \
-            g_trsm_fine[16 * m + (pt)] = __builtin_amdgcn_s_memtime();                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                              \
-    } while (0)
-#else
-#define STAMP8(slot)
-#define FINE(pt)
-#endif
     double qacc = 0.0, macc = 0.0, qtot = 0.0, mtot = 0.0;       // totals live in the h = 1 waves
     if (SWEEP && accumulate && h == 1) {
         qtot = q_out[colw + lc];
@@ -681,9 +609,7 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
         // one per MFMA slot ahead of the stage's last DMA instruction
         auto regular_stage = [&](auto first_tag) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
-            STAMP8(0);
             STAGE8_TOP();
-            STAMP8(1);
             const int bnext = (buf >= 1) ? buf - 1 : 2;       // (buf + 2) % 3
             const double *abase = lds + buf * kABuf + kq * kLdsLd + lc + 64 * h;
             const double *bbase = ldsB + buf * kBBuf + cw * (KB * 16) + kq * 16 + lc;
@@ -713,7 +639,7 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
                     } else if (jj < kDma8) {
                         issue_one(ahead, bnext, jj);                      // stage g+2's DMA rides under the MFMAs
                     }
-                    if (FIRST && t < 3 && 3 * jj + t < kAhead && !(dmask & 2)) request_one(i0, 3 * jj + t);
+                    if (FIRST && t < 3 && 3 * jj + t < kAhead) request_one(i0, 3 * jj + t);
                     if (jj == kDma8) {                                    // cursor bookkeeping under the MFMAs too
                         if (t == 0) step(ahead);
                         if (t == 1) locate_a(ahead);
@@ -723,10 +649,8 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (FIRST && !(dmask & 2)) b1 += kAhead;
+            if (FIRST) b1 += kAhead;
             deferred = true;                                              // the last k-step sits in af[1], bf[1]
-            STAMP8(2);
-            STAMP_NEXT();
             buf = (buf == 2) ? 0 : buf + 1;
         };
         static_assert(3 * (kDma8 - 1) + 2 >= kAhead - 1, "every ahead load has a slot before the stage's last DMA instruction");
@@ -740,11 +664,8 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
         // ---- diagonal stages (two 16-row tiles each): tiles 2m, 2m+1 belong to the waves of half m >> 1
 #pragma unroll
         for (int m = 0; m < kDS; ++m) {
-            STAMP8(0);
             STAGE8_TOP();
-            STAMP8(1);
             const int hs = m >> 1;                            // the solving half
-            if (h == hs) FINE(0);
             const int ls = kDT * (m & 1);                     // its first tile of the stage, as an index into acc[]
             const bool solver = (h == hs);
             if (SWEEP && solver && (m == 2 || (m == 0 && ((i0 / kRB) & 1)))) {     // take over the running lane partials
@@ -757,18 +678,10 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
             auto stage_dma = [&]() __attribute__((always_inline)) {
                 issue_stage(ahead, bnext);
                 advance(ahead);
-                STAMP8(3);
             };
             const double *abase0 = lds + buf * kABuf + kq * kLdsLd + lc;          // U tile of the stage, all 128 columns
             double *xreg = ldsB + buf * kBBuf + cw * (KB * 16);                   // inverses in, solved tiles out
-            if (dmask & 1) {
-                stage_dma();
-                if (hs == 0) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_s_barrier();
-                }
-            } else if (solver) {
+            if (solver) {
                 double iv[kDT][4], uf[kDT][kTH][4], zr[kDT][4];
                 // the first tile's inverse first: its solve starts as soon as these four values are in; every other LDS
                 // operand of the stage is requested behind the solve's first MFMAs
@@ -795,12 +708,11 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
                             for (int r = 0; r < 4; ++r) zr[hh][r] = zrow[16 * hh + 4 * r];
                     }
                 };
-                FINE(1);
                 auto emit = [&](int hh, int s, const d4 &x) __attribute__((always_inline)) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = i0 + 16 * s + kq + 4 * r;
-                        if (!(dmask & 4)) Vc[(int64_t)row * ldv] = x[r];
+                        Vc[(int64_t)row * ldv] = x[r];
                         if (SWEEP) {
                             qacc = fma(x[r], x[r], qacc);
                             macc = fma(x[r], zr[hh][r], macc);
@@ -819,19 +731,15 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
                 x = MFMA_F64(iv[0][2], -acc[ls][2], x);
                 x2 = MFMA_F64(iv[0][3], -acc[ls][3], x2);
                 __builtin_amdgcn_sched_barrier(0);
-                FINE(2);
                 fetch_rest();                                             // under the four MFMAs in flight
                 __builtin_amdgcn_sched_barrier(0);
-                FINE(3);
                 x += x2;
                 asm volatile("" : "+v"(x));
-                FINE(4);
                 if (hs == 0) {
                     publish(0, x);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();                         // the lower half may read x now
                 }
-                FINE(5);
                 // the update of the next tile is a chain of four dependent MFMAs: the stage's DMA issue and cursor
                 // arithmetic sit in its gaps (and ahead of the stage's V stores, as the stage-top accounting assumes)
 #pragma unroll
@@ -844,7 +752,6 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
                         issue_one(ahead, bnext, 2 * kk + 1);
                     } else {
                         advance(ahead);
-                        STAMP8(3);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -860,21 +767,18 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
                 }
                 d4 y = y1 + y2;
                 asm volatile("" : "+v"(y));
-                FINE(6);
                 if (hs == 0) {
                     publish(1, y);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();                         // ... and y
                 }
-                FINE(7);
                 emit(1, s + 1, y);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
                     for (int t = ls + 2; t < kTH; ++t) acc[t] = MFMA_F64(uf[1][t][kk], y[kk], acc[t]);
                 }
-                FINE(8);
-                if (!(dmask & 4)) a1 += kSolverStores;
+                a1 += kSolverStores;
                 if (SWEEP && (m & 1)) {                                   // done with this half's tiles: hand over
                     if (hs == 0) {
                         hand[0] = qacc;
@@ -921,8 +825,6 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
             } else {
                 stage_dma();                                              // upper half, nothing left to solve in this block
             }
-            STAMP8(2);
-            STAMP_NEXT();
             buf = (buf == 2) ? 0 : buf + 1;
         }
         // the hand-issued loads were retired by diagonal stage 3's top (they are older than that stage's DMA)
@@ -939,8 +841,6 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
         }
     }
 #undef STAGE8_TOP
-#undef STAMP8
-#undef FINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the clamped tail DMA before the LDS goes away
     __builtin_amdgcn_s_barrier();
 
@@ -948,12 +848,6 @@ __global__ __launch_bounds__(512) void trsm_strip8_kernel(const double *__restri
         q_out[colw + lc] = qtot;
         mu_out[colw + lc] = mtot;
     }
-#ifdef CBO_DIAG_KNOBS
-    if (tid == 0 && blockIdx.x < 4096) {
-        g_strip_clock[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk_t0;
-        g_strip_clock[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1731,18 +1625,25 @@ void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const doubl
     // n is a multiple of 128 at every call site (n_pad of the sweep, the 128-row Cholesky panel)
     const dim3 grid((unsigned)(m_pad / kStrip));
     const int acc = accumulate ? 1 : 0;
-    // CBO_HIP_STRIP_FORM=4: the one-wave-per-SIMD kernel also where a workgroup has the CU to itself (A/B timing;
-    // same bits).  Default: two waves per SIMD (trsm_strip8_kernel).
-    static const int strip_form = [] {
+    if (half_lds) {
+        // beside a pipelined sweep: 16-row stages, two half-LDS workgroups per CU, one wave per SIMD each
+        if (q != nullptr)
+            hipLaunchKernelGGL((trsm_strip_kernel<true, 16>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, acc);
+        else
+            hipLaunchKernelGGL((trsm_strip_kernel<false, 16>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, 0);
+        return;
+    }
+    // A workgroup per CU: 256-row pair blocks (trsm_pair_kernel) wherever the row count is a multiple of 256, 128-row blocks
+    // (trsm_strip8_kernel) otherwise; CBO_HIP_STRIP_FORM=8 keeps the latter everywhere (A/B: scripts/strip_form_bits.py,
+    // scripts/lib_ab.py -- same bits)
+    static const bool pairs = [] {
         const char *e = getenv("CBO_HIP_STRIP_FORM");
-        return e ? atoi(e) : 2;
+        return !(e && atoi(e) == 8);
     }();
-    if (strip_form == 16) half_lds = true;            // (A/B timing: the half-LDS kernel, two workgroups per CU)
-    // 256-row pair blocks (trsm_pair_kernel) wherever the row count allows; CBO_HIP_STRIP_FORM=8 keeps trsm_strip8_kernel
-    if (!half_lds && strip_form != 4 && strip_form != 8 && n >= kPB && n % kPB == 0) {
+    if (pairs && n >= kPB && n % kPB == 0) {
 #ifdef CBO_DIAG_KNOBS
         static const int pair_mask = [] {
-            const char *e = getenv("CBO_HIP_STRIP_MASK");
+            const char *e = getenv("CBO_HIP_STRIP_MASK");          // 256: stage stamps on (scripts/pair_timeline.py)
             return e ? atoi(e) : 0;
         }();
         const int acc = (accumulate ? 1 : 0) | (pair_mask << 8);
@@ -1753,31 +1654,10 @@ void launch_trsm_strips(hipStream_t s, const double *U, int64_t ldu, const doubl
             hipLaunchKernelGGL((trsm_pair_kernel<false>), grid, dim3(512), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, 0);
         return;
     }
-    if (!half_lds && strip_form != 4) {
-#ifdef CBO_DIAG_KNOBS
-        static const int strip_mask = [] {
-            const char *e = getenv("CBO_HIP_STRIP_MASK");
-            return e ? atoi(e) : 0;
-        }();
-        const int acc = (accumulate ? 1 : 0) | (strip_mask << 8);
-#endif
-        if (q != nullptr)
-            hipLaunchKernelGGL((trsm_strip8_kernel<true>), grid, dim3(512), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, acc);
-        else
-            hipLaunchKernelGGL((trsm_strip8_kernel<false>), grid, dim3(512), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, 0);
-        return;
-    }
-    if (q != nullptr) {
-        if (half_lds)
-            hipLaunchKernelGGL((trsm_strip_kernel<true, 16>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, acc);
-        else
-            hipLaunchKernelGGL((trsm_strip_kernel<true, 32>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, acc);
-    } else {
-        if (half_lds)
-            hipLaunchKernelGGL((trsm_strip_kernel<false, 16>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, 0);
-        else
-            hipLaunchKernelGGL((trsm_strip_kernel<false, 32>), grid, dim3(256), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, 0);
-    }
+    if (q != nullptr)
+        hipLaunchKernelGGL((trsm_strip8_kernel<true>), grid, dim3(512), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, acc);
+    else
+        hipLaunchKernelGGL((trsm_strip8_kernel<false>), grid, dim3(512), 0, s, U, ldu, invDt, V, ldv, (int)n, z, q, mu, 0);
 }
 
 void launch_trsm_update(hipStream_t s, const double *U, int64_t ldu, double *V, int64_t ldv, int k0, int klen,

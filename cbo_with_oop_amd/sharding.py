@@ -275,8 +275,21 @@ def fit_over_ranks(model, comm=None, expected_level=None):
     while True:
         levels = ladder_plan(world, first, min(expected, LADDER_LAST_LEVEL))
         mine = levels[rank]
-        outcome, jitter = (None, 0.0) if mine > LADDER_LAST_LEVEL else model.fit_level(mine)
+        # A rank whose attempt raises (a HIP error, a level beyond the ladder) must not leave the others in the gather: its
+        # error travels as an outcome of its own (-3), and every rank raises together.
+        failure = None
+        try:
+            outcome, jitter = (None, 0.0) if mine > LADDER_LAST_LEVEL else model.fit_level(mine)
+        except Exception as exc:                     # noqa: BLE001 -- whatever it is, the peers have to hear of it
+            if comm is None:
+                raise
+            outcome, failure = -3, exc
         outcomes = comm.gather(-2 if outcome is None else outcome) if comm is not None else [outcome]
+        if any(o == -3 for o in outcomes):
+            if failure is not None:
+                raise failure
+            raise RuntimeError(f"fit_over_ranks: the fit of rank(s) {[r for r, o in enumerate(outcomes) if o == -3]} failed "
+                               f"(their own exception says why); this rank stops with them")
         outcomes = [None if o == -2 else o for o in outcomes]
         level, owners, needers, first = ladder_resolve(levels, outcomes)
         if level is not None:

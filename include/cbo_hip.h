@@ -26,7 +26,7 @@ extern "C" {
  * cbo_abi_version() returns this value from a product build.  Timing-only builds (CBO_DIAG_KNOBS, or a non-zero
  * F32_DBG mask, whose results may be wrong by construction) return CBO_HIP_ABI_DIAG_BASE + this value, so that a
  * consumer checking the version refuses them as the product. */
-#define CBO_HIP_ABI_VERSION 4
+#define CBO_HIP_ABI_VERSION 5
 #define CBO_HIP_ABI_DIAG_BASE 1000
 #define CBO_MAX_DIM 8
 
@@ -325,6 +325,11 @@ int cbo_comm_barrier(cbo_comm *comm);
 int cbo_comm_gather_i64(cbo_comm *comm, int64_t value, int64_t *out);
 int cbo_comm_share_factor(cbo_comm *comm, cbo_gp *gp, int level, const int *owners, int n_owners,
                           const int *needers, int n_needers);
+/* The needer's side of cbo_comm_share_factor with device copies in the place of ncclRecv: dst (same data and
+ * hyper-parameters as src, same context) takes src's factor at `level` in the n_owners row slices the owners would send
+ * and adopts it (fitted, tries = level).  For tests on a one-GPU box, where the transfer between ranks cannot run; no
+ * reference counterpart (the reference's jitchol, reached from src/GaussianProcessFactory.py:57-73, is one process). */
+int cbo_gp_take_factor_slices(cbo_gp *dst, cbo_gp *src, int level, int n_owners);
 
 /* ---- Monte-Carlo interventional target -----------------------------------------
  * Replaces compute_interventions (src/utils_functions/graph_functions.py:48-77): the mean of the target node

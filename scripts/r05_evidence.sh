@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-4 evidence run on the GPU box (from the repo root), on the final sources: bench lines for every BASELINE config,
+# Round-5 evidence run on the GPU box (from the repo root), on the final sources: bench lines for every BASELINE config,
 # rocprofv3 kernel stats of the same commands, the schedule scan, the tolerance report and the auxiliary timings.  Outputs
-# under gpurun_out/r04/ ; the summaries worth keeping are copied to profiles/ afterwards (scripts/pmc_passes.sh is a
-# separate call: one counter set per rocprofv3 run).  usage: scripts/r04_evidence.sh a|b|c
+# under gpurun_out/r05/ ; the summaries worth keeping are copied to profiles/ afterwards (scripts/pmc_passes.sh is a
+# separate call: one counter set per rocprofv3 run).  usage: scripts/r05_evidence.sh a|b|c
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/r04
+OUT=gpurun_out/r05
 mkdir -p $OUT
 if [ "$1" = "a" ]; then
 timeout -k 10 300 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench default rc=$?"
@@ -34,6 +34,11 @@ timeout -k 10 900 python3 scripts/schedule_scan.py > $OUT/schedule_crossover.txt
 timeout -k 10 600 python3 scripts/tolerance_report.py --large > $OUT/tolerance_report.txt 2> $OUT/tolerance_report.err; echo "tolerance rc=$?"
 timeout -k 10 200 python3 scripts/chol_timing.py 1024 2048 4096 8192 16384 > $OUT/chol_timing.txt 2>&1; echo "chol rc=$?"
 timeout -k 10 200 python3 scripts/strip_scaling.py 16384 1024 2048 4096 8192 > $OUT/strip_scaling.txt 2>&1; echo "strip rc=$?"
+CBO_HIP_STRIP_FORM=8 timeout -k 10 200 python3 scripts/strip_scaling.py 16384 1024 2048 4096 8192 > $OUT/strip_scaling_strip8.txt 2>&1; echo "strip8 rc=$?"
+timeout -k 10 300 python3 scripts/strip_form_bits.py > $OUT/strip_form_bits.txt 2>&1; echo "bits rc=$?"
+CBO_HIP_ALLOW_DIAG=1 CBO_HIP_LIB=$GRAFT_REPO_ROOT/cbo_with_oop_amd/libcbo_hip_diag.so timeout -k 10 200 python3 scripts/pair_timeline.py > $OUT/pair_timeline.txt 2>&1; echo "pair timeline rc=$?"
+timeout -k 10 200 python3 scripts/ei_pass_timing.py 20 22 24 > $OUT/ei_pass_timing.txt 2>&1; echo "ei rc=$?"
+timeout -k 10 400 python3 scripts/lib_ab.py cbo_with_oop_amd/libcbo_hip.so@STRIP_FORM=8 cbo_with_oop_amd/libcbo_hip.so > $OUT/lib_ab.txt 2>&1; echo "ab rc=$?"
 timeout -k 10 200 python3 scripts/probes/trial_step_breakdown.py > $OUT/trial_step_breakdown.txt 2>&1; echo "trial step rc=$?"
 CBO_HIP_ALLOW_DIAG=1 CBO_HIP_LIB=$GRAFT_REPO_ROOT/cbo_with_oop_amd/libcbo_hip_diag.so timeout -k 10 200 python3 scripts/small_stamps.py > $OUT/small_stamps.txt 2>&1; echo "small stamps rc=$?"
 timeout -k 10 300 python3 scripts/complete_graph_cbo_loop.py 20 > $OUT/loop.txt 2>&1; timeout -k 10 300 python3 scripts/complete_graph_cbo_loop.py 20 --optimize >> $OUT/loop.txt 2>&1; echo "loop rc=$?"

@@ -37,17 +37,7 @@ for n in sizes:
     tf = t["trsm_flops"] / launches / ms / 1e9
     blocks = (n + 127) // 128
     rows.append((n, ms, blocks * (blocks - 1) * 2, blocks))
-    clock = ""
-    lib = _lib.load()
-    if hasattr(lib, "cbo_diag_strip_clock") and M // 64 <= 4096:      # diagnostic build: the shader clock under the last launch
-        import ctypes
-        buf = (ctypes.c_ulonglong * (2 * 4096))()
-        lib.cbo_diag_strip_clock.argtypes = [ctypes.c_void_p]
-        if lib.cbo_diag_strip_clock(buf) == 0:
-            c = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 2)[: M // 64].astype(np.float64)
-            if c[:, 1].min() > 0:
-                clock = f"  shader clock {c[:, 0].sum() / c[:, 1].sum() * 100.0:.0f} MHz, MFMA issue {(-(-n // 128) * 128) ** 2 / 2 / c[:, 0].mean():.3f} of a workgroup's cycles (n_pad^2 / 2 per SIMD)"
-    print(f"n={n:6d} M={M}: {ms:8.4f} ms/launch  {tf:6.1f} TFLOP/s  {tf / 78.6:.3f} of peak  ({launches} launches){clock}")
+    print(f"n={n:6d} M={M}: {ms:8.4f} ms/launch  {tf:6.1f} TFLOP/s  {tf / 78.6:.3f} of peak  ({launches} launches)")
     grid.close()
 if len(rows) >= 2:
     A = np.array([[r[2], r[3]] for r in rows], float)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/cbo_hip.h but not exported by libcbo_hip.so"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes prototype in cbo_with_oop_amd/_lib.py"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.cbo_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.cbo_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_no_product_import_of_oracle_or_torch_on_the_path():

@@ -379,7 +379,11 @@ def test_c3_bench_problem_against_the_oracle(hip):
     assert np.max(np.abs(res["mean"][sub] - mu)) < 1e-5 * np.max(np.abs(y))
     big = acq[:, 0] > 1e-6 * acq.max()
     assert big.sum() >= 32                                         # (the top 64 are in: the column is not a comparison of zeros)
-    assert np.max(np.abs(res["acq"][sub][big] - acq[big]) / acq[big]) < 1e-4
+    # the improvement moves one for one with the mean (d EI / d mean = -Phi(u)): it inherits the mean's ABSOLUTE tolerance,
+    # 1e-5 max|y| (/ cost), next to 1e-4 of its own value (measured: 5.6e-7 absolute on a value of 0.028, max 4.3)
+    err = np.abs(res["acq"][sub][big] - acq[big])
+    assert np.all(err <= 1e-4 * acq[big] + 1e-5 * np.max(np.abs(y)) / cost), float(np.max(err / acq[big]))
+    assert np.max(err[acq[big] > 0.1 * acq.max()] / acq[big][acq[big] > 0.1 * acq.max()]) < 1e-5     # the candidates that matter
     assert int(sub[np.argmax(acq[:, 0])]) == res["best_idx"]
     m.close()
 
@@ -983,6 +987,52 @@ def test_bench_lines_of_the_other_configs_carry_the_contract(hip):
     assert c1["config"]["candidates_total"] == 400 and c1["cpu_baseline"]["same_choice"] is True
     assert c3["scaling"] == "strong" and c3["config"]["candidates_total"] == 65536 and c3["config"]["n_obs"] == 8192
     assert 0.5 < c3["roofline"]["isolated"]["frac"] < 1.0
+
+
+def test_a_factor_taken_in_row_slices_is_the_factor(hip):
+    """The hand-over of ``cbo_comm_share_factor`` between ranks cannot run on a one-GPU box (with one rank nobody lacks
+    the factor).  Everything around the transfers is pinned here: model A holds the factor at the level the data need,
+    model B (same data) has failed at the level below; B takes A's factor in the row slices of 1, 3 and 7 owners
+    (``factor_slice``'s uneven split: whole lda-rows and the 16x16 diagonal inverses of the same rows, device copies in
+    the place of ncclRecv) and adopts it -- and B's posterior state, predictions and sweep are A's bit for bit, at a size
+    of several row blocks and on the jitter fixture."""
+    import warnings
+    from cbo_with_oop_amd import CausalExpectedImprovement
+    from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
+    f = load_fixture("jitter_ladder")
+    rng = np.random.default_rng(77)
+    Xb = rng.uniform(-3, 3, (700, 2))
+    Xb[350:] = Xb[:350]                                              # duplicate rows, no noise to speak of: level 0 fails
+    yb = np.sin(Xb.sum(1, keepdims=True))
+    cases = [dict(X=f["X"], y=f["y"], noise_var=float(f["noise_var"]), variance=float(f["variance"]), lengthscale=f["lengthscale_arg"]),
+             dict(X=Xb, y=yb, noise_var=1e-12)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        for kw in cases:
+            a = HipGaussianProcess(**kw)
+            need = a.jitter_tries
+            assert need >= 1
+            Xs = rng.uniform(kw["X"].min(0), kw["X"].max(0), (300, kw["X"].shape[1]))
+            ref_state = [np.array(v) for v in a.posterior_state()]
+            ref_pred = a.predict(Xs)
+            ref_sweep = CausalExpectedImprovement(float(kw["y"].min()), "min", a).sweep(Xs, cost=2.0, want_acq=True)
+            for owners in (1, 3, 7):
+                b = HipGaussianProcess(**kw, fit=False)
+                assert b.fit_level(need - 1)[0] == 0                 # B tried the level below: not positive definite
+                b.take_factor_slices(a, need, owners)
+                assert (b.jitter_tries, b.jitter) == (need, a.jitter)
+                for u, v in zip(b.posterior_state(), ref_state):
+                    assert np.array_equal(np.array(u), v)
+                mu, var = b.predict(Xs)
+                assert np.array_equal(mu, ref_pred[0]) and np.array_equal(var, ref_pred[1])
+                res = CausalExpectedImprovement(float(kw["y"].min()), "min", b).sweep(Xs, cost=2.0, want_acq=True)
+                assert np.array_equal(res["acq"], ref_sweep["acq"]) and res["best_idx"] == ref_sweep["best_idx"]
+                b.close()
+            # a source that does not hold the level is refused
+            c = HipGaussianProcess(**kw, fit=False)
+            with pytest.raises(Exception):
+                c.take_factor_slices(a, need + 1, 2)
+            c.close(); a.close()
 
 
 def test_ladder_levels_one_at_a_time_equal_the_plain_fit(hip):
