@@ -30,6 +30,7 @@ timeout -k 10 100 ./scripts/probes/tile_factor_probe > $OUT/tile_factor_probe.tx
 timeout -k 10 300 python3 scripts/complete_graph_cbo_loop.py 20 > $OUT/loop.txt 2>&1; timeout -k 10 300 python3 scripts/complete_graph_cbo_loop.py 20 --optimize >> $OUT/loop.txt 2>&1; echo "loop rc=$?"
 timeout -k 10 200 python3 scripts/small_config_latency.py > $OUT/small_config_latency.txt 2>&1; echo "small config rc=$?"
 else
+timeout -k 10 600 python3 scripts/strong_model.py c2 c3 > $OUT/strong_model.txt 2>&1; echo "strong model rc=$?"
 timeout -k 10 900 python3 scripts/schedule_scan.py > $OUT/schedule_crossover.txt 2> $OUT/schedule_crossover.err; echo "schedule scan rc=$?"
 timeout -k 10 600 python3 scripts/tolerance_report.py --large > $OUT/tolerance_report.txt 2> $OUT/tolerance_report.err; echo "tolerance rc=$?"
 timeout -k 10 200 python3 scripts/chol_timing.py 1024 2048 4096 8192 16384 > $OUT/chol_timing.txt 2>&1; echo "chol rc=$?"
