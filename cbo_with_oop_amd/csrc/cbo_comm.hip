@@ -370,7 +370,6 @@ extern "C" int cbo_comm_share_factor(cbo_comm *m, cbo_gp *g, int level, const in
         if (needers[i] == m->rank) i_need = true;
     }
     if (my_owner >= 0 && i_need) return set_error(CBO_ERR_INVALID, "a rank cannot both hold and need the factor");
-    if (n_needers == 0) return CBO_OK;                    // (the same lists on every rank: everybody returns here together)
     // What only THIS rank can know -- it is listed as an owner but does not hold the factor, its RCCL lacks the point-to-point
     // calls -- must not make it leave while its peers enter the send / receive group and wait for it for ever: every rank of
     // the communicator exchanges a status word first (one all-gather of one integer), and all refuse together.
@@ -388,7 +387,7 @@ extern "C" int cbo_comm_share_factor(cbo_comm *m, cbo_gp *g, int level, const in
         if (all[(size_t)r] == 2)
             return set_error(CBO_ERR_COMM, "the RCCL of rank " + std::to_string(r) + " has no ncclSend / ncclRecv");
     }
-    if (my_owner < 0 && !i_need) return CBO_OK;
+    if (n_needers == 0 || (my_owner < 0 && !i_need)) return CBO_OK;     // nobody lacks the factor / this rank is not involved
     hipError_t e = hipSetDevice(ctx_device(m->ctx));
     // the model's own stream has produced (owner) or will consume (needer) the factor: order the exchange behind it
     if (e == hipSuccess) e = hipStreamSynchronize(ctx_stream(m->ctx));

@@ -4,7 +4,7 @@ which bench.py reads for roofline.traffic:
                        (bench.py --steps 2 --warmup 1 --post-steps 0; a step ends with argmax_final_kernel; the calls on
                        which cbo_gp_fit_sweep settles its schedule come before and are left out), divided by three
   "step_sequential"  : the same for --sequential
-  "strip_kernel"     : mean per dispatch of trsm_strip8_kernel<true> (round 2: trsm_strip_kernel<true, 32>) from the
+  "strip_kernel"     : mean per dispatch of trsm_pair_kernel<true> (rounds 3-4: trsm_strip8_kernel<true>) from the
                        --sequential passes
   "f32_strip_kernel" : mean per dispatch of trsm_strip_f32_kernel from the --dtype f32 passes
 The file carries the hash of the kernel sources the passes ran on (bench.kernel_sources_sha): bench.py reports the
@@ -39,7 +39,7 @@ for run, counter, key in (("fetch", "FETCH_SIZE", "fetch_size_kb"), ("write", "W
     if v:
         res["step_sequential"][key] = sum(v) / steps
         res["step_sequential"][key + "_dispatches_per_step"] = len(v) / steps
-    s = values(run + "_seq", counter, lambda n: "trsm_strip8_kernel<true>" in n or "trsm_strip_kernel<true, 32>" in n)
+    s = values(run + "_seq", counter, lambda n: "trsm_pair_kernel<true>" in n or "trsm_strip8_kernel<true>" in n)
     if s:
         res["strip_kernel"][key] = sum(s) / len(s)
         res["strip_kernel"][key + "_dispatches"] = len(s)

@@ -1001,35 +1001,36 @@ def test_a_factor_taken_in_row_slices_is_the_factor(hip):
     from cbo_with_oop_amd.GaussianProcessFactory import HipGaussianProcess
     f = load_fixture("jitter_ladder")
     rng = np.random.default_rng(77)
-    Xb = rng.uniform(-3, 3, (700, 2))
-    Xb[350:] = Xb[:350]                                              # duplicate rows, no noise to speak of: level 0 fails
-    yb = np.sin(Xb.sum(1, keepdims=True))
-    cases = [dict(X=f["X"], y=f["y"], noise_var=float(f["noise_var"]), variance=float(f["variance"]), lengthscale=f["lengthscale_arg"]),
-             dict(X=Xb, y=yb, noise_var=1e-12)]
+    Xb = np.linspace(-2.0, 2.0, 700)[:, None]                        # a dense 1-D set of six row blocks ...
+    Xb[350:] = Xb[:350]                                              # ... with duplicate rows and the fixture's negative
+    yb = np.sin(3.0 * Xb)                                            # effective diagonal: level 0 fails, level 1 goes through
+    cases = [(f["X"], f["y"], dict(noise_var=float(f["noise_var"]), variance=float(f["variance"]), lengthscale=f["lengthscale_arg"])),
+             (Xb, yb, dict(noise_var=-1e-8 - 1e-9))]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)
-        for kw in cases:
-            a = HipGaussianProcess(**kw)
+        for X, y, kw in cases:
+            a = HipGaussianProcess(X, y, **kw)
             need = a.jitter_tries
             assert need >= 1
-            Xs = rng.uniform(kw["X"].min(0), kw["X"].max(0), (300, kw["X"].shape[1]))
+            Xs = rng.uniform(X.min(0), X.max(0), (300, X.shape[1]))
             ref_state = [np.array(v) for v in a.posterior_state()]
             ref_pred = a.predict(Xs)
-            ref_sweep = CausalExpectedImprovement(float(kw["y"].min()), "min", a).sweep(Xs, cost=2.0, want_acq=True)
+            ref_sweep = CausalExpectedImprovement(float(y.min()), "min", a).sweep(Xs, cost=2.0, want_acq=True)
             for owners in (1, 3, 7):
-                b = HipGaussianProcess(**kw, fit=False)
+                b = HipGaussianProcess(X, y, **kw, fit=False)
                 assert b.fit_level(need - 1)[0] == 0                 # B tried the level below: not positive definite
                 b.take_factor_slices(a, need, owners)
                 assert (b.jitter_tries, b.jitter) == (need, a.jitter)
                 for u, v in zip(b.posterior_state(), ref_state):
                     assert np.array_equal(np.array(u), v)
                 mu, var = b.predict(Xs)
-                assert np.array_equal(mu, ref_pred[0]) and np.array_equal(var, ref_pred[1])
-                res = CausalExpectedImprovement(float(kw["y"].min()), "min", b).sweep(Xs, cost=2.0, want_acq=True)
-                assert np.array_equal(res["acq"], ref_sweep["acq"]) and res["best_idx"] == ref_sweep["best_idx"]
+                assert np.array_equal(mu, ref_pred[0], equal_nan=True) and np.array_equal(var, ref_pred[1], equal_nan=True)
+                res = CausalExpectedImprovement(float(y.min()), "min", b).sweep(Xs, cost=2.0, want_acq=True)
+                # (the fixture's negative effective noise makes some variances negative: NaN acquisitions, in both alike)
+                assert np.array_equal(res["acq"], ref_sweep["acq"], equal_nan=True) and res["best_idx"] == ref_sweep["best_idx"]
                 b.close()
             # a source that does not hold the level is refused
-            c = HipGaussianProcess(**kw, fit=False)
+            c = HipGaussianProcess(X, y, **kw, fit=False)
             with pytest.raises(Exception):
                 c.take_factor_slices(a, need + 1, 2)
             c.close(); a.close()
