@@ -35,4 +35,5 @@ for reserve in [int(t) for t in os.environ.get("RESERVES", "4,2,3,5,6,8,10,4").s
         best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
     rep = ctx.schedule_report()[1].split(";")
     print(f"reserve {reserve:2d} CUs/XCD: {best:7.3f} ms/step after {k} settling calls; {rep[1].strip()}", flush=True)
+    if os.environ.get("RESERVE_SCAN_FULL"): print("    " + ctx.schedule_report()[1].strip(), flush=True)
     g.close(); m.close(); ctx.close()

@@ -1136,6 +1136,19 @@ def last_schedule(ctx, rows, candidates):
     return int(m.group(1)), int(m.group(2))
 
 
+def test_pair_blocks_and_128_row_blocks_give_the_same_bits(hip):
+    """trsm_pair_kernel (256-row pair blocks: the default wherever the padded row count is a multiple of 256) against
+    trsm_strip8_kernel (128-row blocks, CBO_HIP_STRIP_FORM=8; the form is read once per process, hence one process per form):
+    digests of posterior mean, variance, acquisition, winner and prediction gradients -- the kernel's SWEEP and plain
+    instantiations, forward and reversed factor -- at a two-pair, an ill-conditioned 1-D and a six-pair shape."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "strip_form_bits.py"), "500x4096x3", "1000x2048x1", "1500x4096x2"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.count("same bits") == 3 and "DIFFERENT" not in out.stdout, (out.stdout[-1500:], out.stderr[-800:])
+
+
 def forced_context(monkeypatch, **env):
     """A fresh context whose schedule knobs are pinned (they are read when the context is created)."""
     from cbo_with_oop_amd import _lib
