@@ -478,7 +478,9 @@ def main():
     # (schedule settled first, warm-up, barrier + device synchronisation on both sides, the slowest rank's time): with the
     # posterior replicated, every rank still factors all 4096 rows -- the Amdahl term of this design.
     strong = None
-    if args.config == "c2" and scaling == "weak" and world > 1 and not args.sequential and not args.ladder_over_ranks:
+    # (CBO_BENCH_STRONG_AT_ONE=1 takes this branch with one rank as well, so that a one-GPU box executes it: the test suite)
+    several = world > 1 or os.environ.get("CBO_BENCH_STRONG_AT_ONE") == "1"
+    if args.config == "c2" and scaling == "weak" and several and not args.sequential and not args.ladder_over_ranks:
         Xg, sb, se = strong_shard(cfg, world, rank)
         cands_s = CandidateGrid(Xg[sb:se], model, index_offset=sb, context=ctx)
 

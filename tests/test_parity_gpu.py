@@ -940,12 +940,19 @@ def test_bench_exchange_over_rccl_single_rank(hip):
     assert plain.returncode == 0, plain.stderr[-2000:]
     launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-                               os.path.join(ROOT, "bench.py")] + common, env=env, capture_output=True, text=True,
-                              timeout=300, cwd=ROOT)
+                               os.path.join(ROOT, "bench.py")] + common, env=dict(env, CBO_BENCH_STRONG_AT_ONE="1"),
+                              capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert launched.returncode == 0, launched.stderr[-2000:]
     a = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
     b = json.loads([l for l in launched.stdout.splitlines() if l.startswith("{")][-1])
     assert a["winner"] == b["winner"]
+    # the strong-scaling leg of the several-rank line (c2's one grid cut into shards, timed through the same exchange),
+    # taken here with the one rank this box holds: one shard = the whole grid, so its winner is the line's winner
+    assert "strong" not in a
+    st = b["strong"]
+    assert st["scaling"] == "strong" and st["shard_of_rank_0"] == [0, st["candidates_total"]] == [0, 16384]
+    assert st["winner"]["index"] == b["winner"]["index"] and st["winner"]["acq"] == b["winner"]["acq"]
+    assert st["ms_per_step"] > 0 and abs(st["value"] * st["ms_per_step"] * 1e-3 - 16384) < 1e-6 * 16384
     assert b["n_gpus"] == 1 and "RCCL" in b["config"]["exchange"] and "RCCL" not in a["config"]["exchange"]
     assert b["config"]["rccl_ranks"] == 1 and a["config"]["rccl_ranks"] == 0
     # the self-launch form (what a plain `python bench.py --gpus N` does for N > 1; CBO_BENCH_SELF_LAUNCH=1 takes that
