@@ -8,27 +8,40 @@
 
 namespace cbo {
 
-// One kernel-matrix element, GPy operation order (Stationary._unscaled_dist: GEMM-trick squared distance from the
-// same |x|^2 sums, clip at 0; RBF.K_of_r), restating /root/reference/src/utils_functions/causal_kernels.py:45-62
-// without the rank-1 causal term (added by the caller).
-template <int D>
-__device__ __forceinline__ double kernel_value(const double *xi, const double *xj, double sqi, double sqj,
-                                               double variance, double inv_l2, bool force_zero)
+// c ? a : b through the VOP3 encoding of v_cndmask_b32.  gfx950 issues the VOP2 encoding (mask implicitly in vcc) once per
+// ~22 cycles and SIMD, the VOP3 encoding (mask in any scalar pair, vcc included) once per 4.6 like every other full-rate
+// instruction (scripts/probes/valu_rate_probe.hip, profiles/r05_valu_rate_probe.txt) -- and the compiler shrinks a select
+// to VOP2 wherever its mask lands in vcc.  The EI pass executed ~10 such selects per candidate.
+__device__ __forceinline__ unsigned select_u32(unsigned long long mask, unsigned a, unsigned b)
 {
-#pragma clang fp contract(off)
-    // np.dot(X, X2.T): BLAS accumulates a_k*b_k with FMAs from a zero accumulator.
-    double dot = __dmul_rn(xi[0], xj[0]);
-#pragma unroll
-    for (int k = 1; k < D; ++k) dot = __fma_rn(xi[k], xj[k], dot);
-    double r2 = __dadd_rn(__dmul_rn(-2.0, dot), __dadd_rn(sqi, sqj));
-    if (force_zero) r2 = 0.0;
-    r2 = (r2 < 0.0) ? 0.0 : r2;                       // np.clip(r2, 0, inf) (NaN stays NaN)
-    // GPy goes r = sqrt(r2) / lengthscale, then r*r.  The round trip through the square root costs ~40 fp64
-    // instructions per element and changes r^2 by at most a couple of ulp (far below the 1e-16-level
-    // differences between exp() implementations), so the squared scaled distance is formed directly;
-    // inv_l2 = 1 / lengthscale^2 is exactly 1 for the reference's lengthscale = 1 (and for ARD, whose inputs
-    // are pre-scaled).
-    return __dmul_rn(variance, exp(__dmul_rn(-0.5, __dmul_rn(r2, inv_l2))));
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
+}
+__device__ __forceinline__ double select_f64(bool c, double a, double b)
+{
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(c);
+    return __hiloint2double((int)select_u32(mask, (unsigned)__double2hiint(a), (unsigned)__double2hiint(b)),
+                            (int)select_u32(mask, (unsigned)__double2loint(a), (unsigned)__double2loint(b)));
+}
+// s = sqrt(x) (IEEE, round to nearest) and rs ~ 1 / s from ONE hardware estimate of 1/sqrt(x): the coupled Newton steps of the
+// compiler's own sqrt expansion -- without that expansion's scaling of arguments below 2^-767 (three VOP2 selects and two
+// v_ldexp per call; a predictive variance is clipped at 1e-15) -- whose second variable h converges to 1 / (2 s).  rs is good
+// to an ulp or two: a quotient a / s formed as q = a rs, q += (a - q s) rs is within half an ulp and a bit of the IEEE one
+// (4 instructions where the IEEE division is 14).  x = 0 and x = +inf: s = x, rs is not meaningful (`special` says so).
+// Negative and NaN arguments give NaN in both.
+__device__ __forceinline__ void sqrt_and_reciprocal(double x, double &s, double &rs, bool &special)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, x), h, g);
+    g = fma(fma(-g, g, x), h, g);
+    special = __builtin_amdgcn_class(x, 0x260);                      // +-0, +inf
+    s = select_f64(special, x, g);
+    rs = h + h;
 }
 
 // scipy.special.ndtr is cephes ndtr.c: Phi(a) = 0.5 + 0.5 erf(x) for |x| < sqrt(1/2), x = a / sqrt 2, and 0.5 erfc(|x|)
@@ -65,7 +78,6 @@ __device__ __forceinline__ double recip_plain(double q)
 // No range checks beyond the underflow: 18 instructions where the device library's exp is ~45.
 __device__ __forceinline__ double exp_nonpositive(double x)
 {
-    if (!(x > -745.2)) return isnan(x) ? x : 0.0;
     const double k = rint(x * 1.4426950408889634);
     const double r = fma(-k, 1.90821492927058770002e-10, fma(-k, 6.93147180369123816490e-01, x));
     double p = 1.0 / 479001600.0;
@@ -81,8 +93,34 @@ __device__ __forceinline__ double exp_nonpositive(double x)
     p = horner(p, r, 0.5);
     p = horner(p, r, 1.0);
     p = horner(p, r, 1.0);
-    return ldexp(p, (int)k);
+    return select_f64(x <= -745.2, 0.0, ldexp(p, (int)k));           // underflow; a NaN argument has made p NaN
 }
+// One kernel-matrix element, GPy operation order (Stationary._unscaled_dist: GEMM-trick squared distance from the
+// same |x|^2 sums, clip at 0; RBF.K_of_r), restating /root/reference/src/utils_functions/causal_kernels.py:45-62
+// without the rank-1 causal term (added by the caller).
+template <int D>
+__device__ __forceinline__ double kernel_value(const double *xi, const double *xj, double sqi, double sqj,
+                                               double variance, double inv_l2, bool force_zero)
+{
+#pragma clang fp contract(off)
+    // np.dot(X, X2.T): BLAS accumulates a_k*b_k with FMAs from a zero accumulator.
+    double dot = __dmul_rn(xi[0], xj[0]);
+#pragma unroll
+    for (int k = 1; k < D; ++k) dot = __fma_rn(xi[k], xj[k], dot);
+    double r2 = __dadd_rn(__dmul_rn(-2.0, dot), __dadd_rn(sqi, sqj));
+    if (force_zero) r2 = 0.0;
+    r2 = select_f64(r2 < 0.0, 0.0, r2);               // np.clip(r2, 0, inf) (NaN stays NaN)
+    // GPy goes r = sqrt(r2) / lengthscale, then r*r.  The round trip through the square root costs ~40 fp64
+    // instructions per element and changes r^2 by at most a couple of ulp (far below the 1e-16-level
+    // differences between exp() implementations), so the squared scaled distance is formed directly;
+    // inv_l2 = 1 / lengthscale^2 is exactly 1 for the reference's lengthscale = 1 (and for ARD, whose inputs
+    // are pre-scaled).
+    // (exp_nonpositive, not the device library's exp: 24 vector instructions where that one is ~60 with 20 32-bit moves and
+    // four VOP2 selects -- a kernel-matrix element cost ~300 cycles of a SIMD, two thirds of them the exponential; 4.7e-16
+    // against the library's 2e-16, both far inside what separates two hosts' exp())
+    return __dmul_rn(variance, exp_nonpositive(__dmul_rn(-0.5, __dmul_rn(r2, inv_l2))));
+}
+
 __device__ __forceinline__ double cephes_erf_small(double x)       // |x| <= 1
 {
     const double z = x * x;
@@ -105,10 +143,12 @@ __device__ __forceinline__ double ndtr_with_exp(double a, double e)
     if (isnan(a)) return a;
     const double x = a * SQRTH;
     const double z = fabs(x);
-    if (z < SQRTH) return 0.5 + 0.5 * cephes_erf_small(x);
     double c;
     if (z < 1.0) {
-        c = 1.0 - cephes_erf_small(z);
+        // one evaluation for both of cephes' branches below 1: erf(x) = x T / U is odd to the bit, so erf(|x|) = |erf(x)|
+        const double erf_x = cephes_erf_small(x);
+        if (z < SQRTH) return 0.5 + 0.5 * erf_x;
+        c = 1.0 - fabs(erf_x);
     } else if (z * z > MAXLOG) {
         c = 0.0;                                       // cephes: underflow
     } else if (z < 8.0) {
@@ -146,7 +186,7 @@ __device__ __forceinline__ double ndtr_with_exp(double a, double e)
         c = (e * p) * recip_plain(q);
     }
     const double y = 0.5 * c;
-    return (x > 0) ? 1.0 - y : y;
+    return select_f64(x > 0, 1.0 - y, y);
 }
 
 // (va, ia) beats (vb, ib): larger value, NaN maximal (numpy.argmax), lowest index on ties
@@ -176,7 +216,7 @@ __device__ __forceinline__ void posterior_of(double q, double mu, double pm, dou
 #pragma clang fp contract(off)
     const double kss = causal ? (p.variance + pv) : p.variance;
     var = kss - q;
-    var = (var < kGpyVarClip) ? kGpyVarClip : var;                  // np.clip(var, 1e-15, inf); NaN stays NaN
+    var = select_f64(var < kGpyVarClip, kGpyVarClip, var);          // np.clip(var, 1e-15, inf); NaN stays NaN
     if (p.include_noise) var = var + p.noise_var;                   // Gaussian likelihood predictive_values
     mean = mu;
     if (causal) mean = mean + pm;                                   // GP._raw_predict: mu += mean_function.f(Xnew)
@@ -187,9 +227,14 @@ __device__ __forceinline__ void posterior_of(double q, double mu, double pm, dou
 __device__ __forceinline__ double acquisition_of(double mean, double var, const AcqParams &p)
 {
 #pragma clang fp contract(off)
-    const double s = sqrt(var);
+    double s, rs;
+    bool special;
+    sqrt_and_reciprocal(var, s, rs, special);
     const double mj = mean + p.ei_jitter;
-    const double u = (p.y_best - mj) / s;
+    const double a = p.y_best - mj;
+    double u = a * rs;
+    u = fma(fma(-u, s, a), rs, u);
+    if (__builtin_expect(special, 0)) u = a / s;                    // (a zero or infinite variance: the IEEE quotient)
     const double e = exp_nonpositive(-(u * u) / 2.0);
     const double pdf = e * 0.3989422804014327;                     // scipy _norm_pdf: exp(-x**2/2)/sqrt(2 pi), to an ulp
     const double cdf = ndtr_with_exp(u, e);

@@ -40,6 +40,9 @@ constexpr int64_t kNoIndex = INT64_MAX;
 // before this one's arithmetic: with one candidate per lane and the load at the top of the loop body the pass was bound by
 // memory LATENCY -- 32 KB in flight per CU -- and ran at 0.29 of the HBM roofline whatever the arithmetic cost (round 5: halving
 // the transcendental work changed nothing until the loads were decoupled).
+// CAUSAL: the candidates carry a prior mean / variance; MV: mean and / or variance are written out (the plain sweep asks for
+// neither: 24 registers less, one more wave per SIMD)
+template <bool CAUSAL, bool MV>
 __global__ __launch_bounds__(256) void acq_kernel(const double *__restrict__ q, const double *__restrict__ mu,
                                                   const double *__restrict__ pm, const double *__restrict__ pv,
                                                   int64_t m, AcqParams p, double *__restrict__ mean_out,
@@ -49,11 +52,26 @@ __global__ __launch_bounds__(256) void acq_kernel(const double *__restrict__ q, 
 {
     double bv = -INFINITY;
     int64_t bi = kNoIndex;
-    const bool causal = pv != nullptr;
+    constexpr bool causal = CAUSAL;
+    if (!MV) { mean_out = nullptr; var_out = nullptr; }
     const int64_t stride = 2 * (int64_t)gridDim.x * blockDim.x;
-    int64_t c = 2 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
-    // operands of the pair at c (the second of an odd tail: a copy of the first, never stored)
-    auto fetch = [&](int64_t at, d2 &q2, d2 &mu2, d2 &pm2, d2 &pv2) __attribute__((always_inline)) {
+    // the workgroup's first candidate of an iteration is uniform (scalar registers), the lane's share of the address a constant
+    // 16 tid bytes: every load and store is "scalar base + 32-bit lane offset" and the loop advances scalars only
+    int64_t cu = 2 * (int64_t)blockIdx.x * blockDim.x;
+    const unsigned lane2 = 2 * threadIdx.x;
+    const int64_t span = 2 * (int64_t)blockDim.x;
+    // operands of the pair at cu + lane2 (the second of an odd tail: a copy of the first, never stored)
+    auto fetch = [&](int64_t base, d2 &q2, d2 &mu2, d2 &pm2, d2 &pv2) __attribute__((always_inline)) {
+        if (base + span <= m) {                                  // (uniform) every lane has its two candidates
+            q2 = *reinterpret_cast<const d2 *>(q + base + lane2);
+            mu2 = *reinterpret_cast<const d2 *>(mu + base + lane2);
+            if (causal) {
+                pm2 = *reinterpret_cast<const d2 *>(pm + base + lane2);
+                pv2 = *reinterpret_cast<const d2 *>(pv + base + lane2);
+            }
+            return;
+        }
+        const int64_t at = base + lane2;
         if (at + 1 < m) {
             q2 = *reinterpret_cast<const d2 *>(q + at);
             mu2 = *reinterpret_cast<const d2 *>(mu + at);
@@ -70,12 +88,40 @@ __global__ __launch_bounds__(256) void acq_kernel(const double *__restrict__ q, 
             }
         }
     };
+    auto store = [&](int64_t base, const d2 &mean2, const d2 &var2, const d2 &acq2) __attribute__((always_inline)) {
+        const int64_t c = base + lane2;
+        if (base + span <= m) {                                  // (uniform)
+            if (mean_out) *reinterpret_cast<d2 *>(mean_out + base + lane2) = mean2;
+            if (var_out) *reinterpret_cast<d2 *>(var_out + base + lane2) = var2;
+            if (p.want_ei && acq_out) *reinterpret_cast<d2 *>(acq_out + base + lane2) = acq2;
+        } else if (c + 1 < m) {
+            if (mean_out) *reinterpret_cast<d2 *>(mean_out + c) = mean2;
+            if (var_out) *reinterpret_cast<d2 *>(var_out + c) = var2;
+            if (p.want_ei && acq_out) *reinterpret_cast<d2 *>(acq_out + c) = acq2;
+        } else if (c < m) {
+            if (mean_out) mean_out[c] = mean2[0];
+            if (var_out) var_out[c] = var2[0];
+            if (p.want_ei && acq_out) acq_out[c] = acq2[0];
+        }
+    };
+    // Every memory operation of an iteration is issued in one place, right behind the iteration's only wait: the operands of
+    // the NEXT iteration and the results of the PREVIOUS one.  Loads and stores share one counter on gfx9 and the compiler
+    // waits for zero whenever both kinds are pending -- with the stores at the end of the body and the loads at its top (the
+    // form this loop had until round 5) that wait sat right behind the freshly issued prefetch and took its whole latency,
+    // every iteration, plus the stores': the pass ran at "memory floor + arithmetic" (77 + 48 us at 2^24 candidates) instead
+    // of the larger of the two.  Now whatever the wait covers was issued a whole iteration of arithmetic earlier.
     d2 qn = {0.0, 0.0}, mun = {0.0, 0.0}, pmn = {0.0, 0.0}, pvn = {0.0, 0.0};
-    fetch(c, qn, mun, pmn, pvn);
-    while (c < m) {
-        const d2 q2 = qn, mu2 = mun, pm2 = pmn, pv2 = pvn;
-        fetch(c + stride, qn, mun, pmn, pvn);
-        const bool two = c + 1 < m;
+    d2 mean_done = {0.0, 0.0}, var_done = {0.0, 0.0}, acq_done = {0.0, 0.0};
+    fetch(cu, qn, mun, pmn, pvn);
+    for (int64_t done = -1; cu < m; done = cu, cu += stride) {
+        d2 q2 = qn, mu2 = mun, pm2 = pmn, pv2 = pvn;
+        // (the operands are in their registers before anything below is issued; nothing memory moves across this line)
+        asm volatile("" : "+v"(q2), "+v"(mu2), "+v"(pm2), "+v"(pv2) : : "memory");
+        if (done >= 0) store(done, mean_done, var_done, acq_done);
+        fetch(cu + stride, qn, mun, pmn, pvn);
+        const bool full = cu + span <= m;                        // uniform
+        const int64_t c = cu + lane2;
+        const bool one = full || c < m, two = full || c + 1 < m;
         d2 mean2, var2, acq2 = {0.0, 0.0};
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -83,29 +129,36 @@ __global__ __launch_bounds__(256) void acq_kernel(const double *__restrict__ q, 
             posterior_of(q2[e], mu2[e], causal ? pm2[e] : 0.0, causal ? pv2[e] : 0.0, causal, p, mean, var);
             mean2[e] = mean;
             var2[e] = var;
-            if (p.want_ei) {
-                const double acq = acquisition_of(mean, var, p);
-                acq2[e] = acq;
+        }
+        if (p.want_ei) {
+            // (one candidate after the other: the two in lockstep -- shared coefficients, independent chains -- needed selects
+            // where this takes branches, 190 instead of 160 vector instructions per candidate, and 14 more registers: 113 us
+            // against 107 at 2^24 candidates, profiles/r05_ei_pass_ab.txt)
+            acq2[0] = acquisition_of(mean2[0], var2[0], p);
+            acq2[1] = acquisition_of(mean2[1], var2[1], p);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const double acq = acq2[e];
                 const int64_t gi = c + e + index_offset;
-                if ((e == 0 || two) && better(acq, gi, bv, bi)) { bv = acq; bi = gi; }
+                // (a candidate below the lane's best cannot win: better() is only asked when it is not -- one compare on the
+                // usual path instead of better()'s NaN classification of both sides)
+                if ((e == 0 ? one : two) && !(acq < bv) && better(acq, gi, bv, bi)) { bv = acq; bi = gi; }
             }
         }
-        if (two) {
-            if (mean_out) *reinterpret_cast<d2 *>(mean_out + c) = mean2;
-            if (var_out) *reinterpret_cast<d2 *>(var_out + c) = var2;
-            if (p.want_ei && acq_out) *reinterpret_cast<d2 *>(acq_out + c) = acq2;
-        } else {
-            if (mean_out) mean_out[c] = mean2[0];
-            if (var_out) var_out[c] = var2[0];
-            if (p.want_ei && acq_out) acq_out[c] = acq2[0];
-        }
-        c += stride;
+        mean_done = mean2;
+        var_done = var2;
+        acq_done = acq2;
     }
+    // (cu has run past m by whole strides: the last iteration's results, if there was one)
+    if (cu - stride >= 2 * (int64_t)blockIdx.x * blockDim.x) store(cu - stride, mean_done, var_done, acq_done);
     if (p.want_ei) block_argmax(bv, bi, &part_val[blockIdx.x], &part_idx[blockIdx.x]);
 }
 
 // best_val / best_idx may be pinned host memory (the sweep's epilogue writes the winner where the host reads it: no copy
 // operation behind the kernel); status_src -> status_dst carries a factorisation's status word the same way.
+// (Round 5 folded this reduction into acq_kernel -- the workgroup that draws the last ticket of an agent-scope counter
+// reduces the partials -- and took it out again: 2048 tickets on one address serialise, a pass over 2^20 candidates went
+// from 21 to 35 us and one over 2^24 gained nothing.)
 __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restrict__ part_val,
                                                            const int64_t *__restrict__ part_idx, int n,
                                                            double *__restrict__ best_val, int64_t *__restrict__ best_idx,
@@ -176,7 +229,7 @@ __global__ __launch_bounds__(256) void pred_gradients_kernel(const double *__res
             diff[k] = (k < d) ? (xs[(int64_t)k * ldx + i] - xc[k]) * iso_inv_l : 0.0;   // scaled difference
             r2 += diff[k] * diff[k];
         }
-        const double kv = variance * exp(-0.5 * r2);
+        const double kv = variance * exp_nonpositive(-0.5 * r2);
         const double a = alpha[i] * kv, b = W[(n_pad - 1 - i) * ldw + cl] * kv;
 #pragma unroll
         for (int k = 0; k < CBO_MAX_DIM; ++k) {
@@ -228,8 +281,10 @@ void launch_acq(hipStream_t s, const double *q, const double *mu, const double *
                 const AcqParams &p, double *mean_out, double *var_out, double *acq_out, double *part_val,
                 int64_t *part_idx, int64_t index_offset, int n_blocks)
 {
-    hipLaunchKernelGGL(acq_kernel, dim3(n_blocks), dim3(256), 0, s, q, mu, pm, pv, m, p, mean_out, var_out, acq_out,
-                       part_val, part_idx, index_offset);
+    const bool causal = pv != nullptr, mv = mean_out || var_out;
+    auto kernel = causal ? (mv ? acq_kernel<true, true> : acq_kernel<true, false>) : (mv ? acq_kernel<false, true> : acq_kernel<false, false>);
+    hipLaunchKernelGGL(kernel, dim3(n_blocks), dim3(256), 0, s, q, mu, pm, pv, m, p, mean_out, var_out, acq_out, part_val,
+                       part_idx, index_offset);
 }
 
 void launch_argmax_final(hipStream_t s, const double *part_val, const int64_t *part_idx, int n, double *best_val,

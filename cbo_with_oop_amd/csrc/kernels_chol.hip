@@ -1212,7 +1212,7 @@ __global__ __launch_bounds__(256) void small_lml_kernel(const cbo_small_set st, 
                     d2k[k] = df * df * inv_l2;
                     r2 += d2k[k];
                 }
-                const double kv = st.variance * exp(-0.5 * r2);
+                const double kv = st.variance * exp_nonpositive(-0.5 * r2);
                 const double m = (gi == gj ? 1.0 : 2.0) * (alpha_s[gi] * alpha_s[gj] - w[r]);
                 const double mk = m * kv;
                 sum[0] += mk + m * (sh.sv[gi] * sh.sv[gj]);

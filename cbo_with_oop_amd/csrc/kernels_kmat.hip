@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void lml_grad_tile_kernel(const double *__rest
                 d2k[k] = df * df * inv_l2_iso;
                 r2 += d2k[k];
             }
-            const double kv = variance * exp(-0.5 * r2);
+            const double kv = variance * exp_nonpositive(-0.5 * r2);
             const double m = (gi == gj ? 1.0 : 2.0) * (sa[ii] * sb[tx] + negW[gi * ldw + gj]);
             const double mk = m * kv;
             // the variance gradient contracts dL_dK with the kernel's own K(X, X) (GPy Stationary.update_gradients_full:
