@@ -1707,30 +1707,41 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     // pair p to finish, and bulk(p) follows it on the side stream without a gap -- large factorisations are bound by
     // the bulk updates alone, small ones by the chain alone.
     int pending = -1;                      // event index of the bulk update still in flight
-    // Large trailing matrices, groups of two pairs (CBO_HIP_BULK_GROUP=1: pairs only).  The bulk update is the LDS-staged
-    // GEMM kernel, whose rate grows with K (16384 points, upper part: 45-51 TFLOP/s at K = 256, 53-57 at K = 512:
-    // scripts/update_kernel_timing.py), and it accumulates into C sequentially from C's own value, so one K = 512 pass
-    // gives the bits of two K = 256 passes.  Group j = pairs (2j, 2j+1); G_g = the 512 rows of group g:
-    //   side :  [wait pair 2j+1]  bigA(j): G_{j+2} -= group j;  bigB(j): everything below G_{j+2} -= group j   (K = 512)
-    //   chain:  pair 2j;   rows of pair 2j+1 -= pair 2j (rows kernel, as ever);  [wait bigA(j-1)]  near: G_{j+1} -= pair 2j
-    //           pair 2j+1; rows of pair 2j+2 -= pair 2j+1 (rows kernel);  near: rows of pair 2j+3 -= pair 2j+1
+    // Large trailing matrices, groups of G pairs (CBO_HIP_BULK_GROUP caps G: 1 = pairs only, 2, 4 = default).  The bulk update is
+    // the LDS-staged GEMM kernel, whose rate grows with K (16384 points, all columns: 0.68 / 0.75 / 0.83 of peak at K = 256 /
+    // 512 / 1024: scripts/update_kernel_timing.py), and it accumulates into C sequentially from C's own value, so one K = 256 G
+    // pass gives the bits of G passes of K = 256.  Group j = pairs [G j, G j + G); S = 256 G; G_g = the S rows of group g:
+    //   chain:  pair p of group j: factor; rows of pair p+1 -= pair p (rows kernel, as ever);
+    //           [first pair of the group: wait bigA(j-1)]  near(p): the rows from pair p+2 to the end of G_{j+1} -= pair p (K = 256)
+    //   side :  [wait the group's last pair]  bigA(j): G_{j+2} -= group j;  bigB(j): everything below G_{j+2} -= group j   (K = S)
     // -- every row still receives the pairs in order, each through the kernel that applied it before (rows kernel for
-    // the pair right above, GEMM kernel otherwise): the factor is bit-identical to the pairs-only schedule.  The chain
-    // only ever waits for bigA (512 rows, first on the side stream after the previous bigB), so bigB(j) has the whole
-    // chain of group j+1 to finish and bigB(j+1) follows it without a gap.  The near updates (K = 256, 512 + 256 rows
-    // per group) are the price: they run on the chain stream beside the bulk update.  Groups are used while both
-    // pairs' bulk updates would take the GEMM form anyway; the last ~6000 rows go pair by pair as before.
-    static const int bulk_group = [] { const char *e = std::getenv("CBO_HIP_BULK_GROUP"); return e ? std::atoi(e) : 2; }();
+    // the pair right above, GEMM kernel otherwise): the factor is bit-identical to the pairs-only schedule
+    // (scripts/probes/bulk_group_scan.sh: one digest for G = 1, 2, 4).  The chain only ever waits for bigA (S rows, first on
+    // the side stream after the previous bigB), so bigB(j) has the whole chain of group j+1 to finish and bigB(j+1) follows it
+    // without a gap.  The near updates (K = 256) are the price: they run on the chain stream beside the bulk update.  Groups
+    // are used while every pair's bulk update would take the GEMM form anyway; the last ~6000 rows go pair by pair as before.
+    // Groups of four while at least CBO_HIP_BULK_GROUP4_ROWS (10240) rows lie below the group, of two below that: round 5,
+    // 16384 points 29.61 (G = 2) -> 29.07 ms on one box (thresholds 4096 / 6144 / 8192: 29.63 / 29.82 / 29.28).
+    static const int bulk_group = [] { const char *e = std::getenv("CBO_HIP_BULK_GROUP"); return e ? std::atoi(e) : 4; }();
+    static const int group4_rows = [] { const char *e = std::getenv("CBO_HIP_BULK_GROUP4_ROWS"); return e ? std::atoi(e) : 10240; }();
     constexpr bool group_split = true;     // inside groups the strips of a fused launch go as an LDS-free launch of their own
-    bool second_of_group = false;          // this pair closes a group whose first pair went without a bulk update
+    int group_left = 0;                    // pairs of the open group still to come, this one included
+    int group_pairs = 0, group_g0 = 0, group_first_k = 0;
     int pending_big_a = -1;                // event index of the last bigA
     for (int k = 0; k < np; k += 2) {
         const int r0 = 128 * k;
         const int n2 = (int)n_pad - r0 - 128;
         const int n3_pair = (int)n_pad - r0 - 256;                   // rows below this pair
-        const bool first_of_group = !second_of_group && bulk_group == 2 && (fused || lean_panel) &&
-                                    n3_pair - 512 >= syrk_gemm_rows && n3_pair - 512 >= 512;
-        const bool grouped = first_of_group || second_of_group;
+        if (group_left == 0 && bulk_group >= 2 && (fused || lean_panel)) {
+            // a group opens here if the rows below it still take the GEMM form for every pair of the group
+            int G = 0;
+            if (bulk_group >= 4 && n3_pair - 1024 >= group4_rows && n3_pair - 1024 >= syrk_gemm_rows && n3_pair - 1024 >= 1024) G = 4;
+            else if (n3_pair - 512 >= syrk_gemm_rows && n3_pair - 512 >= 512) G = 2;
+            if (G != 0) { group_pairs = G; group_left = G; group_g0 = r0; group_first_k = k; }
+        }
+        const bool grouped = group_left > 0;
+        const bool first_of_group = grouped && group_left == group_pairs;
+        const bool last_of_group = grouped && group_left == 1;
         // beside a bulk update that fills the device the strips go as an LDS-free launch of their own (launch_panel_fused)
         const bool split_now = split || (grouped && group_split && panel_form == 4);
         if (fused && n2 > 0) launch_panel_fused(s, A, lda, r0, rcol, invDt, info_dev, zvec, n2, flags + 2 * (r0 / 128), spin_limit, nullptr, split_now);
@@ -1749,7 +1760,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         const bool gemm_form = bulk && n3 - 256 >= syrk_gemm_rows;
         // the event the side stream waits for completes WITH the launch it follows (no marker packet on the chain)
         const bool carried = bulk && (fused || lean_panel);
-        const hipEvent_t ev_panel = (carried && gemm_form && !first_of_group) ? events[2 * k] : nullptr;
+        const hipEvent_t ev_panel = (carried && gemm_form && (!grouped || last_of_group)) ? events[2 * k] : nullptr;
         const hipEvent_t ev_rows = (carried && !gemm_form) ? events[2 * k] : nullptr;
         if (fused && n3 > 0)
             launch_panel_fused(s, A, lda, r1, rcol, invDt, info_dev, zvec, n3, flags + 2 * (r1 / 128), spin_limit, ev_panel, split_now);
@@ -1761,32 +1772,29 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
         launch_trsm_strips(s, A + (int64_t)r1 * lda + r1, lda, invDt + (int64_t)(r1 / 16) * 256,
                            A + (int64_t)r1 * lda + r1 + 128, lda, 128, n3, nullptr, nullptr, nullptr, false, half_lds);
         sweep_rows(r0, 256);
-        if (first_of_group) {
-            // pair 2j of a group: the next pair's rows on the chain as ever, then the rest of the next group's rows
+        if (grouped) {
+            const int S = 256 * group_pairs, g0 = group_g0, n = (int)n_pad;
+            const int next_end = (g0 + 2 * S < n) ? g0 + 2 * S : n;                   // end of G_{j+1}
+            if (last_of_group) {
+                // the group's bulk update (K = S) on the side stream, first the rows the chain needs next
+                hipStreamWaitEvent(side, events[2 * k], 0);
+                const int a_end = (g0 + 3 * S < n) ? g0 + 3 * S : n;                  // end of G_{j+2}
+                launch_gemm_update(side, A, lda, A, lda, A, lda, g0, S, next_end, a_end, n_pad + kRhsCols, syrk_gemm_chunk,
+                                   syrk_gemm_half, true, info_dev);
+                hipEventRecord(events[2 * group_first_k + 1], side);                  // (the first pair's slot: it has no bulk update of its own)
+                pending_big_a = 2 * group_first_k + 1;
+                if (a_end < n)
+                    launch_gemm_update(side, A, lda, A, lda, A, lda, g0, S, a_end, n, n_pad + kRhsCols, syrk_gemm_chunk,
+                                       syrk_gemm_half, true, info_dev);
+                hipEventRecord(events[2 * k + 1], side);
+                pending = 2 * k + 1;
+            }
+            // the next pair's rows on the chain as ever, then the rest of the rows up to the end of the next group
             launch_syrk_rows(s, A, lda, r0, 256, n3, rcol, info_dev, 256, nullptr);
-            if (pending_big_a >= 0) hipStreamWaitEvent(s, events[pending_big_a], 0);
-            launch_gemm_update(s, A, lda, A, lda, A, lda, r0, 256, r0 + 512, r0 + 1024, n_pad + kRhsCols, syrk_gemm_chunk,
+            if (first_of_group && pending_big_a >= 0) hipStreamWaitEvent(s, events[pending_big_a], 0);
+            launch_gemm_update(s, A, lda, A, lda, A, lda, r0, 256, r0 + 512, next_end, n_pad + kRhsCols, syrk_gemm_chunk,
                                syrk_gemm_half, true, info_dev);
-            second_of_group = true;
-            continue;
-        }
-        if (second_of_group) {
-            // pair 2j+1: the group's bulk update (K = 512) on the side stream, first the rows the chain needs next
-            hipStreamWaitEvent(side, events[2 * k], 0);
-            const int a_end = (r0 + 1280 < (int)n_pad) ? r0 + 1280 : (int)n_pad;
-            launch_gemm_update(side, A, lda, A, lda, A, lda, r0 - 256, 512, r0 + 768, a_end, n_pad + kRhsCols, syrk_gemm_chunk,
-                               syrk_gemm_half, true, info_dev);
-            hipEventRecord(events[2 * k - 3], side);
-            pending_big_a = 2 * k - 3;
-            if (a_end < (int)n_pad)
-                launch_gemm_update(side, A, lda, A, lda, A, lda, r0 - 256, 512, a_end, (int)n_pad, n_pad + kRhsCols,
-                                   syrk_gemm_chunk, syrk_gemm_half, true, info_dev);
-            hipEventRecord(events[2 * k + 1], side);
-            pending = 2 * k + 1;
-            launch_syrk_rows(s, A, lda, r0, 256, n3, rcol, info_dev, 256, nullptr);
-            launch_gemm_update(s, A, lda, A, lda, A, lda, r0, 256, r0 + 512, r0 + 768, n_pad + kRhsCols, syrk_gemm_chunk,
-                               syrk_gemm_half, true, info_dev);
-            second_of_group = false;
+            --group_left;
             continue;
         }
         // both panels against everything below them: the bulk (below the next pair) on the side stream, the next

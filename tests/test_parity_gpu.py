@@ -750,9 +750,11 @@ print("DIGEST", h.hexdigest())
     for form, env in (("auto", {}), ("4", {"CBO_HIP_PANEL_FORM": "4"}), ("2", {"CBO_HIP_PANEL_FORM": "2"}),
                       ("split", {"CBO_HIP_PANEL_FORM": "5"}), ("timeout", {"CBO_HIP_FUSED_SPIN_LIMIT": "-1"}),
                       ("per-block", {"CBO_HIP_VEC_SOLVE_FORM": "1"}),
-                      # the bulk trailing updates pair by pair (K = 256) instead of in groups of two pairs (K = 512 on the
-                      # side stream, the next group's rows brought up to date on the chain): same bits by construction
-                      ("pairs", {"CBO_HIP_BULK_GROUP": "1"})):
+                      # the bulk trailing updates pair by pair (K = 256), in groups of two pairs only (K = 512), in groups of
+                      # four wherever they fit (K = 1024; the default takes them above 10240 trailing rows) -- on the side
+                      # stream, the next group's rows brought up to date on the chain: same bits by construction
+                      ("pairs", {"CBO_HIP_BULK_GROUP": "1"}), ("groups of two", {"CBO_HIP_BULK_GROUP": "2"}),
+                      ("groups of four", {"CBO_HIP_BULK_GROUP4_ROWS": "0"})):
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env),
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
