@@ -2,7 +2,7 @@
 # Round-5 evidence run on the GPU box (from the repo root), on the final sources: bench lines for every BASELINE config,
 # rocprofv3 kernel stats of the same commands, the schedule scan, the tolerance report and the auxiliary timings.  Outputs
 # under gpurun_out/r05/ ; the summaries worth keeping are copied to profiles/ afterwards (scripts/pmc_passes.sh is a
-# separate call: one counter set per rocprofv3 run).  usage: scripts/r05_evidence.sh a|b|c
+# separate call: one counter set per rocprofv3 run).  usage: scripts/r05_evidence.sh a|b|c|d (one gpurun call each: a = bench lines and kernel stats, b = strong-scaling model and schedule scan, d = everything else, c = the subset of d a change of the factorisation touches)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r05
 mkdir -p $OUT
@@ -29,9 +29,10 @@ CBO_HIP_ALLOW_DIAG=1 CBO_HIP_LIB=$GRAFT_REPO_ROOT/cbo_with_oop_amd/libcbo_hip_di
 timeout -k 10 100 ./scripts/probes/tile_factor_probe > $OUT/tile_factor_probe.txt 2>&1; echo "probe rc=$?"
 timeout -k 10 300 python3 scripts/complete_graph_cbo_loop.py 20 > $OUT/loop.txt 2>&1; timeout -k 10 300 python3 scripts/complete_graph_cbo_loop.py 20 --optimize >> $OUT/loop.txt 2>&1; echo "loop rc=$?"
 timeout -k 10 200 python3 scripts/small_config_latency.py > $OUT/small_config_latency.txt 2>&1; echo "small config rc=$?"
-else
+elif [ "$1" = "b" ]; then
 timeout -k 10 600 python3 scripts/strong_model.py c2 c3 > $OUT/strong_model.txt 2>&1; echo "strong model rc=$?"
 timeout -k 10 900 python3 scripts/schedule_scan.py > $OUT/schedule_crossover.txt 2> $OUT/schedule_crossover.err; echo "schedule scan rc=$?"
+else
 timeout -k 10 600 python3 scripts/tolerance_report.py --large > $OUT/tolerance_report.txt 2> $OUT/tolerance_report.err; echo "tolerance rc=$?"
 timeout -k 10 200 python3 scripts/chol_timing.py 1024 2048 4096 8192 16384 > $OUT/chol_timing.txt 2>&1; echo "chol rc=$?"
 timeout -k 10 200 python3 scripts/strip_scaling.py 16384 1024 2048 4096 8192 > $OUT/strip_scaling.txt 2>&1; echo "strip rc=$?"
