@@ -662,11 +662,11 @@ static void enqueue_factor(cbo_gp *g, double jitter)
     {
         PhaseScope ps(c, PH_KXX);
         launch_kxx(c->stream, g->X, g->h, g->noise_var + kGpyDiagJitter, jitter, g->A, g->lda, g->n_pad);
-        launch_rhs(c->stream, g->y, g->X.pm, g->n, g->A, g->lda, g->n_pad);
+        launch_rhs(c->stream, g->y, g->X.pm, g->n, g->A, g->lda, g->n_pad, g->info, cholesky_info_ints(g->n_pad));
     }
     {
         PhaseScope ps(c, PH_CHOL);
-        launch_cholesky(c->stream, c->side_stream, c->chol_events, g->A, g->lda, g->n_pad, g->invDt, g->info);
+        launch_cholesky(c->stream, c->side_stream, c->chol_events, g->A, g->lda, g->n_pad, g->invDt, g->info, nullptr, true);
     }
 }
 
@@ -1600,20 +1600,22 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
         // fork: the sweep stream starts after what is queued on the main stream (candidate preparation)
         HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
         HIP_TRY(hipStreamWaitEvent(c->sweep_stream, c->ev_fork, 0));
+        // K(X,X) first: it heads the factorisation's chain, K(X,X*) is not needed before the first pair is solved.  (Until
+        // round 5 the host queued K(X,X*) and two hipMemsetAsync ahead of it -- a kernel trace showed K(X,X) starting 69 us
+        // after K(X,X*), most of it the host's time in those calls; q and mu are now cleared by one small launch.)
+        {
+            PhaseScope ps(c, PH_KXX);
+            launch_kxx(c->stream, g->X, g->h, g->noise_var + kGpyDiagJitter, jitter, g->A, g->lda, g->n_pad);
+            launch_rhs(c->stream, g->y, g->X.pm, g->n, g->A, g->lda, g->n_pad, g->info, cholesky_info_ints(g->n_pad));
+        }
         {
             PhaseScope ps(c, PH_KSTAR, c->sweep_stream);
             launch_kstar(c->sweep_stream, g->X, k->P, 0, k->m_pad, g->h, Vws, ldv, g->n_pad);
         }
-        HIP_TRY(hipMemsetAsync(qbuf, 0, sizeof(double) * k->m_pad, c->sweep_stream));
-        HIP_TRY(hipMemsetAsync(mubuf, 0, sizeof(double) * k->m_pad, c->sweep_stream));
-        {
-            PhaseScope ps(c, PH_KXX);
-            launch_kxx(c->stream, g->X, g->h, g->noise_var + kGpyDiagJitter, jitter, g->A, g->lda, g->n_pad);
-            launch_rhs(c->stream, g->y, g->X.pm, g->n, g->A, g->lda, g->n_pad);
-        }
+        launch_zero_pair(c->sweep_stream, qbuf, mubuf, k->m_pad);
         {
             PhaseScope ps(c, PH_CHOL);
-            launch_cholesky(c->stream, c->side_stream, c->chol_events, g->A, g->lda, g->n_pad, g->invDt, g->info, &pipe);
+            launch_cholesky(c->stream, c->side_stream, c->chol_events, g->A, g->lda, g->n_pad, g->invDt, g->info, &pipe, true);
         }
         // join: everything the sweep streams were given is done before the main stream goes on (the last
         // pair has no rows below it, so the bulk stream's last launch precedes the sweep stream's in-panel solve

@@ -93,7 +93,10 @@ void launch_prep_points_staged(hipStream_t s, const double *stage, int64_t n, in
 // K(X,X) + diag into the upper 64x64 tiles of A (identity on the padding), and the rhs strip.
 void launch_kxx(hipStream_t s, const PointSet &X, const KernelHyper &h, double diag_add, double jitter,
                 double *A, int64_t lda, int64_t n_pad);
-void launch_rhs(hipStream_t s, const double *y, const double *pm, int64_t n, double *A, int64_t lda, int64_t n_pad);
+void launch_zero_pair(hipStream_t s, double *a, double *b, int64_t n);       // a[0:n] = b[0:n] = 0
+// (zero, zero_count: ints the launch clears on the way -- the factorisation's status word and counters, cholesky_info_ints())
+void launch_rhs(hipStream_t s, const double *y, const double *pm, int64_t n, double *A, int64_t lda, int64_t n_pad,
+                int *zero = nullptr, int zero_count = 0);
 // K(X, X*) for candidate columns [c_begin, c_begin + m_pad) into V (rows >= n are zero).
 void launch_kstar(hipStream_t s, const PointSet &X, const PointSet &C, int64_t c_begin, int64_t m_pad,
                   const KernelHyper &h, double *V, int64_t ldv, int64_t n_pad);
@@ -140,8 +143,14 @@ struct SweepPipe {
 // info_dev: 1 + kCholFlagSlots ints (status word, then one publication counter per 128-row panel)
 constexpr int kCholFlagSlots = 1024;
 constexpr int kCholFusedTimeout = -2147483647 - 1;     // status word when a strip of a fused launch gave up waiting
+// info_zeroed: the caller's launch_rhs has cleared the first cholesky_info_ints(n_pad) ints of info_dev on the same stream
 void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &events, double *A, int64_t lda,
-                     int64_t n_pad, double *invDt, int *info_dev, const SweepPipe *pipe = nullptr);
+                     int64_t n_pad, double *invDt, int *info_dev, const SweepPipe *pipe = nullptr, bool info_zeroed = false);
+inline int cholesky_info_ints(int64_t n_pad)
+{
+    const int np = (int)(n_pad / 128);
+    return 2 * np <= kCholFlagSlots ? 1 + 2 * np : 1;
+}
 // > 0: launch_cholesky of this thread uses that panel form (CBO_HIP_PANEL_FORM's values) whatever the environment says
 void set_panel_form_override(int form);
 // pair p of the pipelined sweep: rows [r0, r0 + klen) of the factor are final on stream `chain`

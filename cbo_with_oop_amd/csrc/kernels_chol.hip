@@ -1648,7 +1648,7 @@ __global__ void zero_ints_kernel(int *p, int n)
 // side stream while the main stream factors and solves pair p; the two meet before pair p's own update of pair
 // p+1's rows (schedule inside).
 void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &events, double *A, int64_t lda,
-                     int64_t n_pad, double *invDt, int *info_dev, const SweepPipe *pipe)
+                     int64_t n_pad, double *invDt, int *info_dev, const SweepPipe *pipe, bool info_zeroed)
 {
     // > 64 KiB of dynamic LDS needs the opt-in on the current device (cheap; done per call so that several
     // devices in one process are all covered)
@@ -1677,7 +1677,7 @@ void launch_cholesky(hipStream_t s, hipStream_t side, std::vector<hipEvent_t> &e
     const bool fused = (panel_form == 4 || panel_form == 5) && 2 * np <= kCholFlagSlots;
     const bool split = panel_form == 5;
     // (a launch, not hipMemsetAsync: the runtime's fill costs two kernels and ~8 us of marker gaps around each)
-    hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(256), 0, s, info_dev, fused ? 1 + 2 * np : 1);
+    if (!info_zeroed) hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(256), 0, s, info_dev, fused ? 1 + 2 * np : 1);
     int *flags = info_dev + 1;
     const int rcol = (int)n_pad;
     while ((int)events.size() < 2 * np + 2) {

@@ -341,9 +341,14 @@ void launch_kstar_f32(hipStream_t s, const PointSet &X, const PointSet &C, int64
 // ------------------------------------------------------------------------------------------------
 // Right-hand-side strip: column n_pad of A carries r = y - m(X) (GPy: Y - mean_function.f(X)); the
 // other 63 columns of the strip and the padded rows are zero.
+// The launch also zeroes the factorisation's status word and publication counters (`zero`, `zero_count` ints): a launch of
+// their own cost the chain ~10 us of kernel and boundary in front of its first panel.
 __global__ __launch_bounds__(256) void rhs_kernel(const double *__restrict__ y, const double *__restrict__ pm,
-                                                  int64_t n, double *__restrict__ A, int64_t lda, int64_t n_pad)
+                                                  int64_t n, double *__restrict__ A, int64_t lda, int64_t n_pad,
+                                                  int *__restrict__ zero, int zero_count)
 {
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < zero_count; i += blockDim.x) zero[i] = 0;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_pad * kRhsCols) return;
     const int64_t i = idx / kRhsCols;
@@ -353,10 +358,25 @@ __global__ __launch_bounds__(256) void rhs_kernel(const double *__restrict__ y, 
     A[i * lda + n_pad + c] = v;
 }
 
-void launch_rhs(hipStream_t s, const double *y, const double *pm, int64_t n, double *A, int64_t lda, int64_t n_pad)
+void launch_rhs(hipStream_t s, const double *y, const double *pm, int64_t n, double *A, int64_t lda, int64_t n_pad,
+                int *zero, int zero_count)
 {
     const int64_t total = n_pad * kRhsCols;
-    hipLaunchKernelGGL(rhs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, y, pm, n, A, lda, n_pad);
+    hipLaunchKernelGGL(rhs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, y, pm, n, A, lda, n_pad, zero,
+                       zero ? zero_count : 0);
+}
+
+// q = mu = 0 ahead of a sweep that accumulates into them (one launch; the runtime's hipMemsetAsync is a fill kernel plus
+// several microseconds of host time per call)
+__global__ __launch_bounds__(256) void zero_pair_kernel(double *__restrict__ a, double *__restrict__ b, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { a[i] = 0.0; b[i] = 0.0; }
+}
+
+void launch_zero_pair(hipStream_t s, double *a, double *b, int64_t n)
+{
+    if (n > 0) hipLaunchKernelGGL(zero_pair_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, n);
 }
 
 // ------------------------------------------------------------------------------------------------
