@@ -330,6 +330,42 @@ def test_argmax_ties_and_nan_like_numpy(hip):
     assert np.isnan(res["acq"][bad, 0]) and res["best_idx"] == bad and np.isnan(res["best_val"])
 
 
+def test_expected_improvement_over_the_whole_range_of_u(hip):
+    """The EI arithmetic of the epilogue alone (cbo_device.h: square root and quotient from one reciprocal-root estimate, lean
+    exponential, cephes ndtr in its three ranges, VOP3 selects) against scipy on the DEVICE's own mean and variance: the
+    incumbent is moved so that u = (y_best - mean) / s sweeps -39 .. +39 over the candidates -- below sqrt(1/2) (erf), up to 1
+    (1 - erf), the middle and the far rational functions of erfc, the underflow beyond 37.5 -- for both tasks.  u Phi(u) +
+    phi(u) cancels in the lower tail (both terms ~ phi, the sum ~ phi / u^2), so the bound is on the TERMS: a few ulp times
+    (1 + u^2) of s (|u| Phi + phi), for the device as for scipy."""
+    from cbo_with_oop_amd import CausalExpectedImprovement
+    f = load_fixture("toy_bo_d2")
+    m = make_model(hip, f)
+    Xs = f["Xs"]
+    base = CausalExpectedImprovement(float(f["y_best"]), "min", m).sweep(Xs, cost=1.0, want_acq=True, want_posterior=True)
+    mean, var = base["mean"][:, 0], base["var"][:, 0]
+    s = np.sqrt(var)
+    eps = np.finfo(float).eps
+    seen = set()
+    for task in ("min", "max"):
+        for shift in (-39.0, -20.0, -12.0, -8.0, -3.0, -1.2, -0.5, 0.0, 0.5, 1.2, 3.0, 8.0, 12.0, 20.0, 39.0):
+            y_best = float(np.median(mean) + shift * np.median(s))
+            res = CausalExpectedImprovement(y_best, task, m).sweep(Xs, cost=1.0, want_acq=True)
+            acq = res["acq"][:, 0]
+            ref = O.expected_improvement(mean, var, y_best, task)
+            u = (y_best - mean) / s
+            import scipy.stats
+            terms = s * (np.abs(u) * scipy.stats.norm.cdf(u) + scipy.stats.norm.pdf(u))
+            bound = 48 * eps * (1.0 + u * u) * terms + 1e-300
+            assert np.all(np.abs(acq - ref) <= bound), (task, shift, float(np.max(np.abs(acq - ref) / bound)))
+            # the winner: the device's arg-max of its own values, and among the oracle's best within the bound
+            assert res["best_idx"] == int(np.argmax(acq)) and ref[res["best_idx"]] >= ref.max() - 2 * bound[res["best_idx"]]
+            z = np.abs(u) * np.sqrt(0.5)
+            seen |= {k for k, hit in (("centre", (z < np.sqrt(0.5)).any()), ("below 1", ((z >= np.sqrt(0.5)) & (z < 1)).any()),
+                                      ("middle", ((z >= 1) & (z < 8)).any()), ("far", ((z >= 8) & (z * z <= 709.78)).any()),
+                                      ("underflow", (z * z > 709.78).any())) if hit}
+    assert seen == {"centre", "below 1", "middle", "far", "underflow"}, seen
+
+
 def test_c3_size_against_oracle_subsample(hip):
     """BASELINE config 3 shape per GPU: N=8192 observations, a 32768-candidate shard (64x32x16 of the 64x32x32
     grid), complete-graph box.  The oracle checks a 512-candidate subsample (full sweep = minutes of CPU)."""
