@@ -1960,7 +1960,7 @@ extern "C" int cbo_trial_step(int n_sets, cbo_gp *const *gps, cbo_cands *const *
 extern "C" int cbo_schedule_report(cbo_ctx *c, char *buf, int64_t cap)
 {
     if (!c) return fail(CBO_ERR_INVALID, "ctx is NULL");      // (CBO_ERR_* codes are negative as they are)
-    static const char *names[] = {"cold", "sequence", "base", "neighbours", "climb", "grouping", "settled"};
+    static const char *names[] = {"cold", "sequence", "base", "neighbours", "climb", "grouping", "settled", "renewing the first split"};
     std::string out;
     int exploring = 0;
     char line[512];

@@ -3,6 +3,7 @@
 // usage: schedule_tuner_sim n_pad m_pad n_cu n_cu_pipe curve noise seed      (tests/test_host_logic.py)
 // prints: "<calls> <pairs> <group> <settled 0/1> <ms of the choice> <ms of the best candidate>"
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <random>
 #include <string>
@@ -95,6 +96,9 @@ int main(int argc, char **argv)
         double ms = step_ms(curve, e, ch.group, ch.pairs) * (1.0 + noise * u(rng));
         if (ch.pairs != last_p || ch.group != last_g) ms *= 1.05;        // the call after a change pays for it
         if (calls == 0) ms *= 3.0;                                       // cold
+        // TUNER_SIM_WARM=w: a device whose clocks are still rising on the context's first calls -- call k is slower by
+        // w exp(-k / 4) (a trace of a fresh context: 12 % on calls 2-3, 3 % ten calls later)
+        if (const char *w = std::getenv("TUNER_SIM_WARM")) ms *= 1.0 + std::atof(w) * std::exp(-calls / 4.0);
         last_p = ch.pairs; last_g = ch.group;
         schedule_report(n_cu, n_cu_pipe, e, ch, 0, ms, ch.pairs < 0 ? 1700.0 : 0.0, ch.pairs < 0 ? 5100.0 : 0.0);
         ++calls;
