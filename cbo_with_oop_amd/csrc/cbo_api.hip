@@ -1588,9 +1588,13 @@ extern "C" int cbo_gp_fit_sweep(cbo_gp *g, cbo_cands *k, double y_best, int task
     const bool speculate = qbuf == k->q;
     SweepPipe pipe = make_pipe(g, Vws, ldv, k->m_pad, qbuf, mubuf);
     pipe.group = choice.group;
+    // pairs that do not fill a group go alone ahead of the first one (CBO_HIP_PIPE_LEAD forces the count where the schedule is
+    // forced; there the default stays 0: whole groups from the first pair, what the forced schedules of rounds 3-5 meant)
+    static const int pipe_lead_env = [] { const char *e = std::getenv("CBO_HIP_PIPE_LEAD"); return e ? std::atoi(e) : -1; }();
     int pairs = choice.pairs;
-    if (pipe.group >= 2 && c->pipe_tail_frac < 0.0 && pairs >= pipe.group && pairs * 256 < (int)g->n_pad)
-        pairs -= pairs % pipe.group;                                                    // whole groups
+    pipe.lead = 0;
+    if (pipe.group >= 2 && pairs >= 1 && pairs * 256 < (int)g->n_pad)
+        pipe.lead = forced ? (pipe_lead_env > 0 ? pipe_lead_env : 0) : (pipe_lead_env >= 0 ? pipe_lead_env : pairs % pipe.group);
     pipe.tail_begin = pairs * 256;
     if (pipe.tail_begin > (int)g->n_pad) pipe.tail_begin = (int)g->n_pad;
     double jitter = 0.0;

@@ -134,6 +134,8 @@ struct SweepPipe {
     bool lower_tri;                      // the right-hand sides are lower triangular (identity: V = L^-1), so rows
                                          // [r0, r0+klen) only reach columns < r0+klen: launch just those strips
     int group;                           // G >= 2: updates in groups of G pairs (K = 256 G on `bulk`), see sweep_pipe_pair
+    int lead = 0;                        // pairs that go alone AHEAD of the first group (their bulk update, K = 256, can start
+                                         // as soon as they are solved: the bulk stream does not idle until a whole group is)
     int tail_begin;                      // rows from here on (a multiple of 256; n_pad = none) are left to ONE
                                          // left-looking strip launch once the factorisation is complete
     std::vector<hipEvent_t> *events;     // factorisation -> sweep dependencies, grown on demand

@@ -1587,21 +1587,26 @@ void sweep_pipe_pair(const SweepPipe &pipe, hipStream_t chain, const double *A, 
     // before.  The caller decides (pipe.group = G): groups pay where the bulk stream is the pipeline's bottleneck (a
     // round of strips or more per CU); with few strips the pairs schedule starts its updates earlier and wins
     // (profiles/r03_schedule_crossover.txt).
-    const int G = pipe.group;
+    const int G = pipe.group, lead = pipe.lead;
     const int full_pairs = ((pipe.tail_begin < (int)n_pad) ? pipe.tail_begin : (int)n_pad) / 256;
-    const bool grouped = G >= 2 && !pipe.lower_tri && klen == 256 && (p / G + 1) * G <= full_pairs;
+    // pipe.lead pairs go alone ahead of the first group (round 5: with groups from the first pair on, the bulk stream idled
+    // until the SECOND pair was solved -- a fifth of the pipelined phase at C2)
+    const bool grouped = G >= 2 && !pipe.lower_tri && klen == 256 && p >= lead && ((p - lead) / G + 1) * G + lead <= full_pairs;
     if (grouped) {
-        const int j = p / G, i = p % G;
-        const int next_end = (256 * G * (j + 2) < (int)n_pad) ? 256 * G * (j + 2) : (int)n_pad;     // end of G_{j+1}
+        const int j = (p - lead) / G, i = (p - lead) % G;
+        const int g0 = 256 * (lead + G * j);                                                       // the group's first row
+        const int next_end = (g0 + 512 * G < (int)n_pad) ? g0 + 512 * G : (int)n_pad;              // end of G_{j+1}
+        // the first group behind lead pairs: its rows were last written by the bulk update of the pair before it
+        if (i == 0 && j == 0 && lead > 0) hipStreamWaitEvent(pipe.stream, pipe_event(2, lead - 1), 0);
         update(pipe.stream, r0, 256, below, first_end);
-        if (i == 0 && j >= 1) hipStreamWaitEvent(pipe.stream, pipe_event(2, G * (j - 1)), 0);      // restA of the group before
+        if (i == 0 && j >= 1) hipStreamWaitEvent(pipe.stream, pipe_event(2, lead + G * (j - 1)), 0);   // restA of the group before
         update(pipe.stream, r0, 256, r0 + 512, next_end);
         if (i < G - 1) return;
         hipStreamWaitEvent(pipe.bulk, pipe_event(1, p), 0);
-        const int a1 = (256 * G * (j + 3) < (int)n_pad) ? 256 * G * (j + 3) : (int)n_pad;           // end of G_{j+2}
-        update(pipe.bulk, 256 * G * j, 256 * G, next_end, a1);
-        hipEventRecord(pipe_event(2, G * j), pipe.bulk);                             // restA (the first pair's slot)
-        update(pipe.bulk, 256 * G * j, 256 * G, a1, (int)n_pad);
+        const int a1 = (g0 + 768 * G < (int)n_pad) ? g0 + 768 * G : (int)n_pad;                    // end of G_{j+2}
+        update(pipe.bulk, g0, 256 * G, next_end, a1);
+        hipEventRecord(pipe_event(2, lead + G * j), pipe.bulk);                      // restA (the first pair's slot)
+        update(pipe.bulk, g0, 256 * G, a1, (int)n_pad);
         hipEventRecord(pipe_event(2, p), pipe.bulk);                                 // restB: what a successor waits for
         return;
     }

@@ -89,13 +89,13 @@ static inline bool schedule_tune_enabled()
     static const bool on = [] { const char *e = std::getenv("CBO_HIP_SCHEDULE_TUNE"); return !(e && std::atoi(e) == 0); }();
     return on;
 }
-static inline int schedule_unit(int group) { return group >= 2 ? group : 1; }
-// The candidates along the axis, in order: kSequence, 0 (overlapped, empty pipeline), the single pairs below the first
-// group, the multiples of the unit below all_pairs, all_pairs.
+// The candidates along the axis, in order: kSequence, 0 (overlapped, empty pipeline), every number of pairs up to all_pairs.
+// (Until round 5 a grouped schedule only took whole groups; pairs % group pairs now go alone AHEAD of the first group --
+// SweepPipe::lead -- so that the bulk stream has work as soon as the first pair is solved: every count is a candidate.)
 static inline bool schedule_is_candidate(const ScheduleEntry &e, int group, int p)
 {
-    const int u = schedule_unit(group);
-    return p == kSequence || (p >= 0 && p <= e.all_pairs && (p < u || p % u == 0 || p == e.all_pairs));
+    (void)group;
+    return p == kSequence || (p >= 0 && p <= e.all_pairs);
 }
 // the nearest candidate at or beyond p in direction dir
 static inline int schedule_snap(const ScheduleEntry &e, int group, int p, int dir)

@@ -1250,7 +1250,8 @@ def test_three_schedules_give_the_same_bits(hip, monkeypatch, n, m, d):
 def test_grouped_pipeline_gives_the_same_bits_at_the_headline_shape(hip):
     """BASELINE config 2's shape (4096 observations, 16384 candidates) through cbo_gp_fit_sweep with the pipelined sweep's
     updates pair by pair (CBO_HIP_PIPE_GROUP=1), in groups of two pairs (the automatic choice there: K = 512 on the bulk
-    stream), of three and of four pairs, with an odd split (a remainder pair behind the groups), and as the two plain calls
+    stream), of three and of four pairs, with an odd split (a remainder pair behind the groups), with pairs going alone ahead of
+    the first group (CBO_HIP_PIPE_LEAD), and as the two plain calls
     (no overlap, left-looking): the update kernel accumulates into V sequentially, so every grouping gives the same bits."""
     import subprocess
     import sys
@@ -1279,6 +1280,11 @@ print("DIGEST", h.hexdigest())
     for name, env in (("first call", {}), ("quarter", {"CBO_HIP_OVERLAP": "1"}), ("pairs", {"CBO_HIP_PIPE_GROUP": "1"}),
                       ("three", {"CBO_HIP_PIPE_GROUP": "3"}), ("four", {"CBO_HIP_PIPE_GROUP": "4"}),
                       ("odd split", {"CBO_HIP_PIPE_TAIL": "0.6875"}), ("all pipelined", {"CBO_HIP_PIPE_TAIL": "0"}),
+                      # pairs that go alone AHEAD of the first group (what the measured schedule runs for a pair count that
+                      # does not fill its groups): {0},{1,2}; {0},{1,2},{3,4}; {0},{1},{2,3,4}
+                      ("one ahead, three pairs", {"CBO_HIP_PIPE_TAIL": "0.8125", "CBO_HIP_PIPE_LEAD": "1"}),
+                      ("one ahead, five pairs", {"CBO_HIP_PIPE_TAIL": "0.6875", "CBO_HIP_PIPE_LEAD": "1"}),
+                      ("two ahead, a group of three", {"CBO_HIP_PIPE_TAIL": "0.6875", "CBO_HIP_PIPE_GROUP": "3", "CBO_HIP_PIPE_LEAD": "2"}),
                       ("two calls", {"CBO_HIP_OVERLAP": "0"})):
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env),
                              capture_output=True, text=True, timeout=300)
