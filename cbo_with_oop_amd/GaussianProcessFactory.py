@@ -24,6 +24,33 @@ class GaussianProcessType(IntEnum):
     NON_CAUSAL_GP = 2
 
 
+# paramz ``transformations.Logexp`` (paramz~=0.9.5, requirements.txt:9), the constraint GPy puts on every positive parameter
+# of these models (``RBF.variance`` / ``.lengthscale``, ``Gaussian.variance``): the optimiser works on x, the model sees
+# theta = log(1 + exp(x)).  Restated here because GPy's ``model.optimize()`` (src/CBO.py:173, src/utils_functions/utils.py:44)
+# runs scipy's L-BFGS-B in THAT space, from x0 = finv(theta0): same routine + same space + same start = its trajectory.
+_LOGEXP_LIM = 36.0
+_LOGEXP_LOG_LIM = float(np.log(np.finfo(np.float64).max))
+
+
+def logexp_f(x):
+    """Logexp.f: theta(x)."""
+    x = np.asarray(x, dtype=np.float64)
+    return np.where(x > _LOGEXP_LIM, x, np.log1p(np.exp(np.clip(x, -_LOGEXP_LOG_LIM, _LOGEXP_LIM))))
+
+
+def logexp_finv(theta):
+    """Logexp.finv: x(theta)."""
+    theta = np.asarray(theta, dtype=np.float64)
+    with np.errstate(over="ignore"):
+        return np.where(theta > _LOGEXP_LIM, theta, np.log(np.expm1(theta)))
+
+
+def logexp_gradfactor(theta):
+    """Logexp.gradfactor without the df factor: d theta / d x = 1 - exp(-theta)."""
+    theta = np.asarray(theta, dtype=np.float64)
+    return np.where(theta > _LOGEXP_LIM, 1.0, -np.expm1(-theta))
+
+
 def _column(values, n, what):
     """A reference closure returns (k,1) (DoCalculus.py:66); accept (k,), (k,1) or a scalar."""
     v = np.asarray(values, dtype=np.float64)
@@ -330,10 +357,12 @@ class HipGaussianProcess:
         self._last_lml = lml.value
         return dv.value, dls, dn.value
 
-    def _objective(self, log_theta):
-        """(negative log marginal likelihood, its gradient) at exp(log_theta) = [variance, lengthscale(s), (noise)],
-        the gradient taken with respect to log_theta."""
-        theta = np.exp(log_theta)
+    def _objective(self, x, transform="log"):
+        """(negative log marginal likelihood, its gradient with respect to x) at theta(x) = [variance, lengthscale(s),
+        (noise)]: ``transform="logexp"``: theta = log(1 + exp(x)), paramz's ``Model._objective_grads`` with
+        ``_transform_gradients`` (gradient times 1 - exp(-theta)); ``"log"``: theta = exp(x)."""
+        x = np.asarray(x, dtype=np.float64)
+        theta = logexp_f(x) if transform == "logexp" else np.exp(x)
         nl = self.lengthscale.size
         noise = self.noise_var if self.fix_noise else theta[1 + nl]
         try:
@@ -342,30 +371,41 @@ class HipGaussianProcess:
                 self.set_hyperparameters(theta[0], theta[1:1 + nl], noise, fit=not self.small)
             dv, dls, dn = self.log_likelihood_gradients()
         except np.linalg.LinAlgError:
-            return 1e25, np.zeros_like(log_theta)      # GPy's optimiser treats a failed Cholesky as a rejected step
-        g = [dv * theta[0], *(dls * theta[1:1 + nl])] + ([] if self.fix_noise else [dn * noise])
-        return -self._last_lml, -np.asarray(g, dtype=np.float64)
+            # paramz hands the optimiser inf and the clipped gradient of the last good point (and gives up after ten such
+            # evaluations in a row); a large finite value keeps scipy's line search defined and is rejected the same way
+            return 1e25, np.zeros_like(x)
+        g = np.asarray([dv, *dls] + ([] if self.fix_noise else [dn]), dtype=np.float64)
+        g = g * (logexp_gradfactor(theta) if transform == "logexp" else theta)
+        return -self._last_lml, -g
 
-    def optimize(self, max_iters=1000, **kwargs):
-        """Hyper-parameter MLE (emukit ``GPyModelWrapper.optimize`` -> GPy ``optimize_restarts(1)``, src/CBO.py:173;
-        ``gp.optimize()`` in src/utils_functions/utils.py:44): maximise the log marginal likelihood over kernel
-        variance, lengthscale(s) and -- unless fixed, as for graph-level GPs -- the noise variance.  Host logic:
-        scipy L-BFGS-B (GPy's default optimiser) in log-parameter space; every evaluation is a device refit plus the
-        device likelihood and its analytic gradients.  GPy optimises through a softplus transform; the optimum is
-        the same stationary point, reached to optimiser tolerance."""
-        from scipy.optimize import minimize
-        x0 = [self.variance, *self.lengthscale]
+    def optimize(self, max_iters=1000, transform="logexp", **kwargs):
+        """Hyper-parameter MLE (emukit ``GPyModelWrapper.optimize`` -> GPy ``optimize_restarts(1, robust=True)`` -- one run from
+        the current parameters, nothing drawn --, src/CBO.py:173; ``gp.optimize()`` in src/utils_functions/utils.py:44):
+        maximise the log marginal likelihood over kernel variance, lengthscale(s) and -- unless fixed, as for graph-level
+        GPs -- the noise variance.  Host logic, as paramz has it (``Model.optimize`` -> ``opt_lbfgsb.opt``):
+        ``scipy.optimize.fmin_l_bfgs_b(f_fp, x0, maxfun=max_iters, maxiter=max_iters)`` on the Logexp-transformed
+        parameters from ``x0 = finv(theta0)``, the model left at the routine's ``x_opt``.  Every evaluation is a device
+        refit plus the device likelihood and its analytic gradients.  ``transform="log"`` is rounds 1-4's parametrisation
+        (theta = exp(x), same stationary point, another path to it).  GPy is not installed here: the trajectory is GPy's
+        by construction, not by comparison (parity unpinned)."""
+        from scipy.optimize import OptimizeResult, fmin_l_bfgs_b
+        if transform not in ("logexp", "log"):
+            raise ValueError("transform must be 'logexp' (GPy / paramz) or 'log'")
+        theta0 = [self.variance, *self.lengthscale]
         if not self.fix_noise:
-            x0.append(self.noise_var)
-        x0 = np.log(np.asarray(x0, dtype=np.float64))
-        f0 = self._objective(x0)[0]
-        res = minimize(self._objective, x0, jac=True, method="L-BFGS-B",
-                       options={"maxiter": int(max_iters), "maxfun": 15000})
-        best = res.x if res.fun <= f0 else x0
-        if self._objective(best)[0] >= 1e25:  # the factorisation failed at the point the optimiser settled on
-            theta0 = np.exp(x0)               # (GPy restores the previous parameters after a failed step): back to the
-            nl = self.lengthscale.size        # starting point, which was fitted before the optimisation began
-            self.set_hyperparameters(theta0[0], theta0[1:1 + nl], self.noise_var if self.fix_noise else theta0[1 + nl])
+            theta0.append(self.noise_var)
+        theta0 = np.asarray(theta0, dtype=np.float64)
+        x0 = logexp_finv(theta0) if transform == "logexp" else np.log(theta0)
+        x_opt, f_opt, info = fmin_l_bfgs_b(lambda x: self._objective(x, transform), x0, maxfun=int(max_iters),
+                                           maxiter=int(max_iters))
+        f_opt = self._objective(x_opt, transform)[0]          # opt_lbfgsb: f_opt = f_fp(x_opt)[0]; the model sits at x_opt
+        if f_opt >= 1e25:                     # the factorisation failed at the point the optimiser settled on
+            nl = self.lengthscale.size        # (GPy restores the previous parameters after a failed step): back to the
+            self.set_hyperparameters(theta0[0], theta0[1:1 + nl],      # starting point, which was fitted before
+                                     self.noise_var if self.fix_noise else theta0[1 + nl])
+        res = OptimizeResult(x=x_opt, fun=f_opt, jac=info["grad"], nfev=info["funcalls"], nit=info["nit"],
+                             status=info["warnflag"], message=info["task"], success=info["warnflag"] == 0,
+                             transform=transform)
         self.optimization_result = res
         return res
 

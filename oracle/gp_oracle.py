@@ -229,18 +229,45 @@ def log_marginal_likelihood_gradients(post):
     return d_var, d_ls, float(np.trace(dL_dK))
 
 
+# paramz ``transformations.Logexp`` (paramz~=0.9.5, /root/reference/requirements.txt:9; not installed: restated from its published
+# source): f(x) = where(x > 36, x, log1p(exp(clip(x, -log(DBL_MAX), 36)))), finv(f) = where(f > 36, f, log(expm1(f))),
+# gradfactor(f, df) = df * where(f > 36, 1, -expm1(-f)).  GPy constrains RBF.variance, RBF.lengthscale and Gaussian.variance with it.
+LOGEXP_LIM = 36.0
+LOGEXP_LOG_LIM = float(np.log(np.finfo(np.float64).max))
+
+
+def logexp_f(x):
+    x = np.asarray(x, dtype=np.float64)
+    return np.where(x > LOGEXP_LIM, x, np.log1p(np.exp(np.clip(x, -LOGEXP_LOG_LIM, LOGEXP_LIM))))
+
+
+def logexp_finv(f):
+    f = np.asarray(f, dtype=np.float64)
+    with np.errstate(over="ignore"):
+        return np.where(f > LOGEXP_LIM, f, np.log(np.expm1(f)))
+
+
+def logexp_gradfactor(f):
+    f = np.asarray(f, dtype=np.float64)
+    return np.where(f > LOGEXP_LIM, 1.0, -np.expm1(-f))
+
+
 def optimize_hyperparameters(X, y, mX=None, vX=None, variance=REF_VARIANCE, lengthscale=REF_LENGTHSCALE,
-                             noise_var=REF_NOISE_VAR, fix_noise=False, max_iters=1000):
-    """Counterpart of GPy ``model.optimize()`` (src/CBO.py:173, src/utils_functions/utils.py:44) for the
-    product's host-side optimiser: same objective and analytic gradients, same scipy L-BFGS-B call in
-    log-parameter space.  (GPy itself optimises through a softplus transform -- not reproducible here,
-    'parity unpinned'.)  Returns (variance, lengthscale array, noise_var, lml)."""
-    from scipy.optimize import minimize
+                             noise_var=REF_NOISE_VAR, fix_noise=False, max_iters=1000, transform="logexp", info=None):
+    """GPy ``model.optimize()`` (src/CBO.py:173 through emukit's ``optimize_restarts(1)``: one run from the current
+    parameters; src/utils_functions/utils.py:44) as paramz runs it: ``Model.optimize`` -> ``opt_lbfgsb.opt`` =
+    ``scipy.optimize.fmin_l_bfgs_b(f_fp, x_init, maxfun=max_iters, maxiter=max_iters)`` with x the Logexp-transformed
+    parameters [rbf.variance, rbf.lengthscale(s), Gaussian_noise.variance (unless fixed)], x_init = finv(current values),
+    f_fp = ``Model._objective_grads`` = (-log likelihood, -gradient * gradfactor), the model left at x_opt.
+    ``transform="log"``: rounds 1-4's parametrisation (theta = exp x).  GPy is not installed: 'parity unpinned'.
+    Returns (variance, lengthscale array, noise_var, lml); ``info`` (a dict) receives funcalls / nit / warnflag."""
+    from scipy.optimize import fmin_l_bfgs_b
     ls0 = np.atleast_1d(np.asarray(lengthscale, dtype=np.float64))
     nl = ls0.size
+    to_theta = logexp_f if transform == "logexp" else np.exp
 
     def unpack(x):
-        th = np.exp(x)
+        th = to_theta(np.asarray(x, dtype=np.float64))
         return th[0], (th[1] if nl == 1 else th[1:1 + nl]), (noise_var if fix_noise else th[1 + nl])
 
     def f(x):
@@ -248,14 +275,19 @@ def optimize_hyperparameters(X, y, mX=None, vX=None, variance=REF_VARIANCE, leng
         try:
             post = fit(X, y, mX, vX, v, l, nz)
         except np.linalg.LinAlgError:
-            return 1e25, np.zeros_like(x)
+            return 1e25, np.zeros_like(x)      # (paramz: inf and the last gradient, clipped; finite here for scipy's line search)
         d_var, d_ls, d_noise = log_marginal_likelihood_gradients(post)
-        g = [d_var * v, *(d_ls * np.atleast_1d(l))] + ([] if fix_noise else [d_noise * nz])   # d/dlog(theta)
-        return -log_marginal_likelihood(post), -np.asarray(g, dtype=np.float64)
+        g = np.asarray([d_var, *np.atleast_1d(d_ls)] + ([] if fix_noise else [d_noise]), dtype=np.float64)
+        th = to_theta(np.asarray(x, dtype=np.float64))
+        g = g * (logexp_gradfactor(th) if transform == "logexp" else th)          # _transform_gradients / d theta / d log theta
+        return -log_marginal_likelihood(post), -g
 
-    x0 = np.log(np.asarray([variance, *ls0] + ([] if fix_noise else [noise_var]), dtype=np.float64))
-    res = minimize(f, x0, jac=True, method="L-BFGS-B", options={"maxiter": int(max_iters), "maxfun": 15000})
-    best = res.x if res.fun <= f(x0)[0] else x0
+    th0 = np.asarray([variance, *ls0] + ([] if fix_noise else [noise_var]), dtype=np.float64)
+    x0 = logexp_finv(th0) if transform == "logexp" else np.log(th0)
+    x_opt, _, d = fmin_l_bfgs_b(f, x0, maxfun=int(max_iters), maxiter=int(max_iters))
+    if info is not None:
+        info.update(funcalls=d["funcalls"], nit=d["nit"], warnflag=d["warnflag"])
+    best = x_opt if f(x_opt)[0] < 1e25 else x0
     v, l, nz = unpack(best)
     return float(v), np.atleast_1d(l), float(nz), -f(best)[0]
 

@@ -320,3 +320,65 @@ def test_schedule_tuner_settles_near_the_best_candidate_on_a_simulated_device(tm
     assert drift[:3] == ["6", "6", "0"] and int(drift[3]) >= 1, drift
     # the per-context table of shapes is bounded
     assert int(subprocess.check_output([str(exe), "bounded"], text=True)) == 64
+
+
+def test_logexp_transform_and_the_optimizer_call_are_paramz_s():
+    """``model.optimize()`` (src/CBO.py:173, src/utils_functions/utils.py:44) is host logic over the device's likelihood and
+    gradients: paramz's Logexp parametrisation (closed forms; the product's and the oracle's restatements agree) and the
+    optimiser call (``fmin_l_bfgs_b(f_fp, finv(theta0), maxfun=max_iters, maxiter=max_iters)``, model left at x_opt).  The
+    method is driven here with the ORACLE's likelihood in the device's place (no GPU): its trajectory must then be the
+    oracle optimiser's, evaluation for evaluation."""
+    from types import SimpleNamespace
+    import importlib
+    F = importlib.import_module("cbo_with_oop_amd.GaussianProcessFactory")     # (the package re-exports the class under this name)
+    x = np.array([-800.0, -720.0, -30.0, -1.0, 0.0, 1.0, 35.0, 36.0, 36.5, 800.0])
+    th = F.logexp_f(x)
+    assert np.array_equal(th, O.logexp_f(x)) and np.all(th > 0)
+    assert np.array_equal(th[x > 36], x[x > 36])                                 # identity above the limit
+    mid = (x >= -30) & (x <= 36)
+    assert np.allclose(th[mid], np.log1p(np.exp(x[mid])), rtol=1e-15)
+    assert np.allclose(F.logexp_finv(th[mid]), x[mid], rtol=0, atol=1e-9)         # round trip
+    assert np.array_equal(F.logexp_finv(th), O.logexp_finv(th))
+    assert np.array_equal(F.logexp_gradfactor(th), O.logexp_gradfactor(th))
+    xs = np.linspace(-20, 30, 101)
+    fd = (F.logexp_f(xs + 1e-6) - F.logexp_f(xs - 1e-6)) / 2e-6                   # d theta / d x = 1 - exp(-theta)
+    assert np.allclose(F.logexp_gradfactor(F.logexp_f(xs)), fd, rtol=1e-6, atol=1e-12)
+    assert F.logexp_finv(np.array([1.0]))[0] == np.log(np.expm1(1.0))           # the reference's initial parameters
+
+    rng = np.random.default_rng(5)
+    X = rng.uniform(-4, 4, (40, 2))
+    y = np.sin(1.3 * X[:, :1]) * np.cos(0.7 * X[:, 1:]) + 0.05 * rng.standard_normal((40, 1))
+
+    def stand_in(fix_noise, ls0, noise0):
+        m = SimpleNamespace(variance=1.0, lengthscale=np.atleast_1d(np.asarray(ls0, dtype=np.float64)), noise_var=noise0,
+                            fix_noise=fix_noise, small=True, _last_lml=None, calls=0)
+        def set_hyperparameters(v, ls, nz, fit=True):
+            m.variance, m.lengthscale, m.noise_var = float(v), np.atleast_1d(np.asarray(ls, dtype=np.float64)), float(nz)
+        def log_likelihood_gradients():
+            m.calls += 1
+            ls = m.lengthscale if m.lengthscale.size > 1 else float(m.lengthscale[0])
+            post = O.fit(X, y, None, None, m.variance, ls, m.noise_var)
+            m._last_lml = O.log_marginal_likelihood(post)
+            dv, dls, dn = O.log_marginal_likelihood_gradients(post)
+            return dv, np.atleast_1d(dls), dn
+        m.set_hyperparameters, m.log_likelihood_gradients = set_hyperparameters, log_likelihood_gradients
+        m._objective = lambda x, transform="log": F.HipGaussianProcess._objective(m, x, transform)
+        return m
+
+    for transform in ("logexp", "log"):
+        for fix_noise, ls0, noise0 in ((False, 1.0, 1e-10), (True, np.ones(2), 1e-2)):
+            m = stand_in(fix_noise, ls0, noise0)
+            res = F.HipGaussianProcess.optimize(m, transform=transform)
+            info = {}
+            v, ls, nz, lml = O.optimize_hyperparameters(X, y, variance=1.0, lengthscale=ls0, noise_var=noise0,
+                                                        fix_noise=fix_noise, transform=transform, info=info)
+            assert res.nfev == info["funcalls"] and res.nit == info["nit"] and res.success
+            assert m.calls == res.nfev + 1                                        # + opt_lbfgsb's f_fp(x_opt)
+            assert (m.variance, m.noise_var) == (v, nz) and np.array_equal(m.lengthscale, ls)     # the model sits at x_opt
+            assert -res.fun == lml and res.transform == transform
+    # the two parametrisations reach the same stationary point by different paths
+    a, b = stand_in(False, 1.0, 1e-10), stand_in(False, 1.0, 1e-10)
+    F.HipGaussianProcess.optimize(a), F.HipGaussianProcess.optimize(b, transform="log")
+    assert np.isclose(a.variance, b.variance, rtol=1e-3) and np.allclose(a.lengthscale, b.lengthscale, rtol=1e-3)
+    with pytest.raises(ValueError):
+        F.HipGaussianProcess.optimize(a, transform="softplus")

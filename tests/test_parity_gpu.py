@@ -492,14 +492,23 @@ def test_optimize_reaches_the_oracle_optimum(hip):
     y = np.sin(1.3 * X[:, :1]) * np.cos(0.7 * X[:, 1:]) + 0.05 * rng.standard_normal((60, 1))
     m = GaussianProcessFactory.create(GaussianProcessType.NON_CAUSAL_GP, X, y, None, emukit_wrapper=True)
     l0 = m.log_likelihood()
-    m.optimize()
-    v, ls, nz, lml = O.optimize_hyperparameters(X, y)
+    res = m.optimize()                       # paramz's call: L-BFGS-B on the Logexp-transformed parameters (the default)
+    info = {}
+    v, ls, nz, lml = O.optimize_hyperparameters(X, y, info=info)
+    assert res.transform == "logexp" and res.success and info["warnflag"] == 0
+    assert abs(res.nfev - info["funcalls"]) <= 5, (res.nfev, info)       # the same path to rounding of the gradients
     assert m.log_likelihood() > l0 + 1.0
     assert np.isclose(m.log_likelihood(), lml, rtol=1e-5, atol=1e-4)
     assert np.isclose(m.variance, v, rtol=2e-2) and np.allclose(m.lengthscale, ls, rtol=2e-2)
     mean, var = m.predict(X[:5])
     mu, vv = O.predict(O.fit(X, y, variance=m.variance, lengthscale=float(m.lengthscale[0]), noise_var=m.noise_var), X[:5])
     assert np.allclose(mean, mu, rtol=1e-6, atol=1e-8) and np.allclose(var, vv, rtol=1e-5)
+    # rounds 1-4's parametrisation (theta = exp x) stays selectable: same stationary point
+    m2 = GaussianProcessFactory.create(GaussianProcessType.NON_CAUSAL_GP, X, y, None, emukit_wrapper=True)
+    assert m2.optimize(transform="log").transform == "log"
+    v2, ls2, nz2, lml2 = O.optimize_hyperparameters(X, y, transform="log")
+    assert np.isclose(m2.log_likelihood(), lml2, rtol=1e-5, atol=1e-4) and np.isclose(m2.log_likelihood(), lml, rtol=1e-5, atol=1e-4)
+    assert np.isclose(m2.variance, v2, rtol=2e-2) and np.allclose(m2.lengthscale, ls2, rtol=2e-2)
     # graph-level GP: ARD lengthscales, noise fixed at 1e-2 (src/utils_functions/utils.py:40-45)
     Xg = rng.uniform(-2, 2, (80, 3))
     yg = (np.cos(Xg[:, 0]) + 0.5 * Xg[:, 1])[:, None] + 0.1 * rng.standard_normal((80, 1))
